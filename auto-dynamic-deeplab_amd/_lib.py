@@ -1,0 +1,151 @@
+"""ctypes binding of libaddk.so (the C ABI declared in include/addk.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+symbol is absent, importing/using `addk` raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libaddk.so')
+
+MAX_SRC, MAX_SLAB, MAX_TERMS = 12, 32, 4
+fp = C.POINTER(C.c_float)
+i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class Src(C.Structure):
+    _fields_ = [('x', vp), ('a', vp), ('b', vp), ('ld', i32), ('C', i32), ('relu', i32), ('_pad', i32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('src', Src * MAX_SRC), ('nsrc', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('Cout', i32), ('ldw', i32),
+                ('cin_total', i32), ('w_choff', i32), ('ldy', i32), ('w', vp), ('y', vp), ('bias', vp), ('bias_n', vp),
+                ('stats', vp), ('stats_ld', i32), ('_pad', i32)]
+
+
+class ConvDgradArgs(C.Structure):
+    _fields_ = [('dy', vp), ('lddy', i32), ('Cout', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('w', vp), ('ldw', i32),
+                ('cin_total', i32), ('w_choff', i32), ('dst', Src), ('g', vp), ('ldg', i32), ('accumulate', i32),
+                ('dab', vp)]
+
+
+class ConvWgradArgs(C.Structure):
+    _fields_ = [('dy', vp), ('lddy', i32), ('Cout', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('src', Src), ('dw', vp),
+                ('ldw', i32), ('cin_total', i32), ('w_choff', i32), ('accumulate', i32), ('ws', vp), ('ws_floats', i64)]
+
+
+class DwArgs(C.Structure):
+    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32), ('KH', i32), ('KW', i32),
+                ('stride', i32), ('pad', i32), ('dil', i32), ('w', vp), ('y', vp), ('ldy', i32)]
+
+
+class DwBwdArgs(C.Structure):
+    _fields_ = [('dy', vp), ('lddy', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32), ('KH', i32),
+                ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('src', Src), ('w', vp), ('g', vp), ('ldg', i32),
+                ('accumulate', i32), ('dab', vp), ('dw', vp), ('dw_accumulate', i32), ('ws', vp)]
+
+
+class BnFinalizeArgs(C.Structure):
+    _fields_ = [('partial', vp), ('rows', i32), ('C', i32), ('count', f64), ('gamma', vp), ('beta', vp),
+                ('running_mean', vp), ('running_var', vp), ('momentum', f32), ('eps', f32), ('a', vp), ('b', vp),
+                ('mean', vp), ('invstd', vp)]
+
+
+class BnBwdArgs(C.Structure):
+    _fields_ = [('slab', vp * MAX_SLAB), ('rows', i32 * MAX_SLAB), ('nslab', i32), ('C', i32), ('count', f64),
+                ('gamma', vp), ('mean', vp), ('invstd', vp), ('a', vp), ('dgamma', vp), ('dbeta', vp),
+                ('accumulate', i32), ('c1', vp), ('c2', vp), ('dmv', vp)]
+
+
+class AffineSumArgs(C.Structure):
+    _fields_ = [('term', Src * MAX_TERMS), ('nterm', i32), ('P', i64), ('C', i32), ('out', vp), ('ldo', i32),
+                ('relu_out', i32), ('accumulate', i32)]
+
+
+class AffineSumBwdArgs(C.Structure):
+    _fields_ = [('term', Src * MAX_TERMS), ('nterm', i32), ('P', i64), ('C', i32), ('dout', vp), ('lddo', i32),
+                ('out', vp), ('ldo', i32), ('relu_out', i32), ('g', vp * MAX_TERMS), ('ldg', i32 * MAX_TERMS),
+                ('accumulate', i32 * MAX_TERMS), ('dab', vp * MAX_TERMS)]
+
+
+class ResizeArgs(C.Structure):
+    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32), ('y', vp), ('ldy', i32),
+                ('nchw_out', i32)]
+
+
+class ResizeBwdArgs(C.Structure):
+    _fields_ = [('dy', vp), ('lddy', i32), ('nchw_in', i32), ('dy_scale', vp), ('src', Src), ('N', i32), ('H', i32),
+                ('W', i32), ('OH', i32), ('OW', i32), ('g', vp), ('ldg', i32), ('accumulate', i32), ('dab', vp)]
+
+
+_SIGS = {
+    'addk_last_error': (C.c_char_p, []),
+    'addk_version': (i32, []),
+    'addk_selftest_mfma': (i32, [vp, vp]),
+    'addk_conv_fwd': (i32, [C.POINTER(ConvArgs), vp]),
+    'addk_conv_rows': (i32, [i64, i32]),
+    'addk_conv_dgrad': (i32, [C.POINTER(ConvDgradArgs), vp]),
+    'addk_conv_wgrad': (i32, [C.POINTER(ConvWgradArgs), vp]),
+    'addk_conv_wgrad_ws': (i64, [i64, i32, i32, i32]),
+    'addk_dw_fwd': (i32, [C.POINTER(DwArgs), vp]),
+    'addk_dw_bwd': (i32, [C.POINTER(DwBwdArgs), vp]),
+    'addk_dw_rows': (i32, [i64, i32]),
+    'addk_bn_finalize': (i32, [C.POINTER(BnFinalizeArgs), vp]),
+    'addk_slab_reduce': (i32, [vp, i32, i32, vp, vp]),
+    'addk_bn_eval_affine': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
+    'addk_bn_bwd': (i32, [C.POINTER(BnBwdArgs), vp]),
+    'addk_bn_bwd_coeffs_from_dmv': (i32, [vp, i32, f64, vp, vp, vp]),
+    'addk_affine_sum_fwd': (i32, [C.POINTER(AffineSumArgs), vp]),
+    'addk_affine_sum_bwd': (i32, [C.POINTER(AffineSumBwdArgs), vp]),
+    'addk_ew_rows': (i32, [i64, i32]),
+    'addk_bn_bwd_apply': (i32, [vp, i32, vp, i32, vp, vp, vp, i64, i32, vp, i32, vp]),
+    'addk_resize_fwd': (i32, [C.POINTER(ResizeArgs), vp]),
+    'addk_resize_bwd': (i32, [C.POINTER(ResizeBwdArgs), vp]),
+    'addk_gap_fwd': (i32, [C.POINTER(Src), i32, i32, vp, i32, vp, i32, vp]),
+    'addk_gap_bwd': (i32, [C.POINTER(Src), i32, i32, vp, i32, vp, i32, i32, vp, vp]),
+    'addk_pool3_fwd': (i32, [C.POINTER(Src), i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    'addk_pool3_bwd': (i32, [C.POINTER(Src), i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp]),
+    'addk_nchw_to_nhwc': (i32, [vp, i32, i32, i64, vp, i32, vp]),
+    'addk_nhwc_to_nchw': (i32, [C.POINTER(Src), i32, i64, vp, vp]),
+    'addk_nchw_grad_to_nhwc': (i32, [vp, C.POINTER(Src), i32, i64, vp, i32, i32, vp, vp]),
+    'addk_ce_count': (i32, [vp, i64, vp, i32, i32, vp, vp, vp]),
+    'addk_ce_fwd_bwd': (i32, [vp, vp, i32, i32, i64, vp, i32, vp, f32, vp, vp, vp, vp]),
+    'addk_ce_ws_floats': (i64, [i32, i64]),
+    'addk_sgd_step': (i32, [vp, vp, vp, i64, vp, f32, f32, i32, i32, f32, vp]),
+    'addk_fill': (i32, [vp, i64, f32, vp]),
+    'addk_entropy_sum': (i32, [vp, i32, i32, i64, vp, vp, vp]),
+    'addk_argmax_nchw': (i32, [vp, i32, i32, i64, vp, vp]),
+    'addk_confusion': (i32, [vp, vp, i64, i32, vp, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+_lib = None
+
+
+class AddkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libaddk.so and bind every declared symbol.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AddkError('libaddk.so not found at %s — run `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(hipcc --offload-arch=gfx950).  addk has no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise AddkError('%s failed (%d): %s' % (what or 'addk call', rc, load().addk_last_error().decode()))

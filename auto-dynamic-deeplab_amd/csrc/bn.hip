@@ -1,0 +1,136 @@
+// BatchNorm statistics kernels (F.batch_norm training mode at every BatchNorm(...) call site of
+// the path: operations.py:25,39,54,58,93; ADD.py:156,162,168,258; aspp_train.py:27-32; decoder.py:15,19).
+// They only touch [rows][C][2] partial slabs written by the producing kernels and C-length vectors;
+// sums are carried in fp64 so that the E[x^2]-E[x]^2 form stays accurate.
+#include "common.h"
+
+namespace {
+
+// block = 32 channels x 32 row groups; result (sum0, sum1) per channel for threads with rg == 0
+__device__ __forceinline__ void slab_sum(const float* slab, int rows, int C, int c, int rg, double& s0, double& s1,
+                                         double (*sh)[32][2]) {
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int r = rg; r < rows; r += 32) {
+      float2 v = *reinterpret_cast<const float2*>(slab + ((long)r * C + c) * 2);
+      a += v.x; b += v.y;
+    }
+  const int cl = threadIdx.x & 31;
+  sh[rg][cl][0] = a; sh[rg][cl][1] = b;
+  __syncthreads();
+  for (int s = 16; s > 0; s >>= 1) {
+    if (rg < s) { sh[rg][cl][0] += sh[rg + s][cl][0]; sh[rg][cl][1] += sh[rg + s][cl][1]; }
+    __syncthreads();
+  }
+  s0 = sh[0][cl][0]; s1 = sh[0][cl][1];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finalize_args p) {
+  __shared__ double sh[32][32][2];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s0, s1;
+  slab_sum(p.partial, p.rows, p.C, c, rg, s0, s1, sh);
+  if (rg == 0 && c < p.C) {
+    double mean = s0 / p.count;
+    double var = s1 / p.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double invstd = 1.0 / sqrt(var + (double)p.eps);
+    float g = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+    float a = (float)(g * invstd);
+    p.a[c] = a;
+    p.b[c] = (float)(be - mean * (g * invstd));
+    if (p.mean) p.mean[c] = (float)mean;
+    if (p.invstd) p.invstd[c] = (float)invstd;
+    if (p.running_mean) {
+      double unb = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+      p.running_mean[c] = (float)((1.0 - p.momentum) * p.running_mean[c] + p.momentum * mean);
+      p.running_var[c] = (float)((1.0 - p.momentum) * p.running_var[c] + p.momentum * unb);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) slab_reduce_kernel(const float* slab, int rows, int C, float* out) {
+  __shared__ double sh[32][32][2];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s0, s1;
+  slab_sum(slab, rows, C, c, rg, s0, s1, sh);
+  if (rg == 0 && c < C) { out[2 * c] = (float)s0; out[2 * c + 1] = (float)s1; }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* a, float* b) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    float s = g / sqrtf(rv[c] + eps);
+    a[c] = s; b[c] = be - rm[c] * s;
+  }
+}
+
+__global__ void __launch_bounds__(1024) bn_bwd_kernel(const addk_bn_bwd_args p) {
+  __shared__ double sh[32][32][2];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double dA = 0.0, dB = 0.0;
+  for (int k = 0; k < p.nslab; ++k) {
+    double s0, s1;
+    slab_sum(p.slab[k], p.rows[k], p.C, c, rg, s0, s1, sh);
+    dA += s0; dB += s1;
+  }
+  if (rg == 0 && c < p.C) {
+    double mean = p.mean[c], invstd = p.invstd[c], gamma = p.gamma ? p.gamma[c] : 1.0, a = p.a[c];
+    double t = dA - mean * dB;
+    double dgamma = invstd * t, dbeta = dB;
+    double dvar = -0.5 * gamma * t * invstd * invstd * invstd;
+    double dmean_tot = -a * dB - 2.0 * mean * dvar;
+    if (p.dgamma) p.dgamma[c] = (float)((p.accumulate ? (double)p.dgamma[c] : 0.0) + dgamma);
+    if (p.dbeta) p.dbeta[c] = (float)((p.accumulate ? (double)p.dbeta[c] : 0.0) + dbeta);
+    if (p.dmv) { p.dmv[2 * c] = (float)dmean_tot; p.dmv[2 * c + 1] = (float)dvar; }
+    if (p.c1) { p.c1[c] = (float)(dmean_tot / p.count); p.c2[c] = (float)(2.0 * dvar / p.count); }
+  }
+}
+
+__global__ void bn_coeffs_kernel(const float* dmv, int C, double count, float* c1, float* c2) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { c1[c] = (float)((double)dmv[2 * c] / count); c2[c] = (float)(2.0 * (double)dmv[2 * c + 1] / count); }
+}
+
+}  // namespace
+
+extern "C" int addk_bn_finalize(const addk_bn_finalize_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->partial && a->a && a->b && a->C > 0 && a->rows > 0 && a->count > 0, "bn_finalize: bad args");
+  ADDK_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "bn_finalize: running stats come together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 32)), dim3(1024), 0, (hipStream_t)stream, *a);
+  return addk_check_launch("bn_finalize");
+}
+
+extern "C" int addk_slab_reduce(const float* partial, int32_t rows, int32_t C, float* out, void* stream) {
+  ADDK_REQUIRE(partial && out && rows > 0 && C > 0, "slab_reduce: bad args");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, partial, rows, C, out);
+  return addk_check_launch("slab_reduce");
+}
+
+extern "C" int addk_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                   int32_t C, float* a, float* b, void* stream) {
+  ADDK_REQUIRE(rm && rv && a && b && C > 0, "bn_eval_affine: bad args");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, C, a, b);
+  return addk_check_launch("bn_eval_affine");
+}
+
+extern "C" int addk_bn_bwd(const addk_bn_bwd_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->nslab >= 0 && a->nslab <= ADDK_MAX_SLAB && a->C > 0 && a->count > 0, "bn_bwd: bad args");
+  ADDK_REQUIRE(a->mean && a->invstd && a->a, "bn_bwd: saved statistics missing");
+  ADDK_REQUIRE((a->c1 == nullptr) == (a->c2 == nullptr) && (a->c1 || a->dmv), "bn_bwd: need c1/c2 or dmv");
+  for (int i = 0; i < a->nslab; ++i) ADDK_REQUIRE(a->slab[i] && a->rows[i] > 0, "bn_bwd: bad slab %d", i);
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(a->C, 32)), dim3(1024), 0, (hipStream_t)stream, *a);
+  return addk_check_launch("bn_bwd");
+}
+
+extern "C" int addk_bn_bwd_coeffs_from_dmv(const float* dmv, int32_t C, double count, float* c1, float* c2, void* stream) {
+  ADDK_REQUIRE(dmv && c1 && c2 && C > 0 && count > 0, "bn_bwd_coeffs: bad args");
+  hipLaunchKernelGGL(bn_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dmv, C, count, c1, c2);
+  return addk_check_launch("bn_bwd_coeffs");
+}

@@ -1,0 +1,72 @@
+// Shared device/host helpers for the addk gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "addk.h"
+
+void addk_set_error(const char* fmt, ...);
+int addk_check_launch(const char* what);
+
+#define ADDK_REQUIRE(cond, ...)                    \
+  do {                                             \
+    if (!(cond)) {                                 \
+      addk_set_error(__VA_ARGS__);                 \
+      return ADDK_ERR_INVALID;                     \
+    }                                              \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// A source can use 16-byte accesses when its base, pixel stride and channel count allow it.
+static inline bool src_vec_ok(const addk_src& s) {
+  return aligned16(s.x) && (s.ld % 4 == 0) && (s.C % 4 == 0) && (!s.a || aligned16(s.a)) && (!s.b || aligned16(s.b));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// guarded 4-element load: elements with index >= n read as 0
+__device__ __forceinline__ float4 ld4g(const float* p, int n, bool vec) {
+  if (vec && n >= 4) return ld4(p);
+  float4 v = zero4();
+  if (n > 0) v.x = p[0];
+  if (n > 1) v.y = p[1];
+  if (n > 2) v.z = p[2];
+  if (n > 3) v.w = p[3];
+  return v;
+}
+__device__ __forceinline__ void st4g(float* p, float4 v, int n, bool vec) {
+  if (vec && n >= 4) { st4(p, v); return; }
+  if (n > 0) p[0] = v.x;
+  if (n > 1) p[1] = v.y;
+  if (n > 2) p[2] = v.z;
+  if (n > 3) p[3] = v.w;
+}
+
+// lazy prologue z = relu?(a*x+b) on 4 channels; lanes >= n stay 0
+__device__ __forceinline__ float4 prologue4(float4 x, const float* a, const float* b, int c, int n, bool relu, bool vec) {
+  if (a) {
+    float4 av = ld4g(a + c, n, vec), bv = ld4g(b + c, n, vec);
+    x.x = fmaf(av.x, x.x, bv.x); x.y = fmaf(av.y, x.y, bv.y);
+    x.z = fmaf(av.z, x.z, bv.z); x.w = fmaf(av.w, x.w, bv.w);
+  }
+  if (relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+  if (n < 4) { if (n < 1) x.x = 0.f; if (n < 2) x.y = 0.f; if (n < 3) x.z = 0.f; x.w = 0.f; }
+  return x;
+}
+
+__device__ __forceinline__ float get4(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ void set4(float4& v, int e, float f) { if (e == 0) v.x = f; else if (e == 1) v.y = f; else if (e == 2) v.z = f; else v.w = f; }
+
+// Thread mapping for channel-reducing elementwise kernels: a 256-thread block is viewed as
+// npl "pixel lanes" x nq channel quads; a thread keeps its quad for the whole kernel so that
+// per-channel sums stay in registers.
+struct EwMap { int nq, npl; };
+static inline EwMap ew_map(int C) {
+  EwMap m; m.nq = (C + 3) / 4; if (m.nq > 256) m.nq = 256; m.npl = 256 / m.nq; if (m.npl < 1) m.npl = 1; return m;
+}

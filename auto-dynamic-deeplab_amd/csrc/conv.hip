@@ -1,0 +1,384 @@
+// Dense convolution forward and data-gradient as one implicit-GEMM kernel on the fp32 matrix
+// cores of gfx950 (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, 64-wide wavefronts).
+//
+//   out[p, n] = sum_{tap, c}  Z[p @ tap, c] * Wt[n][tap][c]
+//
+// M = pixels (tile of 64*PT, 16*PT per wave), N = output channels (tile of 16*CT, shared by the
+// four waves), K = taps x channels walked in chunks of 32 channels of one tap of one source.
+// The MFMA "A" operand is the WEIGHT fragment and the "B" operand the PIXEL fragment, so a
+// lane's four accumulator registers are four consecutive output channels of one pixel and the
+// epilogue stores 16 bytes per lane into the NHWC destination.
+// Input tiles are staged through LDS with the producer's BatchNorm/ReLU applied on the way in
+// (zero padding is applied after that prologue, as in the reference where the conv pads its
+// already-activated input).  Rows are padded to 36 floats: ds_read_b64 fragment reads are
+// bank-conflict free (row*36 mod 64 walks the 16 multiples of 4).
+//
+// Reference call sites: see include/addk.h (addk_conv_fwd / addk_conv_dgrad).
+#include "common.h"
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct ConvK {
+  addk_src src[ADDK_MAX_SRC];
+  int nsrc;
+  int N, H, W;      // A-side tensor spatial size (fwd: input; dgrad: dy)
+  int OH, OW;       // M-side pixel grid        (fwd: output; dgrad: input)
+  int KH, KW, stride, pad, dil;
+  int Cn;           // GEMM N (fwd: Cout; dgrad: channels of dst)
+  int ldw, cin_total, w_choff;
+  int ldy;
+  const float* w;
+  float* y;
+  const float* bias;
+  const float* bias_n;
+  float* slab; int slab_ld;
+  addk_src dst;     // dgrad epilogue
+  int accumulate;
+  int vecA, vecB, vecY;
+  long P;
+  int ntiles;
+};
+
+constexpr int BK = 32;
+constexpr int BKP = 36;
+
+template <int PT, int CT, int MODE>
+__global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
+  constexpr int BP = 64 * PT;
+  constexpr int BC = 16 * CT;
+  constexpr int NAJ = 2 * PT;             // float4 A slots per thread
+  constexpr int NBJ = (CT + 1) / 2;       // float4 B slots per thread
+  __shared__ __attribute__((aligned(16))) float As[BP * BKP];
+  __shared__ __attribute__((aligned(16))) float Bs[BC * BKP];
+  __shared__ float red[4][BC][2];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.y * BC;
+  const int aq = t & 7, ar = t >> 3;
+  const int ntaps = p.KH * p.KW;
+  const long ohw = (long)p.OH * p.OW;
+  float tot0 = 0.f, tot1 = 0.f;
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int rn[NAJ], rh[NAJ], rw[NAJ];
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j) {
+      long pp = (long)tile * BP + ar + 32 * j;
+      if (pp < p.P) {
+        int n = (int)(pp / ohw);
+        int rem = (int)(pp - (long)n * ohw);
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        rn[j] = n;
+        if (MODE == MODE_FWD) { rh[j] = oh * p.stride - p.pad; rw[j] = ow * p.stride - p.pad; }
+        else                  { rh[j] = oh + p.pad;            rw[j] = ow + p.pad; }
+      } else { rn[j] = -1; rh[j] = 0; rw[j] = 0; }
+    }
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[NAJ], rb[NBJ];
+    int s = 0, tap = 0, c0 = 0, choff = 0;
+
+    auto load_chunk = [&](int s_, int tap_, int c0_, int choff_) {
+      const addk_src S = p.src[s_];
+      const int kh = tap_ / p.KW, kw = tap_ - kh * p.KW;
+      const int c = c0_ + 4 * aq;
+      const int nrem = S.C - c;          // valid channels from c on
+#pragma unroll
+      for (int j = 0; j < NAJ; ++j) {
+        float4 v = zero4();
+        if (rn[j] >= 0 && nrem > 0) {
+          int ih, iw; bool ok;
+          if (MODE == MODE_FWD) {
+            ih = rh[j] + kh * p.dil; iw = rw[j] + kw * p.dil;
+            ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          } else {
+            int th = rh[j] - kh * p.dil, tw = rw[j] - kw * p.dil;
+            ok = th >= 0 && tw >= 0;
+            if (p.stride > 1) {
+              ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
+              ih = th / p.stride; iw = tw / p.stride;
+            } else { ih = th; iw = tw; }
+            ok = ok && ih < p.H && iw < p.W;
+          }
+          if (ok) {
+            const float* src = S.x + ((long)(rn[j] * p.H + ih) * p.W + iw) * S.ld + c;
+            v = ld4g(src, nrem, p.vecA);
+            v = prologue4(v, S.a, S.b, c, nrem, S.relu != 0, p.vecA);
+          }
+        }
+        ra[j] = v;
+      }
+      if (MODE == MODE_FWD) {
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+          int slot = t + 256 * j, row = slot >> 3, q = slot & 7;
+          int cc = c0_ + 4 * q, co = n0 + row;
+          float4 v = zero4();
+          if (row < BC && co < p.Cn && cc < S.C) {
+            const float* wp = p.w + (long)co * p.ldw + (long)tap_ * p.cin_total + p.w_choff + choff_ + cc;
+            v = ld4g(wp, S.C - cc, p.vecB);
+          }
+          rb[j] = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+          int slot = t + 256 * j, k = slot / (4 * CT), ng = slot - k * (4 * CT);
+          int co = c0_ + k, ci = n0 + 4 * ng;
+          float4 v = zero4();
+          if (k < BK && co < S.C && ci < p.Cn) {
+            const float* wp = p.w + (long)co * p.ldw + (long)tap_ * p.cin_total + p.w_choff + ci;
+            v = ld4g(wp, p.Cn - ci, p.vecB);
+          }
+          rb[j] = v;
+        }
+      }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+      for (int j = 0; j < NAJ; ++j) st4(&As[(ar + 32 * j) * BKP + 4 * aq], ra[j]);
+      if (MODE == MODE_FWD) {
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+          int slot = t + 256 * j, row = slot >> 3, q = slot & 7;
+          if (row < BC) st4(&Bs[row * BKP + 4 * q], rb[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+          int slot = t + 256 * j, k = slot / (4 * CT), ng = slot - k * (4 * CT);
+          if (k < BK) {
+            Bs[(4 * ng + 0) * BKP + k] = rb[j].x;
+            Bs[(4 * ng + 1) * BKP + k] = rb[j].y;
+            Bs[(4 * ng + 2) * BKP + k] = rb[j].z;
+            Bs[(4 * ng + 3) * BKP + k] = rb[j].w;
+          }
+        }
+      }
+    };
+
+    load_chunk(s, tap, c0, choff);
+    store_chunk();
+    __syncthreads();
+    while (true) {
+      // current chunk extent, then advance the iterator
+      const int Cs = p.src[s].C;
+      const int kc = min(BK, Cs - c0);
+      const int nu = (kc + 7) >> 3;
+      int s2 = s, tap2 = tap, c2 = c0 + BK, ch2 = choff;
+      if (c2 >= Cs) { c2 = 0; ++tap2; if (tap2 == ntaps) { tap2 = 0; ch2 += Cs; ++s2; } }
+      const bool more = s2 < p.nsrc;
+      if (more) load_chunk(s2, tap2, c2, ch2);
+
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < nu) {
+          float2 wf[CT], xf[PT];
+#pragma unroll
+          for (int i = 0; i < CT; ++i)
+            wf[i] = *reinterpret_cast<const float2*>(&Bs[(i * 16 + li) * BKP + 8 * u + 2 * kq]);
+#pragma unroll
+          for (int j = 0; j < PT; ++j)
+            xf[j] = *reinterpret_cast<const float2*>(&As[((wave * PT + j) * 16 + li) * BKP + 8 * u + 2 * kq]);
+#pragma unroll
+          for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].x, xf[j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].y, xf[j].y, acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+      __syncthreads();
+      if (!more) break;
+      s = s2; tap = tap2; c0 = c2; choff = ch2;
+      store_chunk();
+      __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const bool want_red = p.slab != nullptr;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int c = n0 + i * 16 + kq * 4;
+      const int nrem = p.Cn - c;
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        const long pp = (long)tile * BP + (wave * PT + j) * 16 + li;
+        const bool pv = pp < p.P && nrem > 0;
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (MODE == MODE_FWD) {
+          if (pv) {
+            if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.bias_n) {
+              int n = (int)(pp / ohw);
+              float4 b = ld4g(p.bias_n + (long)n * p.Cn + c, nrem, false);
+              v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            st4g(p.y + pp * p.ldy + c, v, nrem, p.vecY);
+            if (want_red) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float f = (e < nrem) ? get4(v, e) : 0.f;
+                s1[e] += f; s2v[e] += f * f;
+              }
+            }
+          }
+        } else {
+          if (pv) {
+            float4 x = ld4g(p.dst.x + pp * p.dst.ld + c, nrem, p.vecY);
+            float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+            if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, p.vecY); bv = ld4g(p.dst.b + c, nrem, p.vecY); }
+            float4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), dz = get4(v, e);
+              bool m = (e < nrem) && (!p.dst.relu || fmaf(ae, xe, be) > 0.f);
+              set4(g, e, m ? dz * ae : 0.f);
+              if (want_red) { s1[e] += m ? dz * xe : 0.f; s2v[e] += m ? dz : 0.f; }
+            }
+            float* gp = p.y + pp * p.ldy + c;
+            if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vecY); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+            st4g(gp, g, nrem, p.vecY);
+          }
+        }
+      }
+      if (want_red) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = s1[e], b = s2v[e];
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+          if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = a; red[wave][i * 16 + kq * 4 + e][1] = b; }
+        }
+      }
+    }
+    if (want_red) {
+      __syncthreads();
+      if (t < BC) {
+        tot0 += red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
+        tot1 += red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
+      }
+      __syncthreads();
+    }
+  }
+  if (p.slab && t < BC && n0 + t < p.Cn) {
+    float* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+    o[0] = tot0; o[1] = tot1;
+  }
+}
+
+int pick_ct(int Cn) {
+  // smallest padding first, larger tiles on ties (fewer re-reads of the pixel tile)
+  const int cands[5] = {8, 5, 4, 3, 2};
+  int best = 2; long best_cost = -1;
+  for (int k = 0; k < 5; ++k) {
+    int ct = cands[k];
+    long cols = (long)cdiv(Cn, 16 * ct) * 16 * ct;
+    if (best_cost < 0 || cols < best_cost) { best_cost = cols; best = ct; }
+  }
+  return best;
+}
+int pick_pt(long P) { return P >= 128L * 512 ? 2 : 1; }
+
+template <int MODE>
+int launch(ConvK& k, hipStream_t st) {
+  const int ct = pick_ct(k.Cn), pt = pick_pt(k.P);
+  const int BP = 64 * pt;
+  k.ntiles = cdiv(k.P, BP);
+  dim3 grid(k.ntiles < 1024 ? k.ntiles : 1024, cdiv(k.Cn, 16 * ct));
+#define ADDK_CASE(PT_, CT_) \
+  if (pt == PT_ && ct == CT_) { hipLaunchKernelGGL((conv_kernel<PT_, CT_, MODE>), grid, dim3(256), 0, st, k); return addk_check_launch("conv"); }
+  ADDK_CASE(1, 2) ADDK_CASE(1, 3) ADDK_CASE(1, 4) ADDK_CASE(1, 5) ADDK_CASE(1, 8)
+  ADDK_CASE(2, 2) ADDK_CASE(2, 3) ADDK_CASE(2, 4) ADDK_CASE(2, 5) ADDK_CASE(2, 8)
+#undef ADDK_CASE
+  addk_set_error("conv: no tile config");
+  return ADDK_ERR_UNSUPPORTED;
+}
+
+__global__ void mfma_selftest_kernel(float* out) {
+  const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+  // A[i][k] = i*4+k  (lane supplies A[li][kq]);  B[k][j] = (k+1)*(j+2) (lane supplies B[kq][li])
+  float a = (float)(li * 4 + kq), b = (float)((kq + 1) * (li + 2));
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[(kq * 4 + r) * 16 + li] = acc[r];   // D[row=kq*4+r][col=li]
+}
+
+}  // namespace
+
+extern "C" int addk_selftest_mfma(float* out256, void* stream) {
+  hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out256);
+  return addk_check_launch("selftest");
+}
+
+extern "C" int addk_conv_rows(int64_t P, int32_t Cout) {
+  (void)Cout;
+  int nt = cdiv(P, 64 * pick_pt(P));
+  return nt < 1024 ? nt : 1024;
+}
+
+extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->nsrc >= 1 && a->nsrc <= ADDK_MAX_SRC, "conv_fwd: nsrc out of range");
+  ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0 && a->Cout > 0, "conv_fwd: empty shape");
+  ADDK_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0 && a->dil > 0, "conv_fwd: bad kernel geometry");
+  ADDK_REQUIRE(a->w && a->y && a->ldy >= a->Cout, "conv_fwd: null/short output");
+  ADDK_REQUIRE(!a->stats || a->stats_ld == 0 || a->stats_ld >= a->Cout, "conv_fwd: stats_ld < Cout");
+  // every output pixel must map inside the padded input (guards against OOB reads by construction:
+  // taps outside [0,H) are masked, so only the geometry of the output grid needs checking)
+  ConvK k;
+  long ctot = 0;
+  k.vecA = 1;
+  for (int i = 0; i < a->nsrc; ++i) {
+    k.src[i] = a->src[i];
+    ADDK_REQUIRE(a->src[i].x && a->src[i].C > 0 && a->src[i].ld >= a->src[i].C, "conv_fwd: bad source %d", i);
+    ADDK_REQUIRE((a->src[i].a == nullptr) == (a->src[i].b == nullptr), "conv_fwd: a/b must come together");
+    if (!src_vec_ok(a->src[i])) k.vecA = 0;
+    ctot += a->src[i].C;
+  }
+  ADDK_REQUIRE(a->w_choff + ctot <= a->cin_total, "conv_fwd: sources exceed cin_total");
+  ADDK_REQUIRE(a->ldw >= a->KH * a->KW * a->cin_total, "conv_fwd: ldw too small");
+  k.nsrc = a->nsrc;
+  k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
+  k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
+  k.Cn = a->Cout; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.ldy = a->ldy;
+  k.w = a->w; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n; k.slab = a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.accumulate = 0; k.dst = addk_src{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  bool chan4 = true;
+  for (int i = 0; i < a->nsrc; ++i) chan4 = chan4 && (a->src[i].C % 4 == 0);
+  k.vecB = aligned16(a->w) && a->ldw % 4 == 0 && a->cin_total % 4 == 0 && a->w_choff % 4 == 0 && chan4;
+  k.vecY = aligned16(a->y) && a->ldy % 4 == 0;
+  k.P = (long)a->N * a->OH * a->OW;
+  return launch<MODE_FWD>(k, (hipStream_t)stream);
+}
+
+extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->dy && a->w && a->g && a->dst.x, "conv_dgrad: null pointer");
+  ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0 && a->Cout > 0 && a->dst.C > 0, "conv_dgrad: empty shape");
+  ADDK_REQUIRE(a->lddy >= a->Cout && a->ldg >= a->dst.C && a->dst.ld >= a->dst.C, "conv_dgrad: short stride");
+  ADDK_REQUIRE(a->w_choff + a->dst.C <= a->cin_total && a->ldw >= a->KH * a->KW * a->cin_total, "conv_dgrad: weight layout");
+  ADDK_REQUIRE((a->dst.a == nullptr) == (a->dst.b == nullptr), "conv_dgrad: a/b must come together");
+  ConvK k;
+  k.nsrc = 1;
+  k.src[0] = addk_src{a->dy, nullptr, nullptr, a->lddy, a->Cout, 0, 0};
+  k.vecA = src_vec_ok(k.src[0]);
+  k.N = a->N; k.H = a->OH; k.W = a->OW;      // A side = dy
+  k.OH = a->H; k.OW = a->W;                  // M side = input pixels
+  k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
+  k.Cn = a->dst.C; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.ldy = a->ldg;
+  k.w = a->w; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr; k.slab = a->dab; k.slab_ld = a->dst.C;
+  k.dst = a->dst; k.accumulate = a->accumulate;
+  k.vecB = aligned16(a->w) && a->ldw % 4 == 0 && a->cin_total % 4 == 0 && a->w_choff % 4 == 0 && a->dst.C % 4 == 0;
+  k.vecY = aligned16(a->g) && a->ldg % 4 == 0 && src_vec_ok(a->dst);
+  k.P = (long)a->N * a->H * a->W;
+  return launch<MODE_DGRAD>(k, (hipStream_t)stream);
+}

@@ -1,0 +1,215 @@
+// Depthwise k x k convolution (the depthwise halves of SepConv, operations.py:52,56), NHWC fp32.
+// HBM-bound: every thread owns one channel quad (float4) for the whole kernel and walks pixels,
+// so global accesses are 16 B per lane, contiguous across the lanes of a pixel, and per-channel
+// reductions of the backward pass (BN-backward sums, weight gradients) stay in registers until a
+// single fixed-order block reduction.  Tap weights sit in LDS transposed to [tap][channel].
+#include "common.h"
+
+namespace {
+
+struct DwK {
+  addk_src src;
+  int N, H, W, OH, OW, KH, KW, stride, pad, dil;
+  const float* w;
+  float* y; int ldy;
+  // backward
+  const float* dy; int lddy;
+  float* g; int ldg; int accumulate;
+  float* dab; float* ws;
+  int nq, npl; long P; int vec;
+};
+
+constexpr int MAXT = 25;
+
+__global__ void __launch_bounds__(256) dw_fwd_kernel(const DwK p) {
+  extern __shared__ float wl[];               // [taps][C4] with C4 = nq*4
+  const int taps = p.KH * p.KW, C = p.src.C, C4 = p.nq * 4;
+  for (int i = threadIdx.x; i < taps * C4; i += 256) {
+    int tp = i / C4, c = i - tp * C4;
+    wl[i] = c < C ? p.w[(long)c * taps + tp] : 0.f;
+  }
+  __syncthreads();
+  const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
+  if (pl >= p.npl) return;
+  const int c = 4 * q, nrem = C - c;
+  const long ohw = (long)p.OH * p.OW;
+  for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
+    int n = (int)(pp / ohw); int rem = (int)(pp - (long)n * ohw);
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    float4 acc = zero4();
+    for (int kh = 0; kh < p.KH; ++kh) {
+      int ih = oh * p.stride - p.pad + kh * p.dil;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int kw = 0; kw < p.KW; ++kw) {
+        int iw = ow * p.stride - p.pad + kw * p.dil;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        float4 v = ld4g(p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + c, nrem, p.vec);
+        v = prologue4(v, p.src.a, p.src.b, c, nrem, p.src.relu != 0, p.vec);
+        const float* wt = &wl[(kh * p.KW + kw) * C4 + c];
+        acc.x = fmaf(wt[0], v.x, acc.x); acc.y = fmaf(wt[1], v.y, acc.y);
+        acc.z = fmaf(wt[2], v.z, acc.z); acc.w = fmaf(wt[3], v.w, acc.w);
+      }
+    }
+    st4g(p.y + pp * p.ldy + c, acc, nrem, p.vec);
+  }
+}
+
+// Backward, organised by INPUT pixel: for input pixel p and tap t the output pixel o(p,t) that read p
+// through t contributes  w[t]*dy[o]  to dz[p]  and  dy[o]*z[p]  to dW[t]  — one pass yields both.
+template <int NT>
+__global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
+  extern __shared__ float sm[];               // weights [NT][C4], then reduction tile
+  const int C = p.src.C, C4 = p.nq * 4;
+  float* wl = sm;
+  float* redt = sm + NT * C4;                 // [C4][NT] weight-gradient tile, then [C4][2] dab tile
+  for (int i = threadIdx.x; i < NT * C4; i += 256) {
+    int tp = i / C4, c = i - tp * C4;
+    wl[i] = c < C ? p.w[(long)c * NT + tp] : 0.f;
+  }
+  __syncthreads();
+  const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
+  const bool active = pl < p.npl;
+  const int c = 4 * q, nrem = C - c;
+  const long hw = (long)p.H * p.W;
+  float4 dwacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) dwacc[i] = zero4();
+  float4 sA = zero4(), sB = zero4();
+  if (active) {
+    for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
+      int n = (int)(pp / hw); int rem = (int)(pp - (long)n * hw);
+      int ih = rem / p.W, iw = rem - ih * p.W;
+      float4 x = ld4g(p.src.x + pp * p.src.ld + c, nrem, p.vec);
+      float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+      if (p.src.a) { av = ld4g(p.src.a + c, nrem, p.vec); bv = ld4g(p.src.b + c, nrem, p.vec); }
+      float4 zp = make_float4(fmaf(av.x, x.x, bv.x), fmaf(av.y, x.y, bv.y), fmaf(av.z, x.z, bv.z), fmaf(av.w, x.w, bv.w));
+      const bool r = p.src.relu != 0;
+      bool m0 = !r || zp.x > 0.f, m1 = !r || zp.y > 0.f, m2 = !r || zp.z > 0.f, m3 = !r || zp.w > 0.f;
+      float4 z = make_float4(m0 ? zp.x : 0.f, m1 ? zp.y : 0.f, m2 ? zp.z : 0.f, m3 ? zp.w : 0.f);
+      float4 dz = zero4();
+#pragma unroll
+      for (int tp = 0; tp < NT; ++tp) {
+        int kh = tp / p.KW, kw = tp - kh * p.KW;
+        int th = ih + p.pad - kh * p.dil, tw = iw + p.pad - kw * p.dil;
+        bool ok = th >= 0 && tw >= 0;
+        int oh = th, ow = tw;
+        if (p.stride > 1) { ok = ok && (th % p.stride == 0) && (tw % p.stride == 0); oh = th / p.stride; ow = tw / p.stride; }
+        ok = ok && oh < p.OH && ow < p.OW;
+        if (ok) {
+          float4 d = ld4g(p.dy + ((long)(n * p.OH + oh) * p.OW + ow) * p.lddy + c, nrem, p.vec);
+          const float* wt = &wl[tp * C4 + c];
+          dz.x = fmaf(wt[0], d.x, dz.x); dz.y = fmaf(wt[1], d.y, dz.y);
+          dz.z = fmaf(wt[2], d.z, dz.z); dz.w = fmaf(wt[3], d.w, dz.w);
+          dwacc[tp].x = fmaf(d.x, z.x, dwacc[tp].x); dwacc[tp].y = fmaf(d.y, z.y, dwacc[tp].y);
+          dwacc[tp].z = fmaf(d.z, z.z, dwacc[tp].z); dwacc[tp].w = fmaf(d.w, z.w, dwacc[tp].w);
+        }
+      }
+      float4 gm = make_float4(m0 ? dz.x : 0.f, m1 ? dz.y : 0.f, m2 ? dz.z : 0.f, m3 ? dz.w : 0.f);
+      sA.x += gm.x * x.x; sA.y += gm.y * x.y; sA.z += gm.z * x.z; sA.w += gm.w * x.w;
+      sB.x += gm.x; sB.y += gm.y; sB.z += gm.z; sB.w += gm.w;
+      if (p.g) {
+        float4 gv = make_float4(gm.x * av.x, gm.y * av.y, gm.z * av.z, gm.w * av.w);
+        float* gp = p.g + pp * p.ldg + c;
+        if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vec); gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
+        st4g(gp, gv, nrem, p.vec);
+      }
+    }
+  }
+  // fixed-order block reduction over pixel lanes (deterministic)
+  for (int r = 0; r < p.npl; ++r) {
+    if (active && pl == r) {
+#pragma unroll
+      for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = get4(dwacc[tp], e);
+          float* d = &redt[(c + e) * NT + tp];
+          *d = (r == 0) ? v : *d + v;
+        }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < C * NT; i += 256) p.ws[(long)blockIdx.x * C * NT + i] = redt[i];
+  __syncthreads();
+  if (p.dab) {
+    for (int r = 0; r < p.npl; ++r) {
+      if (active && pl == r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* d = &redt[(c + e) * 2];
+          d[0] = (r == 0) ? get4(sA, e) : d[0] + get4(sA, e);
+          d[1] = (r == 0) ? get4(sB, e) : d[1] + get4(sB, e);
+        }
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < C * 2; i += 256) p.dab[(long)blockIdx.x * C * 2 + i] = redt[i];
+  }
+}
+
+__global__ void dw_wreduce_kernel(const float* ws, int rows, int n, float* dw, int accumulate) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += ws[(long)r * n + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+int dw_rows(long P, int C) {
+  EwMap m = ew_map(C);
+  long r = P / ((long)m.npl * 8);
+  if (r < 1) r = 1;
+  if (r > 512) r = 512;
+  return (int)r;
+}
+
+}  // namespace
+
+extern "C" int addk_dw_rows(int64_t P, int32_t C) { return dw_rows(P, C); }
+
+static int dw_fill(DwK& k, const addk_src& src, int N, int H, int W, int OH, int OW, int KH, int KW, int stride, int pad, int dil) {
+  ADDK_REQUIRE(src.x && src.C > 0 && src.C <= 1024 && src.ld >= src.C, "dw: bad source");
+  ADDK_REQUIRE((src.a == nullptr) == (src.b == nullptr), "dw: a/b must come together");
+  ADDK_REQUIRE(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && KH * KW <= MAXT && stride > 0 && dil > 0, "dw: bad geometry");
+  k.src = src; k.N = N; k.H = H; k.W = W; k.OH = OH; k.OW = OW; k.KH = KH; k.KW = KW; k.stride = stride; k.pad = pad; k.dil = dil;
+  EwMap m = ew_map(src.C); k.nq = m.nq; k.npl = m.npl;
+  return 0;
+}
+
+extern "C" int addk_dw_fwd(const addk_dw_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->w && a->y && a->ldy >= a->src.C, "dw_fwd: null/short output");
+  DwK k{};
+  int rc = dw_fill(k, a->src, a->N, a->H, a->W, a->OH, a->OW, a->KH, a->KW, a->stride, a->pad, a->dil);
+  if (rc) return rc;
+  k.w = a->w; k.y = a->y; k.ldy = a->ldy;
+  k.P = (long)a->N * a->OH * a->OW;
+  k.vec = src_vec_ok(a->src) && aligned16(a->y) && a->ldy % 4 == 0;
+  long blocks = cdiv(k.P, k.npl * 4); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  size_t sh = (size_t)a->KH * a->KW * k.nq * 4 * sizeof(float);
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, k);
+  return addk_check_launch("dw_fwd");
+}
+
+extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->dy && a->w && a->dw && a->ws && a->lddy >= a->src.C, "dw_bwd: null pointer");
+  ADDK_REQUIRE(!a->g || a->ldg >= a->src.C, "dw_bwd: short ldg");
+  DwK k{};
+  int rc = dw_fill(k, a->src, a->N, a->H, a->W, a->OH, a->OW, a->KH, a->KW, a->stride, a->pad, a->dil);
+  if (rc) return rc;
+  k.w = a->w; k.dy = a->dy; k.lddy = a->lddy; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate;
+  k.dab = a->dab; k.ws = a->ws;
+  k.P = (long)a->N * a->H * a->W;
+  k.vec = src_vec_ok(a->src) && aligned16(a->dy) && a->lddy % 4 == 0 && (!a->g || (aligned16(a->g) && a->ldg % 4 == 0));
+  const int taps = a->KH * a->KW, C4 = k.nq * 4;
+  const int rows = dw_rows(k.P, a->src.C);
+  size_t sh = (size_t)(taps * C4 + C4 * (taps > 2 ? taps : 2)) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (taps == 9) hipLaunchKernelGGL(dw_bwd_kernel<9>, dim3(rows), dim3(256), sh, st, k);
+  else if (taps == 25) hipLaunchKernelGGL(dw_bwd_kernel<25>, dim3(rows), dim3(256), sh, st, k);
+  else { addk_set_error("dw_bwd: only 3x3 and 5x5 depthwise kernels are built"); return ADDK_ERR_UNSUPPORTED; }
+  rc = addk_check_launch("dw_bwd");
+  if (rc) return rc;
+  int n = a->src.C * taps;
+  hipLaunchKernelGGL(dw_wreduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a->ws, rows, n, a->dw, a->dw_accumulate);
+  return addk_check_launch("dw_wreduce");
+}

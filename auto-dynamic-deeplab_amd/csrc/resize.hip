@@ -1,0 +1,246 @@
+// Bilinear resize, align_corners=False, no antialias — F.interpolate(mode='bilinear') as called at
+// ADD.py:76-77,84,89,317 and decoder.py:24,28 (used for both up- and down-sampling).
+// Index arithmetic follows ATen's area_pixel_compute_source_index in fp32:
+//     scale = in/out;  src = max(0, scale*(dst+0.5)-0.5);  i0 = floor(src); i1 = min(i0+1, in-1); l1 = src-i0.
+// Forward: one thread per (output pixel, channel quad), 16 B per lane.
+// Backward is a GATHER (deterministic, no atomics): an input pixel enumerates the few output rows/cols
+// whose i0/i1 hit it, recomputing exactly the forward weights.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void src_index(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+// candidate output range [lo, hi] whose taps may touch input index i
+__device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, int& hi) {
+  float inv = 1.f / scale;
+  float a = ((float)i - 1.f + 0.5f) * inv - 0.5f;
+  float b = ((float)i + 1.f + 0.5f) * inv - 0.5f;
+  lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+// weight with which output index o reads input index i (0 when it does not)
+__device__ __forceinline__ float tap_weight(int o, int i, float scale, int in) {
+  int i0, i1; float l0, l1;
+  src_index(o, scale, in, i0, i1, l0, l1);
+  return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+struct RsK {
+  addk_src src; int N, H, W, OH, OW;
+  float* y; int ldy; int nchw;
+  const float* dy; int lddy; const float* dy_scale;
+  float* g; int ldg; int accumulate; float* dab;
+  int nq, npl, vec; long P;
+};
+
+__global__ void __launch_bounds__(256) resize_fwd_kernel(const RsK p) {
+  const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
+  if (pl >= p.npl) return;
+  const int c = 4 * q, nrem = p.src.C - c;
+  const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
+  const long ohw = (long)p.OH * p.OW;
+  const bool relu = p.src.relu != 0;
+  for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
+    int n = (int)(pp / ohw); int rem = (int)(pp - (long)n * ohw);
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    int h0, h1, w0, w1; float lh0, lh1, lw0, lw1;
+    src_index(oh, sh, p.H, h0, h1, lh0, lh1);
+    src_index(ow, sw, p.W, w0, w1, lw0, lw1);
+    const float* b = p.src.x + (long)n * p.H * p.W * p.src.ld + c;
+    float4 v00 = prologue4(ld4g(b + ((long)h0 * p.W + w0) * p.src.ld, nrem, p.vec), p.src.a, p.src.b, c, nrem, relu, p.vec);
+    float4 v01 = prologue4(ld4g(b + ((long)h0 * p.W + w1) * p.src.ld, nrem, p.vec), p.src.a, p.src.b, c, nrem, relu, p.vec);
+    float4 v10 = prologue4(ld4g(b + ((long)h1 * p.W + w0) * p.src.ld, nrem, p.vec), p.src.a, p.src.b, c, nrem, relu, p.vec);
+    float4 v11 = prologue4(ld4g(b + ((long)h1 * p.W + w1) * p.src.ld, nrem, p.vec), p.src.a, p.src.b, c, nrem, relu, p.vec);
+    float4 o;
+    o.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
+    o.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
+    o.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
+    o.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+    st4g(p.y + pp * p.ldy + c, o, nrem, p.vec);
+  }
+}
+
+// NCHW destination (final logits, decoder.py:28): one thread per output pixel, loop over channels so that
+// stores are contiguous along W for every channel plane.
+__global__ void __launch_bounds__(256) resize_fwd_nchw_kernel(const RsK p) {
+  const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
+  const long ohw = (long)p.OH * p.OW;
+  const int C = p.src.C;
+  for (long pp = (long)blockIdx.x * blockDim.x + threadIdx.x; pp < p.P; pp += (long)gridDim.x * blockDim.x) {
+    int n = (int)(pp / ohw); long rem = pp - (long)n * ohw;
+    int oh = (int)(rem / p.OW), ow = (int)(rem - (long)oh * p.OW);
+    int h0, h1, w0, w1; float lh0, lh1, lw0, lw1;
+    src_index(oh, sh, p.H, h0, h1, lh0, lh1);
+    src_index(ow, sw, p.W, w0, w1, lw0, lw1);
+    const float* b = p.src.x + (long)n * p.H * p.W * p.src.ld;
+    const float* p00 = b + ((long)h0 * p.W + w0) * p.src.ld;
+    const float* p01 = b + ((long)h0 * p.W + w1) * p.src.ld;
+    const float* p10 = b + ((long)h1 * p.W + w0) * p.src.ld;
+    const float* p11 = b + ((long)h1 * p.W + w1) * p.src.ld;
+    float* yo = p.y + (long)n * C * ohw + rem;
+    for (int c = 0; c < C; ++c) {
+      float a = p.src.a ? p.src.a[c] : 1.f, bb = p.src.b ? p.src.b[c] : 0.f;
+      float v00 = fmaf(a, p00[c], bb), v01 = fmaf(a, p01[c], bb), v10 = fmaf(a, p10[c], bb), v11 = fmaf(a, p11[c], bb);
+      if (p.src.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+      yo[(long)c * ohw] = lh0 * (lw0 * v00 + lw1 * v01) + lh1 * (lw0 * v10 + lw1 * v11);
+    }
+  }
+}
+
+
+template <bool NCHW>
+__global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
+  extern __shared__ float redt[];        // [C4][2]
+  const int C = p.src.C;
+  const int q = NCHW ? 0 : threadIdx.x % p.nq, pl = NCHW ? threadIdx.x : threadIdx.x / p.nq;
+  const bool active = pl < p.npl;
+  const int c = 4 * q, nrem = C - c;
+  const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
+  const long hw = (long)p.H * p.W, ohw = (long)p.OH * p.OW;
+  const float gs = p.dy_scale ? *p.dy_scale : 1.f;
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4(), sA = zero4(), sB = zero4();
+  if (!NCHW && active && p.src.a) { av = ld4g(p.src.a + c, nrem, p.vec); bv = ld4g(p.src.b + c, nrem, p.vec); }
+  if (active) {
+    for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
+      int n = (int)(pp / hw); int rem = (int)(pp - (long)n * hw);
+      int ih = rem / p.W, iw = rem - ih * p.W;
+      int hlo, hhi, wlo, whi;
+      out_range(ih, sh, p.OH, hlo, hhi);
+      out_range(iw, sw, p.OW, wlo, whi);
+      if (NCHW) {
+        // channel loop outside: dy planes are contiguous along W; no prologue on the logits source
+        for (int cc = 0; cc < C; ++cc) {
+          const float* d = p.dy + ((long)n * C + cc) * ohw;
+          float s = 0.f;
+          for (int oh = hlo; oh <= hhi; ++oh) {
+            float wh = tap_weight(oh, ih, sh, p.H);
+            if (wh == 0.f) continue;
+            float r = 0.f;
+            for (int ow = wlo; ow <= whi; ++ow) {
+              float ww = tap_weight(ow, iw, sw, p.W);
+              if (ww != 0.f) r = fmaf(ww, d[(long)oh * p.OW + ow], r);
+            }
+            s = fmaf(wh, r, s);
+          }
+          s *= gs;
+          float a = p.src.a ? p.src.a[cc] : 1.f;
+          float* gp = p.g + pp * p.ldg + cc;
+          float gv = s * a;
+          *gp = p.accumulate ? *gp + gv : gv;
+        }
+      } else {
+        float4 dz = zero4();
+        for (int oh = hlo; oh <= hhi; ++oh) {
+          float wh = tap_weight(oh, ih, sh, p.H);
+          if (wh == 0.f) continue;
+          for (int ow = wlo; ow <= whi; ++ow) {
+            float ww = tap_weight(ow, iw, sw, p.W);
+            if (ww == 0.f) continue;
+            float4 d = ld4g(p.dy + ((long)(n * p.OH + oh) * p.OW + ow) * p.lddy + c, nrem, p.vec);
+            float k = wh * ww;
+            dz.x = fmaf(k, d.x, dz.x); dz.y = fmaf(k, d.y, dz.y); dz.z = fmaf(k, d.z, dz.z); dz.w = fmaf(k, d.w, dz.w);
+          }
+        }
+        dz.x *= gs; dz.y *= gs; dz.z *= gs; dz.w *= gs;
+        if (p.src.relu || p.dab) {
+          float4 x = ld4g(p.src.x + pp * p.src.ld + c, nrem, p.vec);
+          if (p.src.relu) {
+            if (!(fmaf(av.x, x.x, bv.x) > 0.f)) dz.x = 0.f;
+            if (!(fmaf(av.y, x.y, bv.y) > 0.f)) dz.y = 0.f;
+            if (!(fmaf(av.z, x.z, bv.z) > 0.f)) dz.z = 0.f;
+            if (!(fmaf(av.w, x.w, bv.w) > 0.f)) dz.w = 0.f;
+          }
+          sA.x += dz.x * x.x; sA.y += dz.y * x.y; sA.z += dz.z * x.z; sA.w += dz.w * x.w;
+          sB.x += dz.x; sB.y += dz.y; sB.z += dz.z; sB.w += dz.w;
+        }
+        float4 gv = make_float4(dz.x * av.x, dz.y * av.y, dz.z * av.z, dz.w * av.w);
+        float* gp = p.g + pp * p.ldg + c;
+        if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vec); gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
+        st4g(gp, gv, nrem, p.vec);
+      }
+    }
+  }
+  if (!NCHW && p.dab) {
+    for (int r = 0; r < p.npl; ++r) {
+      if (active && pl == r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* d = &redt[(c + e) * 2];
+          d[0] = (r == 0) ? get4(sA, e) : d[0] + get4(sA, e);
+          d[1] = (r == 0) ? get4(sB, e) : d[1] + get4(sB, e);
+        }
+      }
+      __syncthreads();
+    }
+    for (int k = threadIdx.x; k < C * 2; k += 256) p.dab[(long)blockIdx.x * C * 2 + k] = redt[k];
+  }
+}
+
+int rs_rows(long P, int C) {
+  EwMap m = ew_map(C);
+  long r = P / ((long)m.npl * 8);
+  if (r < 1) r = 1;
+  if (r > 512) r = 512;
+  return (int)r;
+}
+
+}  // namespace
+
+extern "C" int addk_resize_fwd(const addk_resize_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->src.x && a->y && a->src.C > 0 && a->src.C <= 1024 && a->src.ld >= a->src.C, "resize_fwd: bad args");
+  ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "resize_fwd: empty shape");
+  ADDK_REQUIRE((a->src.a == nullptr) == (a->src.b == nullptr), "resize_fwd: a/b must come together");
+  RsK k{};
+  k.src = a->src; k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW; k.y = a->y; k.ldy = a->ldy; k.nchw = a->nchw_out;
+  k.P = (long)a->N * a->OH * a->OW;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->nchw_out) {
+    long b = cdiv(k.P, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(resize_fwd_nchw_kernel, dim3((unsigned)b), dim3(256), 0, st, k);
+  } else {
+    ADDK_REQUIRE(a->ldy >= a->src.C, "resize_fwd: short ldy");
+    EwMap m = ew_map(a->src.C); k.nq = m.nq; k.npl = m.npl;
+    k.vec = src_vec_ok(a->src) && aligned16(a->y) && a->ldy % 4 == 0;
+    long b = cdiv(k.P, (long)m.npl * 2); if (b > 4096) b = 4096; if (b < 1) b = 1;
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3((unsigned)b), dim3(256), 0, st, k);
+  }
+  return addk_check_launch("resize_fwd");
+}
+
+extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->dy && a->g && a->src.C > 0 && a->src.C <= 1024 && a->ldg >= a->src.C, "resize_bwd: bad args");
+  ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "resize_bwd: empty shape");
+  ADDK_REQUIRE(!(a->src.relu || a->dab) || (a->src.x && a->src.ld >= a->src.C), "resize_bwd: prologue needs the forward input");
+  ADDK_REQUIRE((a->src.a == nullptr) == (a->src.b == nullptr), "resize_bwd: a/b must come together");
+  RsK k{};
+  k.src = a->src; k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
+  k.dy = a->dy; k.lddy = a->lddy; k.dy_scale = a->dy_scale; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate; k.dab = a->dab;
+  k.P = (long)a->N * a->H * a->W;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->nchw_in) {
+    ADDK_REQUIRE(!a->src.relu && !a->dab, "resize_bwd: NCHW gradient input has no prologue support");
+    k.nq = 1; k.npl = 256;
+    long b = cdiv(k.P, 256); if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(resize_bwd_kernel<true>, dim3((unsigned)b), dim3(256), 0, st, k);
+  } else {
+    ADDK_REQUIRE(a->lddy >= a->src.C, "resize_bwd: short lddy");
+    EwMap m = ew_map(a->src.C); k.nq = m.nq; k.npl = m.npl;
+    k.vec = aligned16(a->dy) && a->lddy % 4 == 0 && aligned16(a->g) && a->ldg % 4 == 0 && a->src.C % 4 == 0 &&
+            (!a->src.x || src_vec_ok(a->src));
+    int rows = rs_rows(k.P, a->src.C);
+    size_t sh = (size_t)m.nq * 4 * 2 * sizeof(float);
+    hipLaunchKernelGGL(resize_bwd_kernel<false>, dim3(rows), dim3(256), sh, st, k);
+  }
+  return addk_check_launch("resize_bwd");
+}

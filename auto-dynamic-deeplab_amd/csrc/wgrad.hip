@@ -1,0 +1,231 @@
+// Weight gradient of the dense convolution for one source:
+//     dW[co][tap][c] = sum_p dy[p, co] * Z[p @ tap, c],   Z = relu?(a*x+b) recomputed on the fly.
+// GEMM with M = output channels (tile 16*CTY), N = input channels of one tap (tile 16*CTZ) and the
+// reduction over pixels.  A block owns one (co tile, tap, c tile) and one slice of the pixel range;
+// its four waves each take 16 of the 64 pixels staged per step (both tiles are staged in their memory
+// order [pixel][channel]; MFMA fragments are read with ds_read_b32, rows padded so that the two pixel
+// rows a 32-lane group touches fall on disjoint banks).  Wave partials are combined through LDS in a
+// fixed order and the per-slice tiles go to a workspace that addk reduces deterministically into dW.
+#include "common.h"
+
+namespace {
+
+struct WgK {
+  const float* dy; int lddy; int Cout;
+  int N, H, W, OH, OW, KH, KW, stride, pad, dil;
+  addk_src src;
+  float* ws;
+  int taps, nzt, nyt;      // tiles: taps, z (input-channel) tiles, y (output-channel) tiles
+  int splits; long P; long chunkP;
+  int vecY, vecZ;
+};
+
+constexpr int KP = 64;
+constexpr int ldpad(int bc) { return (bc % 32 == 16) ? bc : bc + 16; }
+
+template <int CTY, int CTZ>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
+  constexpr int BCY = 16 * CTY, BCZ = 16 * CTZ;
+  constexpr int LY = ldpad(BCY), LZ = ldpad(BCZ);
+  constexpr int NYJ = (KP * BCY / 4 + 255) / 256;
+  constexpr int NZJ = (KP * BCZ / 4 + 255) / 256;
+  constexpr int STAGE = KP * LY + KP * LZ;
+  constexpr int TILE = BCY * BCZ;
+  constexpr int LDSF = STAGE > TILE ? STAGE : TILE;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  float* Ys = lds;
+  float* Zs = lds + KP * LY;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  int bx = blockIdx.x;
+  const int zt = bx % p.nzt; bx /= p.nzt;
+  const int tap = bx % p.taps; const int yt = bx / p.taps;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int co0 = yt * BCY, c0 = zt * BCZ;
+  const long ohw = (long)p.OH * p.OW;
+  const long pbeg = (long)blockIdx.y * p.chunkP;
+  long pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
+
+  f32x4 acc[CTY][CTZ];
+#pragma unroll
+  for (int i = 0; i < CTY; ++i)
+#pragma unroll
+    for (int j = 0; j < CTZ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ry[NYJ], rz[NZJ];
+  auto load_step = [&](long p0) {
+#pragma unroll
+    for (int j = 0; j < NYJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
+      long pp = p0 + row; int co = co0 + 4 * q;
+      float4 v = zero4();
+      if (row < KP && pp < pend && co < p.Cout) v = ld4g(p.dy + pp * p.lddy + co, p.Cout - co, p.vecY);
+      ry[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NZJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
+      long pp = p0 + row; int c = c0 + 4 * q;
+      float4 v = zero4();
+      if (row < KP && pp < pend && c < p.src.C) {
+        int n = (int)(pp / ohw); int rem = (int)(pp - (long)n * ohw);
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        int ih = oh * p.stride - p.pad + kh * p.dil, iw = ow * p.stride - p.pad + kw * p.dil;
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+          const float* xp = p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + c;
+          v = ld4g(xp, p.src.C - c, p.vecZ);
+          v = prologue4(v, p.src.a, p.src.b, c, p.src.C - c, p.src.relu != 0, p.vecZ);
+        }
+      }
+      rz[j] = v;
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int j = 0; j < NYJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
+      if (row < KP) st4(&Ys[row * LY + 4 * q], ry[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NZJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
+      if (row < KP) st4(&Zs[row * LZ + 4 * q], rz[j]);
+    }
+  };
+
+  if (pbeg < pend) {
+    load_step(pbeg);
+    store_step();
+    __syncthreads();
+    for (long p0 = pbeg; p0 < pend; p0 += KP) {
+      const bool more = p0 + KP < pend;
+      if (more) load_step(p0 + KP);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int px = wave * 16 + ks * 4 + kq;
+        float yf[CTY], zf[CTZ];
+#pragma unroll
+        for (int i = 0; i < CTY; ++i) yf[i] = Ys[px * LY + i * 16 + li];
+#pragma unroll
+        for (int j = 0; j < CTZ; ++j) zf[j] = Zs[px * LZ + j * 16 + li];
+#pragma unroll
+        for (int i = 0; i < CTY; ++i)
+#pragma unroll
+          for (int j = 0; j < CTZ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[i], zf[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) { store_step(); __syncthreads(); }
+    }
+  }
+
+  // combine the four waves in a fixed order (deterministic), tile layout [co][c]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < CTY; ++i)
+#pragma unroll
+        for (int j = 0; j < CTZ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int idx = (i * 16 + kq * 4 + r) * BCZ + j * 16 + li;
+            lds[idx] = (w == 0) ? acc[i][j][r] : lds[idx] + acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  // workspace layout: [split][co][tap][c] over the real (unpadded) extents
+  const int C = p.src.C;
+  float* wsb = p.ws + (long)blockIdx.y * p.Cout * p.taps * C;
+  for (int idx = t; idx < TILE; idx += 256) {
+    int r = idx / BCZ, cc = idx - r * BCZ;
+    int co = co0 + r, c = c0 + cc;
+    if (co < p.Cout && c < C) wsb[((long)co * p.taps + tap) * C + c] = lds[idx];
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* ws, int splits, int Cout, int taps, int C, float* dw, int ldw,
+                                    int cin_total, int w_choff, int accumulate) {
+  long n = (long)Cout * taps * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(long)k * n + i];
+    int c = (int)(i % C); long r = i / C; int tap = (int)(r % taps); int co = (int)(r / taps);
+    float* d = dw + (long)co * ldw + (long)tap * cin_total + w_choff + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+int pick_cty(int Cout) {
+  const int cands[5] = {8, 5, 4, 3, 2};
+  int best = 2; long bc = -1;
+  for (int k = 0; k < 5; ++k) { long cols = (long)cdiv(Cout, 16 * cands[k]) * 16 * cands[k]; if (bc < 0 || cols < bc) { bc = cols; best = cands[k]; } }
+  return best;
+}
+int pick_ctz(int C) {
+  const int cands[4] = {5, 4, 3, 1};
+  int best = 1; long bc = -1;
+  for (int k = 0; k < 4; ++k) { long cols = (long)cdiv(C, 16 * cands[k]) * 16 * cands[k]; if (bc < 0 || cols < bc) { bc = cols; best = cands[k]; } }
+  return best;
+}
+void pick_tiles(int Cout, int C, int* cty, int* ctz) {
+  *cty = pick_cty(Cout); *ctz = pick_ctz(C);
+  if (*cty == 8 && *ctz == 5) *ctz = 4;   // 8x5 accumulator tiles would not leave room for the staging registers
+}
+int pick_splits(long P, int tiles) {
+  long maxs = cdiv(P, 4 * KP);            // at least 4 staged steps per block
+  long want = cdiv(1024, tiles);
+  long s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_t taps) {
+  int cty, ctz; pick_tiles(Cout, C, &cty, &ctz);
+  int tiles = cdiv(Cout, 16 * cty) * taps * cdiv(C, 16 * ctz);
+  return (int64_t)pick_splits(P, tiles) * Cout * taps * C;
+}
+
+extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->dy && a->src.x && a->dw && a->ws, "conv_wgrad: null pointer");
+  ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0 && a->Cout > 0 && a->src.C > 0, "conv_wgrad: empty shape");
+  ADDK_REQUIRE(a->lddy >= a->Cout && a->src.ld >= a->src.C, "conv_wgrad: short stride");
+  ADDK_REQUIRE(a->w_choff + a->src.C <= a->cin_total && a->ldw >= a->KH * a->KW * a->cin_total, "conv_wgrad: weight layout");
+  ADDK_REQUIRE((a->src.a == nullptr) == (a->src.b == nullptr), "conv_wgrad: a/b must come together");
+  WgK k;
+  k.dy = a->dy; k.lddy = a->lddy; k.Cout = a->Cout;
+  k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
+  k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
+  k.src = a->src; k.ws = a->ws;
+  int cty, ctz; pick_tiles(a->Cout, a->src.C, &cty, &ctz);
+  k.taps = a->KH * a->KW; k.nyt = cdiv(a->Cout, 16 * cty); k.nzt = cdiv(a->src.C, 16 * ctz);
+  k.P = (long)a->N * a->OH * a->OW;
+  const int tiles = k.nyt * k.taps * k.nzt;
+  k.splits = pick_splits(k.P, tiles);
+  ADDK_REQUIRE(a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  k.chunkP = (long)cdiv(cdiv(k.P, k.splits), KP) * KP;
+  k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
+  k.vecZ = src_vec_ok(a->src);
+  dim3 grid(tiles, k.splits);
+  hipStream_t st = (hipStream_t)stream;
+  bool done = false;
+#define ADDK_CASE(Y_, Z_) \
+  if (!done && cty == Y_ && ctz == Z_) { hipLaunchKernelGGL((wgrad_kernel<Y_, Z_>), grid, dim3(256), 0, st, k); done = true; }
+  ADDK_CASE(2, 1) ADDK_CASE(2, 3) ADDK_CASE(2, 4) ADDK_CASE(2, 5)
+  ADDK_CASE(3, 1) ADDK_CASE(3, 3) ADDK_CASE(3, 4) ADDK_CASE(3, 5)
+  ADDK_CASE(4, 1) ADDK_CASE(4, 3) ADDK_CASE(4, 4) ADDK_CASE(4, 5)
+  ADDK_CASE(5, 1) ADDK_CASE(5, 3) ADDK_CASE(5, 4) ADDK_CASE(5, 5)
+  ADDK_CASE(8, 1) ADDK_CASE(8, 3) ADDK_CASE(8, 4)
+#undef ADDK_CASE
+  if (!done) { addk_set_error("conv_wgrad: no tile config"); return ADDK_ERR_UNSUPPORTED; }
+  int rc = addk_check_launch("conv_wgrad");
+  if (rc) return rc;
+  long n = (long)a->Cout * k.taps * a->src.C;
+  int rb = cdiv(n, 256); if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, a->ws, k.splits, a->Cout, k.taps, a->src.C,
+                     a->dw, a->ldw, a->cin_total, a->w_choff, a->accumulate);
+  return addk_check_launch("conv_wgrad_reduce");
+}

@@ -1,0 +1,68 @@
+"""EDM-gated dynamic inference (reference ADD.dynamic_inference, ADD.py:379-438; eval.py:195-230).
+
+The gate stays on the host and only selects which exit's kernels fire (north_star): the trunk is emitted
+once into a single launch list that is cut into segments — [stems+cells up to gate k + EDM] and, per gate,
+[early head k]; the last segment is [remaining cells + final head].  All segments share one buffer set."""
+import torch
+
+from .module import ensure_layout
+from . import plan as _plan
+from .plan import Act, Graph
+
+
+class DynamicPlan:
+    def __init__(self, model, edm, x):
+        from .modeling.ADD import _aspp_size
+        for p in list(model.parameters()) + list(edm.parameters()):
+            ensure_layout(p)
+        self.g = g = Graph(x.device, False, False, None)
+        a, self.inref = g.input_nchw(x)
+        size = (a.H, a.W)
+        aspp_size = _aspp_size(size, model.network_arch[-1])          # 2^-last
+        self.trunk_end, self.head_rng, self.conf, self.heads = [], [], [], []
+        gen = model._trunk(g, a)
+        send, it = None, 0
+        self.final = None
+        while True:
+            try:
+                i, y, low = gen.send(send)
+            except StopIteration:
+                break
+            send = None
+            if i in model.C_index or i == model.num_net - 1:
+                if i != model.num_net - 1:
+                    conf = g.output_nchw(edm.emit(g, y))              # EDM applies ReLU to y in place (Q3) ...
+                    y = Act(y.raw, y.bn, True, False)                 # ... so everything downstream sees relu(y)
+                    send = y
+                    self.trunk_end.append(len(g.fwd))
+                    self.conf.append(conf)
+                    h0 = len(g.fwd)
+                    self.heads.append(model._head(g, y, low, size, aspp_size, it, model.network_arch[i]))
+                    self.head_rng.append((h0, len(g.fwd)))
+                    it += 1                                           # ADD.py:422 increments on every passed gate
+                else:
+                    self.final = model._head(g, y, low, size, aspp_size, it, model.network_arch[i], resize=False, adapt=False)
+        g.finalize()
+        self.params = list(g.params)
+        self.ptrs = [p.data_ptr() for p in self.params]
+
+    def check_params(self):
+        return all(p.data_ptr() == q for p, q in zip(self.params, self.ptrs))
+
+    def run(self, x, threshold):
+        g = self.g
+        self.inref.bind(x if x.dtype == torch.float32 else x.float())
+        st = _plan.current_stream()
+        pos, conf = 0, None
+        with torch.no_grad():
+            for k, end in enumerate(self.trunk_end):
+                g.run(g.fwd[pos:end], st)
+                conf = self.conf[k].y.reshape(x.shape[0], -1)
+                h0, h1 = self.head_rng[k]
+                if bool(conf > threshold):                            # D2H sync: the gate (ADD.py:421)
+                    pos = h1
+                    continue
+                g.run(g.fwd[h0:h1], st)
+                return self.heads[k].y, 1, conf
+            g.run(g.fwd[pos:], st)
+        return self.final.y, 0, conf

@@ -1,0 +1,714 @@
+"""Static execution plans for the ADD hot path.
+
+A module tree (modeling/*.py) is *emitted* once per (input shape, mode) into a `Graph`:
+a flat list of C-ABI kernel launches over pre-allocated NHWC buffers plus the matching
+backward list (built in reverse with first-touch/accumulate flags decided at build
+time, so no memsets and no separate add kernels).  Replaying a plan is a tight loop of
+ctypes calls on one HIP stream — or a single hipGraph launch once captured.
+
+Activations are *lazy*: `Act = (raw, bn, relu)` means relu?(a*raw+b) with (a,b) owned by
+the producing BatchNorm; consumers apply it while staging their tiles, so BatchNorm/ReLU
+never cost a pass over HBM.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class Buf:
+    """Flat fp32 device buffer."""
+    __slots__ = ('t', 'ptr', 'n', 'gbuf', 'ginit')
+
+    def __init__(self, n, device, zero=False):
+        self.n = int(n)
+        self.t = (torch.zeros if zero else torch.empty)(max(self.n, 4), dtype=torch.float32, device=device)
+        self.ptr = self.t.data_ptr()
+        self.gbuf = None       # gradient twin
+        self.ginit = []        # initialised channel intervals of this (gradient) buffer
+
+
+class TRef:
+    """NHWC view (n,h,w,c) -> buf[off + ((n*H+h)*W+w)*ld + c]."""
+    __slots__ = ('buf', 'off', 'N', 'H', 'W', 'C', 'ld')
+
+    def __init__(self, buf, off, N, H, W, C, ld):
+        self.buf, self.off, self.N, self.H, self.W, self.C, self.ld = buf, off, N, H, W, C, ld
+
+    @property
+    def ptr(self):
+        return self.buf.ptr + 4 * self.off
+
+    @property
+    def P(self):
+        return self.N * self.H * self.W
+
+    def chan(self, c0, C):
+        assert 0 <= c0 and c0 + C <= self.C
+        return TRef(self.buf, self.off + c0, self.N, self.H, self.W, C, self.ld)
+
+    def view(self):
+        """torch view [N,H,W,C] (strided)."""
+        return self.buf.t.as_strided((self.N, self.H, self.W, self.C),
+                                     (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1), self.off)
+
+
+class Vec:
+    __slots__ = ('buf', 'off', 'n')
+
+    def __init__(self, buf, off, n):
+        self.buf, self.off, self.n = buf, off, n
+
+    @property
+    def ptr(self):
+        return self.buf.ptr + 4 * self.off
+
+    def view(self):
+        return self.buf.t[self.off:self.off + self.n]
+
+
+class BNState:
+    """Per-call state of one BatchNorm application: lazy affine + saved statistics + the
+    partial (dA,dB) slabs its consumers produce in backward."""
+
+    def __init__(self, mod, C, a, b, training, count):
+        self.mod, self.C, self.a, self.b = mod, C, a, b
+        self.training, self.count = training, count
+        self.mean = self.invstd = None
+        self.slabs = []          # [(ptr, rows)]
+        self.c1 = self.c2 = None
+
+
+class Act:
+    """Lazy activation: value = relu?(a*raw+b)."""
+    __slots__ = ('raw', 'bn', 'relu', 'needs_grad', 'zero')
+
+    def __init__(self, raw, bn=None, relu=False, needs_grad=False, zero=False):
+        self.raw, self.bn, self.relu, self.needs_grad, self.zero = raw, bn, relu, needs_grad, zero
+
+    N = property(lambda s: s.raw.N)
+    H = property(lambda s: s.raw.H)
+    W = property(lambda s: s.raw.W)
+    C = property(lambda s: s.raw.C)
+
+
+def _vp(x):
+    return C.c_void_p(x) if x else None
+
+
+class Graph:
+    def __init__(self, device, training, want_grad, world=None):
+        self.lib = L.load()
+        self.device = device
+        self.training = training
+        self.want_grad = want_grad
+        self.world = world            # SyncBN communicator (parallel.SyncBNComm) or None
+        self.fwd, self.bwd = [], []   # [(name, fn, args)]
+        self._bwd_emitters = []       # closures emitting backward commands, run in reverse
+        self.keep = []                # keep ctypes structs / tensors alive
+        self.pgrad = {}               # param -> grad tensor
+        self.pginit = set()
+        self.params = []              # ordered unique params touched
+        self.nbt = {}                 # num_batches_tracked tensor -> increments per forward
+        self._wgrads = []             # wgrad arg structs sharing one scratch buffer (launches are stream-ordered)
+        self.nbytes = 0
+
+    # ---------------- memory ----------------
+    def buf(self, n, zero=False):
+        b = Buf(n, self.device, zero)
+        self.nbytes += 4 * b.n
+        return b
+
+    def tensor(self, N, H, W, Cc, ld=None):
+        ld = ld or (Cc + 3) // 4 * 4
+        return TRef(self.buf(N * H * W * ld, zero=(ld != Cc)), 0, N, H, W, Cc, ld)
+
+    def vec(self, n, zero=False):
+        return Vec(self.buf(n, zero), 0, n)
+
+    def grad(self, tref):
+        """Gradient twin of a TRef (same geometry in the twin buffer)."""
+        b = tref.buf
+        if b.gbuf is None:
+            b.gbuf = self.buf(b.n)
+        return TRef(b.gbuf, tref.off, tref.N, tref.H, tref.W, tref.C, tref.ld)
+
+    def acc_flag(self, gref):
+        """0 the first time a channel interval of a gradient buffer is written in backward order, 1 afterwards."""
+        iv = gref.buf.ginit
+        c0 = gref.off % gref.ld if gref.ld else 0
+        c1 = c0 + gref.C
+        covered = sum(max(0, min(c1, b) - max(c0, a)) for a, b in iv)
+        if covered == 0:
+            iv.append((c0, c1))
+            return 0
+        if covered == c1 - c0:
+            return 1
+        raise NotImplementedError('partially initialised gradient interval [%d,%d) vs %s' % (c0, c1, iv))
+
+    def grad_ready(self, tref):
+        b = tref.buf.gbuf
+        if b is None:
+            return False
+        c0 = tref.off % tref.ld if tref.ld else 0
+        c1 = c0 + tref.C
+        return sum(max(0, min(c1, y) - max(c0, x)) for x, y in b.ginit) == c1 - c0
+
+    def param(self, p):
+        if p not in self.pgrad:          # Tensor hashes by identity
+            self.pgrad[p] = None
+            self.params.append(p)
+        return p.data_ptr()
+
+    def param_grad(self, p):
+        """(ptr, accumulate) of the plan-owned gradient of parameter p."""
+        self.param(p)
+        if self.pgrad[p] is None:
+            self.pgrad[p] = torch.empty_like(p)
+        acc = 1 if p in self.pginit else 0
+        self.pginit.add(p)
+        return self.pgrad[p].data_ptr(), acc
+
+    def finalize(self):
+        """Emit the backward list (reverse op order) and allocate the scratch shared by all wgrad launches."""
+        for em in reversed(self._bwd_emitters):
+            em()
+        self._bwd_emitters = []
+        if self._wgrads:
+            ws = self.buf(max(w.ws_floats for w in self._wgrads))
+            for w in self._wgrads:
+                w.ws = ws.ptr
+
+    # ---------------- command helpers ----------------
+    def _add(self, lst, name, fn, *args):
+        lst.append((name, fn, args))
+
+    def run(self, cmds, stream):
+        for name, fn, args in cmds:
+            rc = fn(*args, stream)
+            if rc:
+                L.check(rc, name)
+
+    def src(self, act, relu_in=False):
+        s = L.Src()
+        s.x = act.raw.ptr
+        if act.bn is not None:
+            s.a, s.b = act.bn.a.ptr, act.bn.b.ptr
+        s.ld, s.C, s.relu = act.raw.ld, act.raw.C, int(bool(act.relu or relu_in))
+        return s
+
+    def _dab(self, act, rows):
+        """Allocate a (dA,dB) partial slab for a lazy source whose BN is in training mode."""
+        if act.bn is None or not act.bn.training or not self.want_grad:
+            return None
+        slab = self.buf(rows * act.C * 2)
+        return slab
+
+    # ---------------- ops ----------------
+    def conv(self, srcs, weight, Cout, k, stride=1, pad=0, dil=1, relu_in=False, bias=None, bias_n=None,
+             out=None, stats=None, stats_ld=0, out_hw=None, w_choff=0, cin_total=None):
+        """Dense conv over virtually concatenated `srcs` (list of Act).  Returns the raw output TRef."""
+        lib = self.lib
+        a0 = srcs[0]
+        N, H, W = a0.N, a0.H, a0.W
+        if out_hw is None:
+            OH = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            OW = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        else:
+            OH, OW = out_hw
+        csum = sum(s.C for s in srcs)
+        cin_total = cin_total or csum
+        if out is None:
+            out = self.tensor(N, OH, OW, Cout)
+        assert (out.N, out.H, out.W, out.C) == (N, OH, OW, Cout), 'conv output geometry'
+        assert len(srcs) <= L.MAX_SRC
+        wptr = self.param(weight)
+        ldw = k * k * cin_total
+        assert weight.numel() == Cout * ldw, 'weight %s does not match Cout=%d k=%d cin=%d' % (tuple(weight.shape), Cout, k, cin_total)
+        ar = L.ConvArgs()
+        for i, s in enumerate(srcs):
+            assert (s.N, s.H, s.W) == (N, H, W), 'virtual concat needs equal spatial size'
+            ar.src[i] = self.src(s, relu_in)
+        ar.nsrc = len(srcs)
+        ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
+        ar.KH = ar.KW = k
+        ar.stride, ar.pad, ar.dil, ar.Cout = stride, pad, dil, Cout
+        ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = ldw, cin_total, w_choff, out.ld
+        ar.w, ar.y = wptr, out.ptr
+        ar.bias = self.param(bias) if bias is not None else None
+        ar.bias_n = bias_n.ptr if bias_n is not None else None
+        ar.stats = stats.ptr if stats is not None else None
+        ar.stats_ld = stats_ld
+        self.keep.append(ar)
+        self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar))
+
+        if self.want_grad:
+            srcs_l = list(srcs)
+
+            def emit_bwd():
+                if not self.grad_ready(out):
+                    return
+                dy = self.grad(out)
+                P = N * OH * OW
+                if bias is not None:
+                    self._colsum(dy, bias, per_image=False)
+                if bias_n is not None:
+                    gbn = self.grad(bias_n)
+                    self._colsum_n(dy, gbn)
+                choff = w_choff
+                for s in srcs_l:
+                    # weight gradient
+                    wa = L.ConvWgradArgs()
+                    wa.dy, wa.lddy, wa.Cout = dy.ptr, dy.ld, Cout
+                    wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, OH, OW, k, k, stride, pad, dil
+                    wa.src = self.src(s, relu_in)
+                    gp, acc = self.param_grad(weight)
+                    wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = gp, ldw, cin_total, choff, acc
+                    wa.ws_floats = lib.addk_conv_wgrad_ws(P, Cout, s.C, k * k)
+                    self._wgrads.append(wa)
+                    self._add(self.bwd, 'conv_wgrad', lib.addk_conv_wgrad, C.byref(wa))
+                    # data gradient
+                    if s.needs_grad:
+                        da = L.ConvDgradArgs()
+                        da.dy, da.lddy, da.Cout = dy.ptr, dy.ld, Cout
+                        da.N, da.H, da.W, da.OH, da.OW, da.KH, da.KW, da.stride, da.pad, da.dil = N, H, W, OH, OW, k, k, stride, pad, dil
+                        da.w, da.ldw, da.cin_total, da.w_choff = wptr, ldw, cin_total, choff
+                        da.dst = self.src(s, relu_in)
+                        gs = self.grad(s.raw)
+                        da.g, da.ldg, da.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
+                        rows = lib.addk_conv_rows(N * H * W, s.C)
+                        slab = self._dab(s, rows)
+                        if slab is not None:
+                            da.dab = slab.ptr
+                            s.bn.slabs.append((slab.ptr, rows))
+                        self.keep.append(da)
+                        self._add(self.bwd, 'conv_dgrad', lib.addk_conv_dgrad, C.byref(da))
+                    choff += s.C
+            self._bwd_emitters.append(emit_bwd)
+        return out
+
+    def _colsum(self, dy, bias, per_image):
+        """bias gradient: db[c] = sum_p dy[p,c]  (via the GAP kernel over all N*H*W pixels as one 'image')."""
+        lib = self.lib
+        s = L.Src(); s.x, s.ld, s.C, s.relu = dy.ptr, dy.ld, dy.C, 0
+        tmp = self.vec(dy.C)
+        rows = lib.addk_ew_rows(dy.P, dy.C)
+        ws = self.buf(rows * dy.C)
+        self.keep.append(s)
+        self._add(self.bwd, 'bias_grad', lib.addk_gap_fwd, C.byref(s), 1, dy.P, tmp.ptr, dy.C, ws.ptr, 0)
+        gp, acc = self.param_grad(bias)
+        one = L.AffineSumArgs()
+        t = L.Src(); t.x, t.ld, t.C = tmp.ptr, dy.C, dy.C
+        one.term[0] = t; one.nterm = 1; one.P = 1; one.C = dy.C
+        one.out, one.ldo, one.relu_out, one.accumulate = gp, dy.C, 0, acc
+        self.keep.append(one)
+        self._add(self.bwd, 'bias_grad_acc', lib.addk_affine_sum_fwd, C.byref(one))
+
+    def _colsum_n(self, dy, gbn):
+        """per-image bias gradient: g[n,c] = sum_{p in image n} dy[p,c]."""
+        lib = self.lib
+        s = L.Src(); s.x, s.ld, s.C, s.relu = dy.ptr, dy.ld, dy.C, 0
+        rows = lib.addk_ew_rows(dy.H * dy.W, dy.C)
+        ws = self.buf(dy.N * rows * dy.C)
+        assert self.acc_flag(gbn) == 0
+        self.keep.append(s)
+        self._add(self.bwd, 'bias_n_grad', lib.addk_gap_fwd, C.byref(s), dy.N, dy.H * dy.W, gbn.ptr, gbn.ld, ws.ptr, 0)
+
+    def stats_slab(self, P, Cc):
+        rows = self.lib.addk_conv_rows(P, Cc)
+        return self.buf(rows * Cc * 2), rows
+
+    def bn(self, raw, mod, slab=None, rows=0, post_relu=False, needs_grad=True):
+        """Apply BatchNorm module `mod` lazily to `raw`.  Training: statistics come from `slab`."""
+        lib = self.lib
+        Cc = raw.C
+        a, b = self.vec(Cc), self.vec(Cc)
+        training = self.training and mod.training
+        count = float(raw.P)
+        st = BNState(mod, Cc, a, b, training, count)
+        gam = self.param(mod.weight) if mod.weight is not None else None
+        bet = self.param(mod.bias) if mod.bias is not None else None
+        if training:
+            st.mean, st.invstd = self.vec(Cc), self.vec(Cc)
+            sync = self.world is not None and getattr(mod, 'sync', False) and self.world.size > 1
+            fa = L.BnFinalizeArgs()
+            if sync:
+                red = self.vec(2 * Cc)
+                self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, red.ptr)
+                self.world.emit_allreduce(self, self.fwd, red)    # every rank has the same per-rank count
+                fa.partial, fa.rows = red.ptr, 1
+                st.count = count * self.world.size
+            else:
+                fa.partial, fa.rows = slab.ptr, rows
+            fa.C, fa.count = Cc, st.count
+            fa.gamma, fa.beta = gam, bet
+            if mod.track_running_stats and mod.running_mean is not None:
+                fa.running_mean, fa.running_var = mod.running_mean.data_ptr(), mod.running_var.data_ptr()
+                if mod.num_batches_tracked is not None:
+                    self.nbt[mod.num_batches_tracked] = self.nbt.get(mod.num_batches_tracked, 0) + 1
+            fa.momentum = 0.1 if mod.momentum is None else mod.momentum
+            fa.eps = mod.eps
+            fa.a, fa.b, fa.mean, fa.invstd = a.ptr, b.ptr, st.mean.ptr, st.invstd.ptr
+            self.keep.append(fa)
+            self._add(self.fwd, 'bn_finalize', lib.addk_bn_finalize, C.byref(fa))
+        else:
+            self._add(self.fwd, 'bn_eval_affine', lib.addk_bn_eval_affine, gam, bet, mod.running_mean.data_ptr(),
+                      mod.running_var.data_ptr(), mod.eps, Cc, a.ptr, b.ptr)
+        act = Act(raw, st, post_relu, needs_grad and self.want_grad)
+
+        if self.want_grad and training:
+            def emit_bwd():
+                if not self.grad_ready(raw) and not st.slabs:
+                    return
+                if not self.grad_ready(raw):
+                    raise RuntimeError('BN output received (dA,dB) but no direct gradient')
+                g = self.grad(raw)
+                ba = L.BnBwdArgs()
+                assert len(st.slabs) <= L.MAX_SLAB, 'too many consumers of one BatchNorm output (%d)' % len(st.slabs)
+                for i, (p, r) in enumerate(st.slabs):
+                    ba.slab[i], ba.rows[i] = p, r
+                ba.nslab, ba.C, ba.count = len(st.slabs), Cc, st.count
+                ba.gamma, ba.mean, ba.invstd, ba.a = gam, st.mean.ptr, st.invstd.ptr, a.ptr
+                if mod.weight is not None:
+                    gp, acc = self.param_grad(mod.weight)
+                    bp, acc2 = self.param_grad(mod.bias)
+                    assert acc == acc2
+                    ba.dgamma, ba.dbeta, ba.accumulate = gp, bp, acc
+                c1, c2 = self.vec(Cc), self.vec(Cc)
+                sync = self.world is not None and getattr(mod, 'sync', False) and self.world.size > 1
+                self.keep.append(ba)
+                if sync:
+                    dmv = self.vec(2 * Cc)
+                    ba.dmv = dmv.ptr
+                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba))
+                    self.world.emit_allreduce(self, self.bwd, dmv)
+                    self._add(self.bwd, 'bn_bwd_coeffs', lib.addk_bn_bwd_coeffs_from_dmv, dmv.ptr, Cc, st.count, c1.ptr, c2.ptr)
+                else:
+                    ba.c1, ba.c2 = c1.ptr, c2.ptr
+                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba))
+                # dy_raw = G + c1 + c2*x, in place on the accumulated gradient
+                self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, None, c1.ptr, c2.ptr,
+                          raw.P, Cc, g.ptr, g.ld)
+            self._bwd_emitters.append(emit_bwd)
+        return act
+
+    def conv_bn(self, srcs, conv_mod, bn_mod, relu_in, post_relu=False, out=None, **kw):
+        """ReLU? -> Conv -> BN (lazy).  conv_mod/bn_mod are nn.Conv2d / nn.BatchNorm2d parameter holders."""
+        k = conv_mod.kernel_size[0]
+        a0 = srcs[0]
+        stride, pad, dil = conv_mod.stride[0], conv_mod.padding[0], conv_mod.dilation[0]
+        OH = (a0.H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        OW = (a0.W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        Cout = conv_mod.out_channels
+        slab = rows = None
+        training = self.training and bn_mod.training
+        if training:
+            slab, rows = self.stats_slab(a0.N * OH * OW, Cout)
+        raw = self.conv(srcs, conv_mod.weight, Cout, k, stride, pad, dil, relu_in, out=out, stats=slab, **kw)
+        return self.bn(raw, bn_mod, slab, rows or 0, post_relu)
+
+    def dwconv(self, src, conv_mod, relu_in):
+        """Depthwise conv; returns a materialised Act."""
+        lib = self.lib
+        k = conv_mod.kernel_size[0]
+        stride, pad, dil = conv_mod.stride[0], conv_mod.padding[0], conv_mod.dilation[0]
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        OH = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        OW = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        out = self.tensor(N, OH, OW, Cc)
+        wptr = self.param(conv_mod.weight)
+        ar = L.DwArgs()
+        ar.src = self.src(src, relu_in)
+        ar.N, ar.H, ar.W, ar.OH, ar.OW, ar.KH, ar.KW, ar.stride, ar.pad, ar.dil = N, H, W, OH, OW, k, k, stride, pad, dil
+        ar.w, ar.y, ar.ldy = wptr, out.ptr, out.ld
+        self.keep.append(ar)
+        self._add(self.fwd, 'dw_fwd', lib.addk_dw_fwd, C.byref(ar))
+        act = Act(out, None, False, self.want_grad)
+        if self.want_grad:
+            def emit_bwd():
+                if not self.grad_ready(out):
+                    return
+                dy = self.grad(out)
+                ba = L.DwBwdArgs()
+                ba.dy, ba.lddy = dy.ptr, dy.ld
+                ba.N, ba.H, ba.W, ba.OH, ba.OW, ba.KH, ba.KW, ba.stride, ba.pad, ba.dil = N, H, W, OH, OW, k, k, stride, pad, dil
+                ba.src = self.src(src, relu_in)
+                ba.w = wptr
+                rows = lib.addk_dw_rows(N * H * W, Cc)
+                if src.needs_grad:
+                    gs = self.grad(src.raw)
+                    ba.g, ba.ldg, ba.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
+                    slab = self._dab(src, rows)
+                    if slab is not None:
+                        ba.dab = slab.ptr
+                        src.bn.slabs.append((slab.ptr, rows))
+                gp, acc = self.param_grad(conv_mod.weight)
+                ba.dw, ba.dw_accumulate = gp, acc
+                ws = self.buf(rows * Cc * k * k)
+                ba.ws = ws.ptr
+                self.keep.append(ba)
+                self._add(self.bwd, 'dw_bwd', lib.addk_dw_bwd, C.byref(ba))
+            self._bwd_emitters.append(emit_bwd)
+        return act
+
+    def affine_sum(self, terms, out=None, relu_out=False):
+        """Materialise sum_i relu_i?(a_i*x_i+b_i) (optionally ReLU'd) into `out`."""
+        lib = self.lib
+        terms = [t for t in terms if not t.zero]
+        t0 = terms[0]
+        if out is None:
+            out = self.tensor(t0.N, t0.H, t0.W, t0.C)
+        assert len(terms) <= L.MAX_TERMS
+        ar = L.AffineSumArgs()
+        for i, t in enumerate(terms):
+            assert (t.N, t.H, t.W, t.C) == (out.N, out.H, out.W, out.C), 'branch shapes differ'
+            ar.term[i] = self.src(t)
+        ar.nterm, ar.P, ar.C = len(terms), out.P, out.C
+        ar.out, ar.ldo, ar.relu_out, ar.accumulate = out.ptr, out.ld, int(relu_out), 0
+        self.keep.append(ar)
+        self._add(self.fwd, 'affine_sum', lib.addk_affine_sum_fwd, C.byref(ar))
+        ng = self.want_grad and any(t.needs_grad for t in terms)
+        act = Act(out, None, False, ng)
+        if ng:
+            def emit_bwd():
+                if not self.grad_ready(out):
+                    return
+                do = self.grad(out)
+                ba = L.AffineSumBwdArgs()
+                rows = lib.addk_ew_rows(out.P, out.C)
+                for i, t in enumerate(terms):
+                    ba.term[i] = self.src(t)
+                    if t.needs_grad:
+                        gt = self.grad(t.raw)
+                        ba.g[i], ba.ldg[i], ba.accumulate[i] = gt.ptr, gt.ld, self.acc_flag(gt)
+                        slab = self._dab(t, rows)
+                        if slab is not None:
+                            ba.dab[i] = slab.ptr
+                            t.bn.slabs.append((slab.ptr, rows))
+                ba.nterm, ba.P, ba.C = len(terms), out.P, out.C
+                ba.dout, ba.lddo = do.ptr, do.ld
+                ba.out, ba.ldo, ba.relu_out = out.ptr, out.ld, int(relu_out)
+                self.keep.append(ba)
+                self._add(self.bwd, 'affine_sum_bwd', lib.addk_affine_sum_bwd, C.byref(ba))
+            self._bwd_emitters.append(emit_bwd)
+        return act
+
+    def materialize(self, act, relu_in=False):
+        if act.bn is None and not (act.relu or relu_in):
+            return act
+        a = Act(act.raw, act.bn, act.relu or relu_in, act.needs_grad)
+        return self.affine_sum([a])
+
+    def resize(self, src, OH, OW, relu_in=False):
+        """Bilinear resize.  A lazy BN without pending ReLU passes through (affine commutes with
+        interpolation); a pending ReLU forces materialisation."""
+        lib = self.lib
+        relu = bool(src.relu or relu_in)
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        out = self.tensor(N, OH, OW, Cc)
+        ar = L.ResizeArgs()
+        carrier = src if relu else Act(src.raw, None, False, src.needs_grad)
+        ar.src = self.src(carrier, relu_in)
+        ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
+        ar.y, ar.ldy, ar.nchw_out = out.ptr, out.ld, 0
+        self.keep.append(ar)
+        self._add(self.fwd, 'resize_fwd', lib.addk_resize_fwd, C.byref(ar))
+        res = Act(out, None if relu else src.bn, False, src.needs_grad)
+        if self.want_grad and src.needs_grad:
+            def emit_bwd():
+                if not self.grad_ready(out):
+                    return
+                dy = self.grad(out)
+                ba = L.ResizeBwdArgs()
+                ba.dy, ba.lddy, ba.nchw_in = dy.ptr, dy.ld, 0
+                ba.src = self.src(carrier, relu_in)
+                ba.N, ba.H, ba.W, ba.OH, ba.OW = N, H, W, OH, OW
+                gs = self.grad(src.raw)
+                ba.g, ba.ldg, ba.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
+                if relu:
+                    rows = lib.addk_ew_rows(N * H * W, Cc)
+                    slab = self._dab(src, rows)
+                    if slab is not None:
+                        ba.dab = slab.ptr
+                        src.bn.slabs.append((slab.ptr, rows))
+                self.keep.append(ba)
+                self._add(self.bwd, 'resize_bwd', lib.addk_resize_bwd, C.byref(ba))
+            self._bwd_emitters.append(emit_bwd)
+        return res
+
+    def resize_to_nchw(self, src, OH, OW):
+        """Final logits resize (decoder.py:28) into a contiguous [N,C,OH,OW] tensor.  Returns (tensor, dy_setter)."""
+        lib = self.lib
+        assert src.bn is None and not src.relu
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        y = torch.empty((N, Cc, OH, OW), dtype=torch.float32, device=self.device)
+        self.nbytes += y.numel() * 4
+        ar = L.ResizeArgs()
+        ar.src = self.src(src)
+        ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
+        ar.y, ar.ldy, ar.nchw_out = y.data_ptr(), 0, 1
+        self.keep.append(ar)
+        self._add(self.fwd, 'resize_nchw', lib.addk_resize_fwd, C.byref(ar))
+        out = OutRef(y)
+        if self.want_grad and src.needs_grad:
+            def emit_bwd():
+                if out.dy_ptr is None and not out.dynamic:
+                    return
+                ba = L.ResizeBwdArgs()
+                ba.dy = out.dy_ptr
+                ba.lddy, ba.nchw_in = 0, 1
+                ba.dy_scale = out.dy_scale
+                ba.src = self.src(src)
+                ba.N, ba.H, ba.W, ba.OH, ba.OW = N, H, W, OH, OW
+                gs = self.grad(src.raw)
+                ba.g, ba.ldg, ba.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
+                self.keep.append(ba)
+                out.bwd_args = ba
+                self._add(self.bwd, 'resize_nchw_bwd', lib.addk_resize_bwd, C.byref(ba))
+            self._bwd_emitters.append(emit_bwd)
+        return out
+
+    def gap(self, src, relu_in=False):
+        lib = self.lib
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        out = self.tensor(N, 1, 1, Cc)
+        s = self.src(src, relu_in)
+        rows = lib.addk_ew_rows(H * W, Cc)
+        ws = self.buf(N * rows * Cc)
+        self.keep.append(s)
+        self._add(self.fwd, 'gap_fwd', lib.addk_gap_fwd, C.byref(s), N, H * W, out.ptr, out.ld, ws.ptr, 1)
+        act = Act(out, None, False, self.want_grad and src.needs_grad)
+        if act.needs_grad:
+            def emit_bwd():
+                if not self.grad_ready(out):
+                    return
+                dy = self.grad(out)
+                gs = self.grad(src.raw)
+                acc = self.acc_flag(gs)
+                rows2 = lib.addk_ew_rows(N * H * W, Cc)
+                slab = self._dab(src, rows2)
+                if slab is not None:
+                    src.bn.slabs.append((slab.ptr, rows2))
+                self._add(self.bwd, 'gap_bwd', lib.addk_gap_bwd, C.byref(s), N, H * W, dy.ptr, dy.ld, gs.ptr, gs.ld, acc,
+                          slab.ptr if slab is not None else None)
+            self._bwd_emitters.append(emit_bwd)
+        return act
+
+    def pool3(self, src, stride, mode):
+        lib = self.lib
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        out = self.tensor(N, OH, OW, Cc)
+        s = self.src(src)
+        self.keep.append(s)
+        self._add(self.fwd, 'pool3_fwd', lib.addk_pool3_fwd, C.byref(s), N, H, W, OH, OW, stride, mode, out.ptr, out.ld)
+        act = Act(out, None, False, self.want_grad and src.needs_grad)
+        if act.needs_grad:
+            assert src.bn is None or not src.bn.training, 'pool3 backward through a lazy training BN is not built (cold path)'
+
+            def emit_bwd():
+                if not self.grad_ready(out):
+                    return
+                dy = self.grad(out)
+                gs = self.grad(src.raw)
+                self._add(self.bwd, 'pool3_bwd', lib.addk_pool3_bwd, C.byref(s), N, H, W, OH, OW, stride, mode, dy.ptr, dy.ld,
+                          gs.ptr, gs.ld, self.acc_flag(gs))
+            self._bwd_emitters.append(emit_bwd)
+        return act
+
+    def zeros(self, N, H, W, Cc):
+        t = TRef(self.buf(N * H * W * Cc, zero=True), 0, N, H, W, Cc, Cc)
+        return Act(t, None, False, False, zero=True)
+
+    def input_nchw(self, x, requires_grad=False, ld=None):
+        """Stage an NCHW torch tensor into the plan.  Returns (Act, InRef)."""
+        lib = self.lib
+        N, Cc, H, W = x.shape
+        t = self.tensor(N, H, W, Cc, ld)
+        inref = InRef(tuple(x.shape))
+        self._add(self.fwd, 'nchw_to_nhwc', _in_stage, lib, inref, N, Cc, H * W, t.ptr, t.ld)
+        act = Act(t, None, False, requires_grad and self.want_grad)
+        if act.needs_grad:
+            gx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=self.device)
+            inref.grad = gx
+
+            def emit_bwd():
+                if not self.grad_ready(t):
+                    inref.grad = None
+                    return
+                g = self.grad(t)
+                s = L.Src(); s.x, s.ld, s.C = g.ptr, g.ld, g.C
+                self.keep.append(s)
+                self._add(self.bwd, 'in_grad_to_nchw', lib.addk_nhwc_to_nchw, C.byref(s), N, H * W, gx.data_ptr())
+            self._bwd_emitters.append(emit_bwd)
+        return act, inref
+
+    def output_nchw(self, act):
+        """Materialise `act` (incl. its lazy BN/ReLU) as a contiguous NCHW tensor."""
+        lib = self.lib
+        N, H, W, Cc = act.N, act.H, act.W, act.C
+        y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=self.device)
+        s = self.src(act)
+        self.keep.append(s)
+        self._add(self.fwd, 'nhwc_to_nchw', lib.addk_nhwc_to_nchw, C.byref(s), N, H * W, y.data_ptr())
+        out = OutRef(y)
+        if self.want_grad and act.needs_grad:
+            def emit_bwd():
+                gs = self.grad(act.raw)
+                acc = self.acc_flag(gs)
+                rows = lib.addk_ew_rows(N * H * W, Cc)
+                slab = self._dab(act, rows)
+                if slab is not None:
+                    act.bn.slabs.append((slab.ptr, rows))
+                cmd = ['out_grad', lib.addk_nchw_grad_to_nhwc, [None, C.byref(s), N, H * W, gs.ptr, gs.ld, acc,
+                                                                slab.ptr if slab is not None else None]]
+                out.bwd_cmd = cmd
+                self.bwd.append(cmd)
+            self._bwd_emitters.append(emit_bwd)
+        return out
+
+
+def require_device(x):
+    """The product path is HIP-only: no CPU fallback exists (tests use oracle/ as the CPU checker)."""
+    if not x.is_cuda:
+        raise L.AddkError('addk runs on the MI355X HIP path only: got a tensor on %s.  There is no CPU fallback.' % x.device)
+
+
+def current_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _in_stage(lib, inref, N, Cc, HW, ptr, ld, stream):
+    return lib.addk_nchw_to_nhwc(inref.ptr, N, Cc, HW, ptr, ld, stream)
+
+
+class InRef:
+    """Per-call input binding (pointer patched before each replay)."""
+
+    def __init__(self, shape):
+        self.shape, self.ptr, self.grad, self.keep = shape, None, None, None
+
+    def bind(self, x):
+        assert tuple(x.shape) == self.shape and x.dtype == torch.float32, 'input changed shape/dtype'
+        require_device(x)
+        x = x.contiguous()
+        self.keep, self.ptr = x, x.data_ptr()
+
+
+class OutRef:
+    """A plan output: tensor + how its incoming gradient pointer is patched per backward call."""
+
+    def __init__(self, y):
+        self.y = y
+        self.dy_ptr, self.dy_scale, self.dynamic = None, None, True
+        self.bwd_args = None     # ResizeBwdArgs (logits path)
+        self.bwd_cmd = None      # generic nhwc path
+
+    def set_grad(self, gy):
+        gy = gy.contiguous()
+        if self.bwd_args is not None:
+            self.bwd_args.dy = gy.data_ptr()
+        elif self.bwd_cmd is not None:
+            self.bwd_cmd[2][0] = gy.data_ptr()
+        return gy

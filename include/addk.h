@@ -1,0 +1,296 @@
+/*
+ * addk — C ABI of the MI355X (gfx950) kernels behind the Auto-Dynamic-DeepLab hot path.
+ *
+ * The reference has no native interface: its boundary is a Python object protocol
+ * (SURVEY.md §8b).  Each entry point below replaces one family of PyTorch op call
+ * sites on that path; the reference file:line it replaces is cited per function.
+ * The Python host (auto-dynamic-deeplab_amd/, imported as `addk`) binds these with
+ * ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every tensor is fp32, NHWC ("pixel-major"): element (n,h,w,c) of a tensor with pixel
+ *     stride `ld` lives at  base[((n*H + h)*W + w)*ld + c].  `ld >= C` lets a tensor be a
+ *     channel slice of a wider concat buffer (producers write at a channel offset, so
+ *     torch.cat on the path — ADD.py:92,112, aspp_train.py:57, decoder.py:26 — is free).
+ *   - a "lazy" activation is (raw, a, b, relu): its value is relu?(a[c]*raw + b[c]).
+ *     BatchNorm (+ReLU) is never materialised: the consumer applies it while staging
+ *     its input tile (a == NULL means a=1,b=0).
+ *   - all pointers are device pointers; nothing is allocated or freed; no host sync;
+ *     every launch goes to `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 ok, <0 error (see addk_last_error()).
+ *   - float4 paths need base pointers 16-byte aligned and ld, C, channel offsets % 4 == 0;
+ *     otherwise a scalar path is taken automatically.
+ */
+#ifndef ADDK_H_
+#define ADDK_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADDK_MAX_SRC 12
+#define ADDK_MAX_SLAB 32
+#define ADDK_MAX_TERMS 4
+
+#define ADDK_OK 0
+#define ADDK_ERR_INVALID (-1)
+#define ADDK_ERR_UNSUPPORTED (-2)
+#define ADDK_ERR_HIP (-3)
+
+const char* addk_last_error(void);
+int addk_version(void);
+/* Probes MFMA f32 16x16x4 fragment layout on the device: out[256] = A(16x4)·B(4x16) with
+ * A[i][k] = i*4+k, B[k][j] = (k+1)*(j+2) (asymmetric).  Used by smoke tests. */
+int addk_selftest_mfma(float* out256, void* stream);
+
+/* One source of a virtually concatenated NHWC input. */
+typedef struct addk_src {
+  const float* x;   /* raw data at channel 0 of this source, pixel 0 */
+  const float* a;   /* lazy-BN scale [C] or NULL */
+  const float* b;   /* lazy-BN shift [C] or NULL */
+  int32_t ld;       /* pixel stride (floats) */
+  int32_t C;        /* channels of this source */
+  int32_t relu;     /* ReLU after the affine */
+  int32_t _pad;
+} addk_src;
+
+/* ---------------------------------------------------------------------------------------
+ * Dense convolution, implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32).
+ * Replaces nn.Conv2d(groups=1) call sites: operations.py:24,38,53,57,91-92,109-110;
+ * ADD.py:155,161,167,257; aspp_train.py:16-25; decoder.py:14,18,21, with the preceding
+ * ReLU / BatchNorm of the producer fused as the input prologue and the per-channel
+ * (sum, sum of squares) needed by the following training-mode BatchNorm fused as the
+ * epilogue.  Weights are "OHWI": w[co*ldw + (kh*KW+kw)*cin_total + ci] — the memory of a
+ * torch [O,I,KH,KW] tensor in channels_last format.  `pad` may be negative
+ * (FactorizedReduce's shifted branch, operations.py:94,99).
+ * ------------------------------------------------------------------------------------- */
+typedef struct addk_conv_args {
+  addk_src src[ADDK_MAX_SRC];
+  int32_t nsrc;
+  int32_t N, H, W;            /* input spatial size */
+  int32_t OH, OW;             /* output spatial size */
+  int32_t KH, KW, stride, pad, dil;
+  int32_t Cout;
+  int32_t ldw;                /* weight row stride (floats) */
+  int32_t cin_total;          /* channels per tap in the weight layout */
+  int32_t w_choff;            /* channel offset of src[0] inside a tap (sources are consecutive) */
+  int32_t ldy;
+  const float* w;
+  float* y;                   /* raw output at channel 0 of the destination slice */
+  const float* bias;          /* [Cout] or NULL (decoder.py:21) */
+  const float* bias_n;        /* [N][Cout] per-image bias or NULL (ASPP image-pool branch folded
+                                 into conv1, aspp_train.py:50-59) */
+  float* stats;               /* [rows][stats_ld][2] partial (sum, sumsq) or NULL; rows = addk_conv_rows().
+                                 Points at this conv's first channel inside the row. */
+  int32_t stats_ld;           /* channels per slab row (>= Cout; FactorizedReduce's two convs share one BN) */
+  int32_t _pad;
+} addk_conv_args;
+int addk_conv_fwd(const addk_conv_args* a, void* stream);
+/* number of partial-statistics rows a launch with these shapes writes (<= 1024) */
+int addk_conv_rows(int64_t P, int32_t Cout);
+
+/* Data gradient of the same convolution with respect to ONE source (autograd of
+ * nn.Conv2d + the ReLU/BN prologue):  g[p,c] (+)= da_mask * sum_{tap,co} dy[..]*w[..], where
+ * da_mask = a[c] * (relu ? a[c]*x[p,c]+b[c] > 0 : 1).  Also emits the partial reductions
+ * dA[c] = sum_p dz*mask*x, dB[c] = sum_p dz*mask that drive the producer BN's backward. */
+typedef struct addk_conv_dgrad_args {
+  const float* dy; int32_t lddy; int32_t Cout;     /* gradient of the raw conv output [N,OH,OW,Cout] */
+  int32_t N, H, W, OH, OW, KH, KW, stride, pad, dil;
+  const float* w; int32_t ldw, cin_total, w_choff; /* w_choff: channel offset of THIS source in a tap */
+  addk_src dst;                /* the source whose gradient is produced (x,a,b,relu,ld,C) */
+  float* g; int32_t ldg;       /* gradient wrt dst.x (raw), same geometry as dst */
+  int32_t accumulate;          /* 0: overwrite g, 1: g += */
+  float* dab;                  /* [rows][C][2] partial (dA,dB) or NULL; rows = addk_conv_rows(N*H*W, C) */
+} addk_conv_dgrad_args;
+int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream);
+
+/* Weight gradient for ONE source: dw[co][tap][w_choff+ci] = sum_p dy[p,co] * z[p@tap,ci],
+ * z = relu?(a*x+b).  Deterministic split-P: partial tiles go to `ws`, then are reduced into
+ * dw (accumulate: the shared ASPP/decoder head is used once per exit — SURVEY Q4). */
+typedef struct addk_conv_wgrad_args {
+  const float* dy; int32_t lddy; int32_t Cout;
+  int32_t N, H, W, OH, OW, KH, KW, stride, pad, dil;
+  addk_src src;
+  float* dw; int32_t ldw, cin_total, w_choff;
+  int32_t accumulate;
+  float* ws; int64_t ws_floats;  /* workspace, >= addk_conv_wgrad_ws() floats */
+} addk_conv_wgrad_args;
+int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream);
+int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_t taps);
+
+/* ---------------------------------------------------------------------------------------
+ * Depthwise k x k convolution (groups == C), stride 1 or 2, pad k/2*dil: the depthwise
+ * halves of SepConv (operations.py:52,56).  w is [C][KH*KW] (torch [C,1,KH,KW]).
+ * ------------------------------------------------------------------------------------- */
+typedef struct addk_dw_args {
+  addk_src src;
+  int32_t N, H, W, OH, OW, KH, KW, stride, pad, dil;
+  const float* w;
+  float* y; int32_t ldy;
+} addk_dw_args;
+int addk_dw_fwd(const addk_dw_args* a, void* stream);
+
+typedef struct addk_dw_bwd_args {
+  const float* dy; int32_t lddy;
+  int32_t N, H, W, OH, OW, KH, KW, stride, pad, dil;
+  addk_src src;                 /* forward input (x,a,b,relu) */
+  const float* w;
+  float* g; int32_t ldg; int32_t accumulate;   /* gradient wrt src.x (may be NULL: skip dgrad) */
+  float* dab;                   /* [rows][C][2] or NULL; rows = addk_dw_rows() */
+  float* dw; int32_t dw_accumulate;            /* [C][KH*KW] */
+  float* ws;                    /* [rows][C][KH*KW] partial weight gradients */
+} addk_dw_bwd_args;
+int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream);
+int addk_dw_rows(int64_t P, int32_t C);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm statistics (F.batch_norm training mode, batchnorm.py:51-53; eps=1e-5, mom=0.1).
+ * ------------------------------------------------------------------------------------- */
+typedef struct addk_bn_finalize_args {
+  const float* partial;  /* [rows][C][2] (sum, sumsq) — or the all-reduced [1][C][2] */
+  int32_t rows, C;
+  double count;          /* number of values per channel (global batch under SyncBN) */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;   /* updated in place (NULL: skip) */
+  float momentum, eps;
+  float* a; float* b;            /* out: lazy affine  a = gamma*invstd, b = beta - mean*a */
+  float* mean; float* invstd;    /* out: saved for backward */
+} addk_bn_finalize_args;
+int addk_bn_finalize(const addk_bn_finalize_args* a, void* stream);
+
+/* sum the rows of a partial slab into out[C][2] (the vector that is all-reduced over RCCL) */
+int addk_slab_reduce(const float* partial, int32_t rows, int32_t C, float* out, void* stream);
+
+/* eval mode: a = gamma/sqrt(running_var+eps), b = beta - running_mean*a */
+int addk_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
+                        float eps, int32_t C, float* a, float* b, void* stream);
+
+/* Backward of the statistics + affine:  given the partial (dA,dB) slabs of every consumer,
+ *   dgamma (+)= invstd*(dA - mean*dB), dbeta (+)= dB,
+ *   dmean_tot = -a*dB - 2*mean*dvar,  dvar = -0.5*gamma*(dA-mean*dB)*invstd^3,
+ *   c1 = dmean_tot/count, c2 = 2*dvar/count  so that  dx_raw = G + c1 + c2*x.
+ * With SyncBN, `dmv` receives (dmean_tot, dvar) per channel for the cross-rank all-reduce
+ * and addk_bn_bwd_coeffs_from_dmv() finishes the job. */
+typedef struct addk_bn_bwd_args {
+  const float* slab[ADDK_MAX_SLAB]; int32_t rows[ADDK_MAX_SLAB]; int32_t nslab;
+  int32_t C; double count;
+  const float* gamma; const float* mean; const float* invstd; const float* a;
+  float* dgamma; float* dbeta; int32_t accumulate;
+  float* c1; float* c2;          /* out (NULL when dmv is used) */
+  float* dmv;                    /* out [C][2] (dmean_tot, dvar) or NULL */
+} addk_bn_bwd_args;
+int addk_bn_bwd(const addk_bn_bwd_args* a, void* stream);
+int addk_bn_bwd_coeffs_from_dmv(const float* dmv, int32_t C, double count, float* c1, float* c2, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Elementwise "materialise" kernels.
+ * affine_sum: out[p,c] = relu?( sum_i (a_i[c]*x_i[p,c] + b_i[c]) )  — the 2-way branch sum of a
+ *   cell block (ADD.py:108) written straight into its slot of the concat buffer (ADD.py:112).
+ * ------------------------------------------------------------------------------------- */
+typedef struct addk_affine_sum_args {
+  addk_src term[ADDK_MAX_TERMS]; int32_t nterm;   /* term.relu applies per term */
+  int64_t P; int32_t C;
+  float* out; int32_t ldo; int32_t relu_out; int32_t accumulate;
+} addk_affine_sum_args;
+int addk_affine_sum_fwd(const addk_affine_sum_args* a, void* stream);
+
+/* backward: for every term i with g_i != NULL:  g_i (+)= a_i*mask_i*dout,  dab_i = partial (sum dout*mask*x_i, sum dout*mask) */
+typedef struct addk_affine_sum_bwd_args {
+  addk_src term[ADDK_MAX_TERMS]; int32_t nterm;
+  int64_t P; int32_t C;
+  const float* dout; int32_t lddo;
+  const float* out; int32_t ldo; int32_t relu_out;   /* forward output, needed only when relu_out */
+  float* g[ADDK_MAX_TERMS]; int32_t ldg[ADDK_MAX_TERMS]; int32_t accumulate[ADDK_MAX_TERMS];
+  float* dab[ADDK_MAX_TERMS];     /* [rows][C][2] partials, rows = addk_ew_rows(P, C) */
+} addk_affine_sum_bwd_args;
+int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stream);
+int addk_ew_rows(int64_t P, int32_t C);
+
+/* dy[p,c] = alpha[c]*g[p,c] + c1[c] + c2[c]*x[p,c]   (BN backward applied to the accumulated gradient;
+ * alpha/c1/c2 may be NULL = 1/0/0).  out may alias g. */
+int addk_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* alpha,
+                      const float* c1, const float* c2, int64_t P, int32_t C, float* out, int32_t ldo,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=False, no antialias (F.interpolate call sites ADD.py:76-77,
+ * 84,89,317; decoder.py:24,28).  Optional lazy prologue on the input; NCHW output / NCHW
+ * gradient input for the final logits (decoder.py:28) so the caller sees [N,C,H,W].
+ * ------------------------------------------------------------------------------------- */
+typedef struct addk_resize_args {
+  addk_src src; int32_t N, H, W, OH, OW;
+  float* y; int32_t ldy;        /* NHWC destination (ignored when nchw_out) */
+  int32_t nchw_out;             /* 1: y is [N,C,OH,OW] contiguous */
+} addk_resize_args;
+int addk_resize_fwd(const addk_resize_args* a, void* stream);
+
+typedef struct addk_resize_bwd_args {
+  const float* dy; int32_t lddy; int32_t nchw_in;   /* gradient of the resized tensor */
+  const float* dy_scale;        /* optional device scalar multiplying dy (loss scale) */
+  addk_src src; int32_t N, H, W, OH, OW;
+  float* g; int32_t ldg; int32_t accumulate;
+  float* dab;                   /* [rows][C][2] or NULL (only with a lazy+relu prologue) */
+} addk_resize_bwd_args;
+int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Global average pool with lazy prologue (AdaptiveAvgPool2d(1), aspp_train.py:13,50; ADD.py:506).
+ * y[n,c] = mean_hw relu?(a*x+b).  Backward: g (+)= mask*a*dy[n,c]/(H*W).
+ * ------------------------------------------------------------------------------------- */
+/* ws: >= N * addk_ew_rows(HW, C) * C floats of scratch; mean=0 returns the plain per-image sum
+ * (used for bias gradients). */
+int addk_gap_fwd(const addk_src* src, int32_t N, int32_t HW, float* y, int32_t ldy, float* ws, int32_t mean, void* stream);
+int addk_gap_bwd(const addk_src* src, int32_t N, int32_t HW, const float* dy, int32_t lddy,
+                 float* g, int32_t ldg, int32_t accumulate, float* dab, void* stream);
+
+/* 3x3 pooling primitives of the registry (operations.py:9-10; cold on every shipped genotype).
+ * mode 0: max, 1: avg with count_include_pad=False.  pad=1. */
+int addk_pool3_fwd(const addk_src* src, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                   int32_t stride, int32_t mode, float* y, int32_t ldy, void* stream);
+int addk_pool3_bwd(const addk_src* src, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                   int32_t stride, int32_t mode, const float* dy, int32_t lddy,
+                   float* g, int32_t ldg, int32_t accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Layout transforms at the model boundary.
+ * ------------------------------------------------------------------------------------- */
+int addk_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int64_t HW, float* y, int32_t ldy, void* stream);
+int addk_nhwc_to_nchw(const addk_src* src, int32_t N, int64_t HW, float* y, void* stream);
+/* gradient of nhwc_to_nchw incl. the lazy prologue: g (+)= mask*a*dy_nchw, dab partials */
+int addk_nchw_grad_to_nhwc(const float* dy, const addk_src* src, int32_t N, int64_t HW,
+                           float* g, int32_t ldg, int32_t accumulate, float* dab, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Softmax cross-entropy over NCHW logits (nn.CrossEntropyLoss(weight, ignore_index), train.py:70,231).
+ * loss_out[0] += scale * sum_valid w[t]*nll / sum_valid w[t];  dlogits = scale*w[t]*(softmax-onehot)/wsum.
+ * `wsum` (device, 1 float) is produced by addk_ce_count.  target is int64 [N,H,W].
+ * `ws` is addk_ce_ws_floats() floats of scratch (per-block partial sums, reduced in a fixed order).
+ * ------------------------------------------------------------------------------------- */
+int addk_ce_count(const int64_t* target, int64_t n, const float* class_w, int32_t ignore_index,
+                  int32_t num_classes, float* wsum, float* ws, void* stream);
+int addk_ce_fwd_bwd(const float* logits, const int64_t* target, int32_t N, int32_t C, int64_t HW,
+                    const float* class_w, int32_t ignore_index, const float* wsum, float scale,
+                    float* loss_out, float* dlogits, float* ws, void* stream);
+int64_t addk_ce_ws_floats(int32_t N, int64_t HW);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused SGD (torch.optim.SGD(momentum, weight_decay, nesterov), train.py:126) on a flat buffer.
+ *   d = g*gscale + wd*p;  buf = first ? d : mom*buf + d;  p -= lr*(nesterov ? d + mom*buf : buf)
+ * lr is read from device memory so a captured graph can be replayed with a new poly-LR value.
+ * ------------------------------------------------------------------------------------- */
+int addk_sgd_step(float* p, const float* g, float* buf, int64_t n, const float* lr_dev, float momentum,
+                  float weight_decay, int32_t nesterov, int32_t first, float gscale, void* stream);
+
+/* misc */
+int addk_fill(float* p, int64_t n, float v, void* stream);
+/* Earlier-Decision-Maker support (operations.py:161-170): per-pixel normalised entropy summed */
+int addk_entropy_sum(const float* logits_nchw, int32_t N, int32_t C, int64_t HW, float* out1, float* ws, void* stream);
+/* argmax over channels of NCHW logits -> int64 [N,HW], and confusion matrix accumulation
+ * (utils/metrics.py:34-43) */
+int addk_argmax_nchw(const float* logits, int32_t N, int32_t C, int64_t HW, int64_t* out, void* stream);
+int addk_confusion(const int64_t* gt, const int64_t* pred, int64_t n, int32_t num_class, int64_t* cm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

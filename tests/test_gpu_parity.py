@@ -1,0 +1,318 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  The HIP path (through the C ABI in libaddk.so) is
+compared with the CPU oracle on identical seeded inputs and weights, and with the golden vectors produced by
+the real reference.  Tolerance: 1e-3 relative fp32 as BASELINE.json's north_star states (max-abs error divided
+by the max-abs of the reference tensor); most checks land 1-2 orders of magnitude below that."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import oracle                       # noqa: E402  (the checker)
+from _util import (ARCH_C2, ARCH_C3, GENOTYPE_AUTODEEPLAB, GENOTYPE_BASELINE_2, GENOTYPE_40_1,   # noqa: E402
+                   NETWORK_PATH_BASELINE, fill_params, make_args, probe_weights, rand_tensor, rel_err)
+
+TOL = 1e-3
+BN = nn.BatchNorm2d
+KW = dict(eps=1e-5, momentum=0.1, affine=True)
+REPORT = []
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    import addk
+    addk.load()
+    return torch.device('cuda:0')
+
+
+def _chk(name, a, b, tol=TOL):
+    e = rel_err(a, b)
+    REPORT.append('%-60s %.3e' % (name, e))
+    assert e <= tol, '%s: rel err %.3e > %.1e' % (name, e, tol)
+    return e
+
+
+def teardown_module(module):
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/parity_report.txt', 'w') as f:
+        f.write('\n'.join(REPORT) + '\n')
+
+
+def pair(dev, make_a, make_o, inputs, seed, tag, call=None, train=True, tol=TOL, golden=None):
+    """Build the addk module and the oracle with identical parameters; compare eval output, train output,
+    input gradients, parameter gradients and updated BN running statistics."""
+    call = call or (lambda m, *a: m(*a))
+    mo, ma = make_o(), make_a()
+    fill_params(mo, seed)
+    ma.load_state_dict(mo.state_dict())
+    ma.to(dev)
+
+    def to_dev(v, rg=False):
+        if isinstance(v, (list, tuple)):
+            return [to_dev(u, rg) for u in v]
+        t = v.clone().to(dev)
+        return t.requires_grad_(True) if rg else t
+
+    mo.eval(); ma.eval()
+    with torch.no_grad():
+        yo = call(mo, *[i.clone() if torch.is_tensor(i) else [u.clone() for u in i] for i in inputs])
+        ya = call(ma, *to_dev(inputs))
+    _chk(tag + '/eval', ya, yo, tol)
+    if golden is not None:
+        _chk(tag + '/eval-vs-reference-golden', ya, torch.from_numpy(golden[0][golden[1] + '/eval']), tol)
+    if not train:
+        return
+    fill_params(mo, seed)
+    ma.load_state_dict(mo.state_dict())
+    mo.train(); ma.train()
+
+    def rg(v):
+        if isinstance(v, (list, tuple)):
+            return [rg(u) for u in v]
+        return v.clone().requires_grad_(True)
+    xo = [rg(i) for i in inputs]
+    xa = to_dev(inputs, True)
+    yo = call(mo, *xo)
+    ya = call(ma, *xa)
+    _chk(tag + '/train', ya, yo, tol)
+    w = probe_weights(seed, tag, tuple(yo.shape))
+    (yo * w).sum().backward()
+    (ya * w.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+
+    def flat(v):
+        return [t for u in v for t in (flat(u) if isinstance(u, (list, tuple)) else [u])]
+    for k, (ga, go) in enumerate(zip(flat(xa), flat(xo))):
+        if go.grad is not None:
+            assert ga.grad is not None, tag + ' missing input grad %d' % k
+            _chk(tag + '/gin%d' % k, ga.grad, go.grad, tol)
+    pa = dict(ma.named_parameters())
+    for n, p in mo.named_parameters():
+        if p.grad is None:
+            continue
+        assert pa[n].grad is not None, '%s: missing grad for %s' % (tag, n)
+        _chk(tag + '/g:' + n, pa[n].grad, p.grad, tol)
+    ba = dict(ma.named_buffers())
+    for n, b in mo.named_buffers():
+        if n.endswith('num_batches_tracked'):
+            assert int(ba[n]) == int(b), tag + ' ' + n
+        else:
+            _chk(tag + '/buf:' + n, ba[n], b, tol)
+
+
+def test_mfma_fragment_layout(dev):
+    """v_mfma_f32_16x16x4_f32 operand/accumulator lane maps, with an asymmetric B."""
+    import addk
+    lib = addk.load()
+    out = torch.zeros(256, device=dev)
+    assert lib.addk_selftest_mfma(out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    A = np.arange(64, dtype=np.float64).reshape(16, 4)
+    B = np.array([[(k + 1) * (j + 2) for j in range(16)] for k in range(4)], dtype=np.float64)
+    assert np.array_equal(out.cpu().numpy().reshape(16, 16), (A @ B).astype(np.float32))
+
+
+@pytest.mark.parametrize('C,hw', [(8, (16, 32)), (20, (17, 33)), (40, (23, 31))])
+@pytest.mark.parametrize('prim', oracle.PRIMITIVES)
+def test_ops_registry(dev, golden, prim, C, hw):
+    from addk.modeling.operations import OPS
+    g = golden('ops')
+    x = torch.from_numpy(g['x_C%d' % C]) if 'x_C%d' % C in g.files else rand_tensor(11, 'ops_x_%d' % C, (2, C) + hw)
+    gold = (g, '%s_C%d' % (prim, C)) if '%s_C%d/eval' % (prim, C) in g.files else None
+    pair(dev, lambda: OPS[prim](C, 1, BN, **KW), lambda: oracle.OPS[prim](C, 1, BN, **KW), [x], 100 + C,
+         '%s_C%d' % (prim, C), golden=gold)
+
+
+@pytest.mark.parametrize('prim', [p for p in oracle.PRIMITIVES if p != 'skip_connect'])
+def test_ops_stride2(dev, golden, prim):
+    from addk.modeling.operations import OPS
+    g = golden('ops')
+    pair(dev, lambda: OPS[prim](8, 2, BN, **KW), lambda: oracle.OPS[prim](8, 2, BN, **KW), [torch.from_numpy(g['x_s2'])],
+         150, '%s_s2' % prim, golden=(g, '%s_s2' % prim))
+
+
+def test_relu_conv_bn_and_reduce(dev, golden):
+    from addk.modeling.operations import DoubleFactorizedReduce, FactorizedReduce, ReLUConvBN
+    g = golden('ops')
+    for ci, co in ((40, 24), (200, 40)):
+        x = torch.from_numpy(g['rcb_x_%d' % ci])
+        pair(dev, lambda: ReLUConvBN(ci, co, 1, 1, 0, BN, **KW), lambda: oracle.ReLUConvBN(ci, co, 1, 1, 0, BN, **KW), [x],
+             200 + ci, 'rcb_%d_%d' % (ci, co), golden=(g, 'rcb_%d_%d' % (ci, co)))
+    for h in (16, 17, 15):
+        x = torch.from_numpy(g['fr_x_%d' % h])
+        pair(dev, lambda: FactorizedReduce(24, 16, BN, eps=1e-5, momentum=0.1),
+             lambda: oracle.FactorizedReduce(24, 16, BN, eps=1e-5, momentum=0.1), [x], 300, 'fr_%d' % h, golden=(g, 'fr_%d' % h))
+        pair(dev, lambda: DoubleFactorizedReduce(24, 16, BN, eps=1e-5, momentum=0.1),
+             lambda: oracle.DoubleFactorizedReduce(24, 16, BN, eps=1e-5, momentum=0.1), [x], 301, 'dfr_%d' % h, golden=(g, 'dfr_%d' % h))
+    # odd channel counts (scalar path) and a large-K 1x1 with non-multiple-of-8 channels
+    x = rand_tensor(14, 'rcb_odd', (2, 10, 9, 13))
+    pair(dev, lambda: ReLUConvBN(10, 6, 1, 1, 0, BN, **KW), lambda: oracle.ReLUConvBN(10, 6, 1, 1, 0, BN, **KW), [x], 210, 'rcb_10_6')
+    x = rand_tensor(14, 'rcb_k3', (2, 12, 11, 14))
+    pair(dev, lambda: ReLUConvBN(12, 20, 3, 2, 1, BN, **KW), lambda: oracle.ReLUConvBN(12, 20, 3, 2, 1, BN, **KW), [x], 211, 'rcb_k3s2')
+
+
+def test_bilinear_resize(dev, golden):
+    """The resize kernels against F.interpolate golden vectors (forward and gather-form backward)."""
+    from addk.module import AddkModule
+
+    class Resize(AddkModule):
+        def __init__(self, size):
+            super().__init__()
+            self.size = size
+
+        def emit(self, g, x):
+            return g.resize(x, *self.size)
+    g = golden('bilinear')
+    for k in ('down4', 'up_32_63', 'fit_63_64', 'up8', 'up_odd', 'down_odd'):
+        size = tuple(int(v) for v in g[k + '/size'])
+        x = torch.from_numpy(g[k + '/x']).to(dev).requires_grad_(True)
+        y = Resize(size).to(dev)(x)
+        _chk('bilinear/%s/y' % k, y, torch.from_numpy(g[k + '/y']), 1e-5)
+        w = probe_weights(21, 'bil_' + k, tuple(y.shape)).to(dev)
+        (y * w).sum().backward()
+        _chk('bilinear/%s/gx' % k, x.grad, torch.from_numpy(g[k + '/gx']), 1e-5)
+
+
+def test_heads(dev, golden):
+    from addk.modeling.aspp_train import ASPP_train
+    from addk.modeling.decoder import Decoder
+    g = golden('heads')
+    pair(dev, lambda: ASPP_train(40, 256, BN, mult=1), lambda: oracle.ASPP_train(40, 256, BN, mult=1),
+         [torch.from_numpy(g['aspp40/x'])], 400, 'aspp40', golden=(g, 'aspp40'))
+    pair(dev, lambda: ASPP_train(80, 256, BN, mult=2), lambda: oracle.ASPP_train(80, 256, BN, mult=2),
+         [torch.from_numpy(g['aspp80_m2/x'])], 401, 'aspp80_m2', golden=(g, 'aspp80_m2'))
+    pair(dev, lambda: ASPP_train(400, 256, BN, mult=1), lambda: oracle.ASPP_train(400, 256, BN, mult=1),
+         [torch.from_numpy(g['aspp400/x'])], 402, 'aspp400', train=False, golden=(g, 'aspp400'))
+    lo = torch.from_numpy(g['dec/low'])
+    pair(dev, lambda: Decoder(19, BN), lambda: oracle.Decoder(19, BN), [torch.from_numpy(g['dec/x']), lo], 410, 'dec',
+         call=lambda m, a, b: m(a, b, (33, 65)), golden=(g, 'dec'))
+    pair(dev, lambda: Decoder(19, BN), lambda: oracle.Decoder(19, BN), [torch.from_numpy(g['dec_same/x']), lo], 411, 'dec_same',
+         call=lambda m, a, b: m(a, b, (34, 66)), golden=(g, 'dec_same'))
+
+
+def test_cells(dev, golden):
+    from addk.modeling.ADD import Cell
+    g = golden('cells')
+    ga = torch.from_numpy(GENOTYPE_AUTODEEPLAB)
+    ins = [torch.from_numpy(g['plain/pp']), torch.from_numpy(g['plain/p'])]
+    for k, name in ((1, 'concat'), (2, 'dense')):
+        pair(dev, lambda: Cell(BN, 5, 16, 32, ga, 1, 8, -1, dense_in=False, dense_out=True),
+             lambda: oracle.Cell(BN, 5, 16, 32, ga, 1, 8, -1, dense_in=False, dense_out=True), ins, 500, 'plain_' + name,
+             call=lambda m, a, b, k=k: m(a, b)[k], golden=(g, 'plain_' + name))
+    ins = [[torch.from_numpy(g['densein/d%d' % i]) for i in range(3)], torch.from_numpy(g['densein/p'])]
+    for k, name in ((1, 'concat'), (2, 'dense')):
+        pair(dev, lambda: Cell(BN, 5, [8, 16, 8], 80, ga, 1, 8, 1, dense_in=True, dense_out=True),
+             lambda: oracle.Cell(BN, 5, [8, 16, 8], 80, ga, 1, 8, 1, dense_in=True, dense_out=True), ins, 501, 'densein_' + name,
+             call=lambda m, a, b, k=k: m(a, b)[k], golden=(g, 'densein_' + name))
+    g40 = torch.from_numpy(GENOTYPE_40_1)
+    ins = [[torch.from_numpy(g['last/d0']), torch.from_numpy(g['last/d1'])], torch.from_numpy(g['last/p'])]
+    pair(dev, lambda: Cell(BN, 5, [8, 8], 40, g40, 1, 8, 0, dense_in=True, dense_out=False),
+         lambda: oracle.Cell(BN, 5, [8, 8], 40, g40, 1, 8, 0, dense_in=True, dense_out=False), ins, 502, 'last',
+         call=lambda m, a, b: m(a, b), golden=(g, 'last'))
+
+
+def _build_add(dev, Fv, arch, seed=600, cls=None, ocls=None, genotype=GENOTYPE_AUTODEEPLAB, low=None):
+    from addk.modeling.ADD import ADD
+    cls, ocls = cls or ADD, ocls or oracle.ADD
+    low = arch['low_level_layer'] if low is None else low
+    mo = ocls(arch['network_arch'], arch['C_index'], genotype, 19, make_args(Fv), low)
+    ma = cls(arch['network_arch'], arch['C_index'], genotype, 19, make_args(Fv), low)
+    chk = fill_params(mo, seed)
+    ma.load_state_dict(mo.state_dict())
+    return ma.to(dev), mo, chk
+
+
+@pytest.mark.parametrize('tag,Fv,arch', [('F4_65', 4, ARCH_C2), ('F4_64', 4, ARCH_C2), ('F4_C3_65', 4, ARCH_C3), ('F20_65', 20, ARCH_C2)])
+def test_add_whole_net(dev, golden, tag, Fv, arch):
+    g = golden('add')
+    ma, mo, chk = _build_add(dev, Fv, arch)
+    assert abs(chk - float(g[tag + '/chk'])) <= 1e-9 * chk
+    x = torch.from_numpy(g[tag + '/x'])
+    ma.eval(); mo.eval()
+    with torch.no_grad():
+        ya, yo = ma(x.to(dev)), mo(x)
+    assert len(ya) == len(arch['C_index']) + 1
+    for i, (a, o) in enumerate(zip(ya, yo)):
+        _chk('%s/eval%d' % (tag, i), a, o)
+        if tag + '/eval%d' % i in g.files:
+            _chk('%s/eval%d-vs-reference-golden' % (tag, i), a, torch.from_numpy(g[tag + '/eval%d' % i]))
+    if tag + '/loss' not in g.files:
+        return
+    fill_params(mo, 600)
+    ma.load_state_dict(mo.state_dict())
+    ma.train(); mo.train()
+    tgt = torch.from_numpy(g[tag + '/target'].astype(np.int64))
+    yo = mo(x)
+    lo = oracle.cross_entropy_mean_exits(yo, tgt)
+    lo.backward()
+    ya = ma(x.to(dev))
+    crit = nn.CrossEntropyLoss(weight=None, ignore_index=255)          # train.py:70,229-233 verbatim usage
+    la = sum(crit(y, tgt.to(dev)) for y in ya) / len(ya)
+    la.backward()
+    torch.cuda.synchronize()
+    assert abs(la.item() - float(g[tag + '/loss'])) < 1e-4 * abs(float(g[tag + '/loss']))
+    for i, (a, o) in enumerate(zip(ya, yo)):
+        _chk('%s/train%d' % (tag, i), a, o)
+    pa, po = dict(ma.named_parameters()), dict(mo.named_parameters())
+    worst = 0.0
+    for n, p in po.items():
+        if p.grad is None:
+            continue
+        assert pa[n].grad is not None, n
+        worst = max(worst, _chk('%s/g:%s' % (tag, n), pa[n].grad, p.grad, 5e-3))
+    gn = sum(float((p.grad.double() ** 2).sum()) for p in ma.parameters() if p.grad is not None) ** 0.5
+    assert abs(gn - float(g[tag + '/gnorm'])) < 1e-3 * gn
+    ba = dict(ma.named_buffers())
+    for n, b in mo.named_buffers():
+        if not n.endswith('num_batches_tracked'):
+            _chk('%s/buf:%s' % (tag, n), ba[n], b)
+        else:
+            assert int(ba[n]) == int(b), n
+
+
+def test_dynamic_inference_and_entropy(dev, golden):
+    from addk.modeling.ADD import EDM
+    from addk.modeling.operations import normalized_shannon_entropy
+    g = golden('dynamic')
+    ma, mo, chk = _build_add(dev, 20, ARCH_C2, seed=700)
+    eo = oracle.EDM()
+    fill_params(eo, 701)
+    ea = EDM()
+    ea.load_state_dict(eo.state_dict())
+    ea.to(dev).eval()
+    ma.eval(); mo.eval(); eo.eval()
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        y, feat = ma.get_feature(x.to(dev))
+        _chk('get_feature/logits', y, torch.from_numpy(g['get_feature/logits']))
+        _chk('get_feature/feature', feat, torch.from_numpy(g['get_feature/feature']))
+        _chk('edm(feature)', ea(feat.clone()), torch.from_numpy(g['edm_on_feature']))
+        for name, thr in (('early', 1e9), ('final', -1e9)):
+            y, ee, secs, conf = ma.dynamic_inference(x.to(dev), threshold=thr, confidence='edm', edm=ea)
+            assert ee == int(g[name + '/exit']) and secs > 0
+            _chk('dynamic/%s/logits' % name, y, torch.from_numpy(g[name + '/logits']))
+            _chk('dynamic/%s/conf' % name, conf, torch.from_numpy(g[name + '/conf']))
+        ys = ma(x.to(dev))
+        assert abs(normalized_shannon_entropy(ys[0]) - float(g['entropy0'])) < 1e-4
+        assert abs(normalized_shannon_entropy(ys[1]) - float(g['entropy1'])) < 1e-4
+
+
+def test_baseline_model_config1(dev, golden):
+    from addk.modeling.baseline_model import Baselin_Model
+    g = golden('baseline')
+    arch = dict(network_arch=NETWORK_PATH_BASELINE, C_index=[5], low_level_layer=1)
+    ma, mo, chk = _build_add(dev, 20, arch, seed=800, cls=Baselin_Model, ocls=oracle.Baselin_Model, genotype=GENOTYPE_BASELINE_2)
+    ma.eval()
+    with torch.no_grad():
+        ys = ma(torch.from_numpy(g['129/x']).to(dev))
+        _chk('baseline/129/last', ys[-1], torch.from_numpy(g['129/last']))
+        _chk('baseline/129/first', ys[0], torch.from_numpy(g['129/first']))
+        ys = ma(rand_tensor(81, 'base_x513', (1, 3, 513, 513)).to(dev))
+        _chk('baseline/513/last_sub8', ys[-1][:, :, ::8, ::8], torch.from_numpy(g['513/last_sub8']))
+        agree = (ys[-1].argmax(1)[:, ::4, ::4].cpu().numpy() == g['513/argmax_sub4']).mean()
+        assert agree > 0.999
