@@ -1,19 +1,20 @@
 // BatchNorm statistics kernels (F.batch_norm training mode at every BatchNorm(...) call site of
 // the path: operations.py:25,39,54,58,93; ADD.py:156,162,168,258; aspp_train.py:27-32; decoder.py:15,19).
-// They only touch [rows][C][2] partial slabs written by the producing kernels and C-length vectors;
-// sums are carried in fp64 so that the E[x^2]-E[x]^2 form stays accurate.
+// They only touch [rows][C][2] partial slabs written by the producing kernels and C-length vectors.
+// Slabs are fp64 end to end (squares, partial sums, cross-block sums): the E[x^2]-E[x]^2 form must survive
+// the 2-sample BatchNorm of the ASPP image-pool branch at bs=2 as ATen's fp64-accumulating CPU path does.
 #include "common.h"
 
 namespace {
 
 // block = 32 channels x 32 row groups; result (sum0, sum1) per channel for threads with rg == 0
-__device__ __forceinline__ void slab_sum(const float* slab, int rows, int C, int c, int rg, double& s0, double& s1,
+__device__ __forceinline__ void slab_sum(const double* slab, int rows, int C, int c, int rg, double& s0, double& s1,
                                          double (*sh)[32][2]) {
   double a = 0.0, b = 0.0;
   if (c < C)
     for (int r = rg; r < rows; r += 32) {
-      float2 v = *reinterpret_cast<const float2*>(slab + ((long)r * C + c) * 2);
-      a += v.x; b += v.y;
+      const double* v = slab + ((long)r * C + c) * 2;
+      a += v[0]; b += v[1];
     }
   const int cl = threadIdx.x & 31;
   sh[rg][cl][0] = a; sh[rg][cl][1] = b;
@@ -31,7 +32,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finaliz
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s0, s1;
-  slab_sum(p.partial, p.rows, p.C, c, rg, s0, s1, sh);
+  slab_sum((const double*)p.partial, p.rows, p.C, c, rg, s0, s1, sh);
   if (rg == 0 && c < p.C) {
     double mean = s0 / p.count;
     double var = s1 / p.count - mean * mean;
@@ -51,13 +52,13 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finaliz
   }
 }
 
-__global__ void __launch_bounds__(1024) slab_reduce_kernel(const float* slab, int rows, int C, float* out) {
+__global__ void __launch_bounds__(1024) slab_reduce_kernel(const double* slab, int rows, int C, double* out) {
   __shared__ double sh[32][32][2];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s0, s1;
   slab_sum(slab, rows, C, c, rg, s0, s1, sh);
-  if (rg == 0 && c < C) { out[2 * c] = (float)s0; out[2 * c + 1] = (float)s1; }
+  if (rg == 0 && c < C) { out[2 * c] = s0; out[2 * c + 1] = s1; }
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(1024) bn_bwd_kernel(const addk_bn_bwd_args p) 
   double dA = 0.0, dB = 0.0;
   for (int k = 0; k < p.nslab; ++k) {
     double s0, s1;
-    slab_sum(p.slab[k], p.rows[k], p.C, c, rg, s0, s1, sh);
+    slab_sum((const double*)p.slab[k], p.rows[k], p.C, c, rg, s0, s1, sh);
     dA += s0; dB += s1;
   }
   if (rg == 0 && c < p.C) {
@@ -107,7 +108,7 @@ extern "C" int addk_bn_finalize(const addk_bn_finalize_args* a, void* stream) {
   return addk_check_launch("bn_finalize");
 }
 
-extern "C" int addk_slab_reduce(const float* partial, int32_t rows, int32_t C, float* out, void* stream) {
+extern "C" int addk_slab_reduce(const double* partial, int32_t rows, int32_t C, double* out, void* stream) {
   ADDK_REQUIRE(partial && out && rows > 0 && C > 0, "slab_reduce: bad args");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, partial, rows, C, out);
   return addk_check_launch("slab_reduce");

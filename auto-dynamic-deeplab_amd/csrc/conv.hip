@@ -33,7 +33,7 @@ struct ConvK {
   float* y;
   const float* bias;
   const float* bias_n;
-  float* slab; int slab_ld;
+  double* slab; int slab_ld;
   addk_src dst;     // dgrad epilogue
   int accumulate;
   int vecA, vecB, vecY;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   constexpr int NBJ = (CT + 1) / 2;       // float4 B slots per thread
   __shared__ __attribute__((aligned(16))) float As[BP * BKP];
   __shared__ __attribute__((aligned(16))) float Bs[BC * BKP];
-  __shared__ float red[4][BC][2];
+  __shared__ double red[4][BC][2];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   const int aq = t & 7, ar = t >> 3;
   const int ntaps = p.KH * p.KW;
   const long ohw = (long)p.OH * p.OW;
-  float tot0 = 0.f, tot1 = 0.f;
+  double tot0 = 0.0, tot1 = 0.0;
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int rn[NAJ], rh[NAJ], rw[NAJ];
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
     for (int i = 0; i < CT; ++i) {
       const int c = n0 + i * 16 + kq * 4;
       const int nrem = p.Cn - c;
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
+      double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
         const long pp = (long)tile * BP + (wave * PT + j) * 16 + li;
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
             if (want_red) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float f = (e < nrem) ? get4(v, e) : 0.f;
+                double f = (e < nrem) ? (double)get4(v, e) : 0.0;
                 s1[e] += f; s2v[e] += f * f;
               }
             }
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
               float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), dz = get4(v, e);
               bool m = (e < nrem) && (!p.dst.relu || fmaf(ae, xe, be) > 0.f);
               set4(g, e, m ? dz * ae : 0.f);
-              if (want_red) { s1[e] += m ? dz * xe : 0.f; s2v[e] += m ? dz : 0.f; }
+              if (want_red && m) { s1[e] += (double)dz * (double)xe; s2v[e] += (double)dz; }
             }
             float* gp = p.y + pp * p.ldy + c;
             if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vecY); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       if (want_red) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float a = s1[e], b = s2v[e];
+          double a = s1[e], b = s2v[e];
 #pragma unroll
           for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
           if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = a; red[wave][i * 16 + kq * 4 + e][1] = b; }
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
     }
   }
   if (p.slab && t < BC && n0 + t < p.Cn) {
-    float* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+    double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
     o[0] = tot0; o[1] = tot1;
   }
 }
@@ -351,7 +351,7 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
   k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
   k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
   k.Cn = a->Cout; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.ldy = a->ldy;
-  k.w = a->w; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n; k.slab = a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.w = a->w; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n; k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
   k.accumulate = 0; k.dst = addk_src{nullptr, nullptr, nullptr, 0, 0, 0, 0};
   bool chan4 = true;
   for (int i = 0; i < a->nsrc; ++i) chan4 = chan4 && (a->src[i].C % 4 == 0);
@@ -375,7 +375,7 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
   k.OH = a->H; k.OW = a->W;                  // M side = input pixels
   k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
   k.Cn = a->dst.C; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.ldy = a->ldg;
-  k.w = a->w; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr; k.slab = a->dab; k.slab_ld = a->dst.C;
+  k.w = a->w; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr; k.slab = (double*)a->dab; k.slab_ld = a->dst.C;
   k.dst = a->dst; k.accumulate = a->accumulate;
   k.vecB = aligned16(a->w) && a->ldw % 4 == 0 && a->cin_total % 4 == 0 && a->w_choff % 4 == 0 && a->dst.C % 4 == 0;
   k.vecY = aligned16(a->g) && a->ldg % 4 == 0 && src_vec_ok(a->dst);

@@ -15,7 +15,7 @@ struct DwK {
   // backward
   const float* dy; int lddy;
   float* g; int ldg; int accumulate;
-  float* dab; float* ws;
+  double* dab; float* ws;
   int nq, npl; long P; int vec;
 };
 
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
   float4 dwacc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) dwacc[i] = zero4();
-  float4 sA = zero4(), sB = zero4();
+  double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
   if (active) {
     for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
       int n = (int)(pp / hw); int rem = (int)(pp - (long)n * hw);
@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
         }
       }
       float4 gm = make_float4(m0 ? dz.x : 0.f, m1 ? dz.y : 0.f, m2 ? dz.z : 0.f, m3 ? dz.w : 0.f);
-      sA.x += gm.x * x.x; sA.y += gm.y * x.y; sA.z += gm.z * x.z; sA.w += gm.w * x.w;
-      sB.x += gm.x; sB.y += gm.y; sB.z += gm.z; sB.w += gm.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sA[e] += (double)get4(gm, e) * (double)get4(x, e); sB[e] += (double)get4(gm, e); }
       if (p.g) {
         float4 gv = make_float4(gm.x * av.x, gm.y * av.y, gm.z * av.z, gm.w * av.w);
         float* gp = p.g + pp * p.ldg + c;
@@ -132,18 +132,19 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
   for (int i = threadIdx.x; i < C * NT; i += 256) p.ws[(long)blockIdx.x * C * NT + i] = redt[i];
   __syncthreads();
   if (p.dab) {
+    double* redd = reinterpret_cast<double*>(redt);      // [C4][2] doubles fit in the [C4][NT] float tile (NT >= 4)
     for (int r = 0; r < p.npl; ++r) {
       if (active && pl == r) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float* d = &redt[(c + e) * 2];
-          d[0] = (r == 0) ? get4(sA, e) : d[0] + get4(sA, e);
-          d[1] = (r == 0) ? get4(sB, e) : d[1] + get4(sB, e);
+          double* d = &redd[(c + e) * 2];
+          d[0] = (r == 0) ? sA[e] : d[0] + sA[e];
+          d[1] = (r == 0) ? sB[e] : d[1] + sB[e];
         }
       }
       __syncthreads();
     }
-    for (int i = threadIdx.x; i < C * 2; i += 256) p.dab[(long)blockIdx.x * C * 2 + i] = redt[i];
+    for (int i = threadIdx.x; i < C * 2; i += 256) p.dab[(long)blockIdx.x * C * 2 + i] = redd[i];
   }
 }
 
@@ -197,12 +198,12 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
   int rc = dw_fill(k, a->src, a->N, a->H, a->W, a->OH, a->OW, a->KH, a->KW, a->stride, a->pad, a->dil);
   if (rc) return rc;
   k.w = a->w; k.dy = a->dy; k.lddy = a->lddy; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate;
-  k.dab = a->dab; k.ws = a->ws;
+  k.dab = (double*)a->dab; k.ws = a->ws;
   k.P = (long)a->N * a->H * a->W;
   k.vec = src_vec_ok(a->src) && aligned16(a->dy) && a->lddy % 4 == 0 && (!a->g || (aligned16(a->g) && a->ldg % 4 == 0));
   const int taps = a->KH * a->KW, C4 = k.nq * 4;
   const int rows = dw_rows(k.P, a->src.C);
-  size_t sh = (size_t)(taps * C4 + C4 * (taps > 2 ? taps : 2)) * sizeof(float);
+  size_t sh = (size_t)(taps * C4 + C4 * (taps > 4 ? taps : 4)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (taps == 9) hipLaunchKernelGGL(dw_bwd_kernel<9>, dim3(rows), dim3(256), sh, st, k);
   else if (taps == 25) hipLaunchKernelGGL(dw_bwd_kernel<25>, dim3(rows), dim3(256), sh, st, k);

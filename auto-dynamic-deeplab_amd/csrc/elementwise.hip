@@ -15,7 +15,7 @@ struct SumK {
   const float* dout; int lddo;
   const float* fout; int ldfo;
   float* g[ADDK_MAX_TERMS]; int ldg[ADDK_MAX_TERMS]; int acc[ADDK_MAX_TERMS];
-  float* dab[ADDK_MAX_TERMS];
+  double* dab[ADDK_MAX_TERMS];
   int nq, npl, vec;
 };
 
@@ -48,14 +48,17 @@ __global__ void __launch_bounds__(256) affine_sum_fwd_kernel(const SumK p) {
 }
 
 __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
-  extern __shared__ float redt[];        // [C4][2]
+  extern __shared__ double redt[];       // [C4][2]
   const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
   const bool active = pl < p.npl;
   const int c = 4 * q, nrem = p.C - c;
-  float4 av[ADDK_MAX_TERMS], bv[ADDK_MAX_TERMS], sA[ADDK_MAX_TERMS], sB[ADDK_MAX_TERMS];
+  float4 av[ADDK_MAX_TERMS], bv[ADDK_MAX_TERMS];
+  double sA[ADDK_MAX_TERMS][4], sB[ADDK_MAX_TERMS][4];
 #pragma unroll
   for (int i = 0; i < ADDK_MAX_TERMS; ++i) {
-    av[i] = make_float4(1.f, 1.f, 1.f, 1.f); bv[i] = zero4(); sA[i] = zero4(); sB[i] = zero4();
+    av[i] = make_float4(1.f, 1.f, 1.f, 1.f); bv[i] = zero4();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sA[i][e] = 0.0; sB[i][e] = 0.0; }
     if (active && i < p.nterm && p.term[i].a) { av[i] = ld4g(p.term[i].a + c, nrem, p.vec); bv[i] = ld4g(p.term[i].b + c, nrem, p.vec); }
   }
   if (active) {
@@ -76,8 +79,8 @@ __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
             if (!(fmaf(av[i].z, x.z, bv[i].z) > 0.f)) dm.z = 0.f;
             if (!(fmaf(av[i].w, x.w, bv[i].w) > 0.f)) dm.w = 0.f;
           }
-          sA[i].x += dm.x * x.x; sA[i].y += dm.y * x.y; sA[i].z += dm.z * x.z; sA[i].w += dm.w * x.w;
-          sB[i].x += dm.x; sB[i].y += dm.y; sB[i].z += dm.z; sB[i].w += dm.w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sA[i][e] += (double)get4(dm, e) * (double)get4(x, e); sB[i][e] += (double)get4(dm, e); }
           if (p.g[i]) {
             float4 gv = make_float4(dm.x * av[i].x, dm.y * av[i].y, dm.z * av[i].z, dm.w * av[i].w);
             float* gp = p.g[i] + pp * p.ldg[i] + c;
@@ -95,9 +98,9 @@ __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
         if (active && pl == r) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float* d = &redt[(c + e) * 2];
-            d[0] = (r == 0) ? get4(sA[i], e) : d[0] + get4(sA[i], e);
-            d[1] = (r == 0) ? get4(sB[i], e) : d[1] + get4(sB[i], e);
+            double* d = &redt[(c + e) * 2];
+            d[0] = (r == 0) ? sA[i][e] : d[0] + sA[i][e];
+            d[1] = (r == 0) ? sB[i][e] : d[1] + sB[i][e];
           }
         }
         __syncthreads();
@@ -185,13 +188,13 @@ extern "C" int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stre
   k.vec = aligned16(a->dout) && a->lddo % 4 == 0 && (!a->relu_out || (aligned16(a->out) && a->ldo % 4 == 0));
   for (int i = 0; i < a->nterm; ++i) {
     ADDK_REQUIRE(a->term[i].x && a->term[i].ld >= a->C && a->term[i].C == a->C, "affine_sum_bwd: bad term %d", i);
-    k.term[i] = a->term[i]; k.g[i] = a->g[i]; k.ldg[i] = a->ldg[i]; k.acc[i] = a->accumulate[i]; k.dab[i] = a->dab[i];
+    k.term[i] = a->term[i]; k.g[i] = a->g[i]; k.ldg[i] = a->ldg[i]; k.acc[i] = a->accumulate[i]; k.dab[i] = (double*)a->dab[i];
     ADDK_REQUIRE(!a->g[i] || a->ldg[i] >= a->C, "affine_sum_bwd: short ldg %d", i);
     if (!src_vec_ok(a->term[i]) || (a->g[i] && (!aligned16(a->g[i]) || a->ldg[i] % 4))) k.vec = 0;
   }
   k.nterm = a->nterm; k.P = a->P; k.C = a->C; k.dout = a->dout; k.lddo = a->lddo; k.fout = a->out; k.ldfo = a->ldo; k.relu_out = a->relu_out;
   EwMap m = ew_map(a->C); k.nq = m.nq; k.npl = m.npl;
-  size_t sh = (size_t)m.nq * 4 * 2 * sizeof(float);
+  size_t sh = (size_t)m.nq * 4 * 2 * sizeof(double);
   hipLaunchKernelGGL(affine_sum_bwd_kernel, dim3(ew_rows(a->P, a->C)), dim3(256), sh, (hipStream_t)stream, k);
   return addk_check_launch("affine_sum_bwd");
 }

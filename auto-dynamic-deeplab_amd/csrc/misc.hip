@@ -6,7 +6,7 @@ namespace {
 struct GapK {
   addk_src src; int N; long HW;
   float* y; int ldy; float* ws; int rows;
-  const float* dy; int lddy; float* g; int ldg; int accumulate; float* dab;
+  const float* dy; int lddy; float* g; int ldg; int accumulate; double* dab;
   int nq, npl, vec;
 };
 
@@ -46,13 +46,14 @@ __global__ void gap_final_kernel(const float* ws, int N, int rows, int C, float 
 }
 
 __global__ void __launch_bounds__(256) gap_bwd_kernel(const GapK p) {
-  extern __shared__ float redt[];      // [C4][2]
+  extern __shared__ double redd[];     // [C4][2]
   const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
   const bool active = pl < p.npl;
   const int c = 4 * q, C = p.src.C, nrem = C - c;
   const long P = (long)p.N * p.HW;
   const float inv = 1.f / (float)p.HW;
-  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4(), sA = zero4(), sB = zero4();
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
   if (active && p.src.a) { av = ld4g(p.src.a + c, nrem, p.vec); bv = ld4g(p.src.b + c, nrem, p.vec); }
   if (active) {
     for (long pp = (long)blockIdx.x * p.npl + pl; pp < P; pp += (long)gridDim.x * p.npl) {
@@ -66,8 +67,8 @@ __global__ void __launch_bounds__(256) gap_bwd_kernel(const GapK p) {
         if (!(fmaf(av.z, x.z, bv.z) > 0.f)) d.z = 0.f;
         if (!(fmaf(av.w, x.w, bv.w) > 0.f)) d.w = 0.f;
       }
-      sA.x += d.x * x.x; sA.y += d.y * x.y; sA.z += d.z * x.z; sA.w += d.w * x.w;
-      sB.x += d.x; sB.y += d.y; sB.z += d.z; sB.w += d.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sA[e] += (double)get4(d, e) * (double)get4(x, e); sB[e] += (double)get4(d, e); }
       float4 gv = make_float4(d.x * av.x, d.y * av.y, d.z * av.z, d.w * av.w);
       float* gp = p.g + pp * p.ldg + c;
       if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vec); gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
@@ -79,14 +80,14 @@ __global__ void __launch_bounds__(256) gap_bwd_kernel(const GapK p) {
       if (active && pl == r) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float* d = &redt[(c + e) * 2];
-          d[0] = (r == 0) ? get4(sA, e) : d[0] + get4(sA, e);
-          d[1] = (r == 0) ? get4(sB, e) : d[1] + get4(sB, e);
+          double* d = &redd[(c + e) * 2];
+          d[0] = (r == 0) ? sA[e] : d[0] + sA[e];
+          d[1] = (r == 0) ? sB[e] : d[1] + sB[e];
         }
       }
       __syncthreads();
     }
-    for (int k = threadIdx.x; k < C * 2; k += 256) p.dab[(long)blockIdx.x * C * 2 + k] = redt[k];
+    for (int k = threadIdx.x; k < C * 2; k += 256) p.dab[(long)blockIdx.x * C * 2 + k] = redd[k];
   }
 }
 
@@ -189,19 +190,19 @@ __global__ void nhwc_to_nchw_kernel(const addk_src s, int N, long HW, float* y) 
 // gradient of nhwc_to_nchw: one block per pixel range, thread per pixel, channel loop; dab partial via per-thread
 // channel loop + block reduction per channel (C small at module boundaries; used by standalone modules / tests)
 __global__ void __launch_bounds__(256) nchw_grad_kernel(const float* dy, const addk_src s, int N, long HW, float* g, int ldg,
-                                                        int accumulate, float* dab, int rows) {
-  __shared__ float red[256][2];
+                                                        int accumulate, double* dab, int rows) {
+  __shared__ double red[256][2];
   const long total = (long)N * HW;
   const int C = s.C;
   for (int c = 0; c < C; ++c) {
     float a = s.a ? s.a[c] : 1.f, b = s.b ? s.b[c] : 0.f;
-    float sA = 0.f, sB = 0.f;
+    double sA = 0.0, sB = 0.0;
     for (long pp = (long)blockIdx.x * 256 + threadIdx.x; pp < total; pp += (long)rows * 256) {
       int n = (int)(pp / HW); long i = pp - (long)n * HW;
       float d = dy[((long)n * C + c) * HW + i];
       float x = s.x[pp * s.ld + c];
       if (s.relu && !(fmaf(a, x, b) > 0.f)) d = 0.f;
-      sA += d * x; sB += d;
+      sA += (double)d * (double)x; sB += (double)d;
       float* gp = g + pp * ldg + c;
       float gv = d * a;
       *gp = accumulate ? *gp + gv : gv;
@@ -245,14 +246,14 @@ extern "C" int addk_gap_fwd(const addk_src* src, int32_t N, int32_t HW, float* y
 }
 
 extern "C" int addk_gap_bwd(const addk_src* src, int32_t N, int32_t HW, const float* dy, int32_t lddy, float* g, int32_t ldg,
-                            int32_t accumulate, float* dab, void* stream) {
+                            int32_t accumulate, double* dab, void* stream) {
   ADDK_REQUIRE(src && src->x && dy && g && N > 0 && HW > 0 && src->C > 0 && src->C <= 1024 && ldg >= src->C && lddy >= src->C, "gap_bwd: bad args");
   GapK k{};
-  k.src = *src; k.N = N; k.HW = HW; k.dy = dy; k.lddy = lddy; k.g = g; k.ldg = ldg; k.accumulate = accumulate; k.dab = dab;
+  k.src = *src; k.N = N; k.HW = HW; k.dy = dy; k.lddy = lddy; k.g = g; k.ldg = ldg; k.accumulate = accumulate; k.dab = (double*)dab;
   EwMap m = ew_map(src->C); k.nq = m.nq; k.npl = m.npl;
   k.vec = src_vec_ok(*src) && aligned16(g) && ldg % 4 == 0;
   int rows = rows_for((long)N * HW, src->C);
-  hipLaunchKernelGGL(gap_bwd_kernel, dim3(rows), dim3(256), (size_t)m.nq * 8 * sizeof(float), (hipStream_t)stream, k);
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(rows), dim3(256), (size_t)m.nq * 8 * sizeof(double), (hipStream_t)stream, k);
   return addk_check_launch("gap_bwd");
 }
 
@@ -301,9 +302,9 @@ extern "C" int addk_nhwc_to_nchw(const addk_src* src, int32_t N, int64_t HW, flo
 }
 
 extern "C" int addk_nchw_grad_to_nhwc(const float* dy, const addk_src* src, int32_t N, int64_t HW, float* g, int32_t ldg,
-                                      int32_t accumulate, float* dab, void* stream) {
+                                      int32_t accumulate, double* dab, void* stream) {
   ADDK_REQUIRE(dy && src && src->x && g && N > 0 && HW > 0 && src->C > 0 && ldg >= src->C, "nchw_grad_to_nhwc: bad args");
   int rows = rows_for((long)N * HW, src->C);
-  hipLaunchKernelGGL(nchw_grad_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, *src, N, (long)HW, g, ldg, accumulate, dab, rows);
+  hipLaunchKernelGGL(nchw_grad_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, *src, N, (long)HW, g, ldg, accumulate, (double*)dab, rows);
   return addk_check_launch("nchw_grad_to_nhwc");
 }

@@ -40,7 +40,7 @@ struct RsK {
   addk_src src; int N, H, W, OH, OW;
   float* y; int ldy; int nchw;
   const float* dy; int lddy; const float* dy_scale;
-  float* g; int ldg; int accumulate; float* dab;
+  float* g; int ldg; int accumulate; double* dab;
   int nq, npl, vec; long P;
 };
 
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) resize_fwd_nchw_kernel(const RsK p) {
 
 template <bool NCHW>
 __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
-  extern __shared__ float redt[];        // [C4][2]
+  extern __shared__ double redt[];       // [C4][2]
   const int C = p.src.C;
   const int q = NCHW ? 0 : threadIdx.x % p.nq, pl = NCHW ? threadIdx.x : threadIdx.x / p.nq;
   const bool active = pl < p.npl;
@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
   const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
   const long hw = (long)p.H * p.W, ohw = (long)p.OH * p.OW;
   const float gs = p.dy_scale ? *p.dy_scale : 1.f;
-  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4(), sA = zero4(), sB = zero4();
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
   if (!NCHW && active && p.src.a) { av = ld4g(p.src.a + c, nrem, p.vec); bv = ld4g(p.src.b + c, nrem, p.vec); }
   if (active) {
     for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
@@ -161,8 +162,8 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
             if (!(fmaf(av.z, x.z, bv.z) > 0.f)) dz.z = 0.f;
             if (!(fmaf(av.w, x.w, bv.w) > 0.f)) dz.w = 0.f;
           }
-          sA.x += dz.x * x.x; sA.y += dz.y * x.y; sA.z += dz.z * x.z; sA.w += dz.w * x.w;
-          sB.x += dz.x; sB.y += dz.y; sB.z += dz.z; sB.w += dz.w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sA[e] += (double)get4(dz, e) * (double)get4(x, e); sB[e] += (double)get4(dz, e); }
         }
         float4 gv = make_float4(dz.x * av.x, dz.y * av.y, dz.z * av.z, dz.w * av.w);
         float* gp = p.g + pp * p.ldg + c;
@@ -176,9 +177,9 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
       if (active && pl == r) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float* d = &redt[(c + e) * 2];
-          d[0] = (r == 0) ? get4(sA, e) : d[0] + get4(sA, e);
-          d[1] = (r == 0) ? get4(sB, e) : d[1] + get4(sB, e);
+          double* d = &redt[(c + e) * 2];
+          d[0] = (r == 0) ? sA[e] : d[0] + sA[e];
+          d[1] = (r == 0) ? sB[e] : d[1] + sB[e];
         }
       }
       __syncthreads();
@@ -225,7 +226,7 @@ extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
   ADDK_REQUIRE((a->src.a == nullptr) == (a->src.b == nullptr), "resize_bwd: a/b must come together");
   RsK k{};
   k.src = a->src; k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
-  k.dy = a->dy; k.lddy = a->lddy; k.dy_scale = a->dy_scale; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate; k.dab = a->dab;
+  k.dy = a->dy; k.lddy = a->lddy; k.dy_scale = a->dy_scale; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate; k.dab = (double*)a->dab;
   k.P = (long)a->N * a->H * a->W;
   hipStream_t st = (hipStream_t)stream;
   if (a->nchw_in) {
@@ -239,7 +240,7 @@ extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
     k.vec = aligned16(a->dy) && a->lddy % 4 == 0 && aligned16(a->g) && a->ldg % 4 == 0 && a->src.C % 4 == 0 &&
             (!a->src.x || src_vec_ok(a->src));
     int rows = rs_rows(k.P, a->src.C);
-    size_t sh = (size_t)m.nq * 4 * 2 * sizeof(float);
+    size_t sh = (size_t)m.nq * 4 * 2 * sizeof(double);
     hipLaunchKernelGGL(resize_bwd_kernel<false>, dim3(rows), dim3(256), sh, st, k);
   }
   return addk_check_launch("resize_bwd");

@@ -133,7 +133,7 @@ class FactorizedReduce(AddkModule):
         for i, (conv, pad) in enumerate(((self.conv_1, 0), (self.conv_2, -sh))):
             st = None
             if slab is not None:
-                st = Vec(slab, i * half * 2, 0)
+                st = Vec(slab, i * half * 4, 0)        # fp64 (sum, sumsq) pairs: 4 floats per channel
             g.conv([x], conv.weight, half, 1, s, pad, 1, relu_in=True, out=raw.chan(i * half, half), stats=st,
                    stats_ld=Cout, out_hw=(OH, OW))
         return g.bn(raw, self.bn, slab, rows or 0)

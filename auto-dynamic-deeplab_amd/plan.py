@@ -109,14 +109,17 @@ class Graph:
         self.keep = []                # keep ctypes structs / tensors alive
         self.pgrad = {}               # param -> grad tensor
         self.pginit = set()
+        self._pcols = {}
         self.params = []              # ordered unique params touched
         self.nbt = {}                 # num_batches_tracked tensor -> increments per forward
         self._wgrads = []             # wgrad arg structs sharing one scratch buffer (launches are stream-ordered)
         self.nbytes = 0
+        self._bufs = []               # owns every device buffer: kernels only see raw pointers
 
     # ---------------- memory ----------------
     def buf(self, n, zero=False):
         b = Buf(n, self.device, zero)
+        self._bufs.append(b)
         self.nbytes += 4 * b.n
         return b
 
@@ -161,12 +164,24 @@ class Graph:
             self.params.append(p)
         return p.data_ptr()
 
-    def param_grad(self, p):
-        """(ptr, accumulate) of the plan-owned gradient of parameter p."""
+    def param_grad(self, p, cols=None):
+        """(ptr, accumulate) of the plan-owned gradient of parameter p.  `cols` = (c0, c1) is the input-channel
+        interval a launch writes (virtual-concat sources and the ASPP image-pool fold write disjoint column
+        ranges of one weight): first touch of an interval overwrites, later touches accumulate."""
         self.param(p)
         if self.pgrad[p] is None:
             self.pgrad[p] = torch.empty_like(p)
-        acc = 1 if p in self.pginit else 0
+            self._pcols[p] = []
+        iv = self._pcols[p]
+        c0, c1 = cols if cols is not None else (0, 1 << 30)
+        covered = sum(max(0, min(c1, b) - max(c0, a)) for a, b in iv)
+        if covered == 0:
+            iv.append((c0, c1))
+            acc = 0
+        elif covered == c1 - c0 or (cols is None and iv == [(0, 1 << 30)]):
+            acc = 1
+        else:
+            raise NotImplementedError('partially initialised weight-gradient columns')
         self.pginit.add(p)
         return self.pgrad[p].data_ptr(), acc
 
@@ -202,8 +217,7 @@ class Graph:
         """Allocate a (dA,dB) partial slab for a lazy source whose BN is in training mode."""
         if act.bn is None or not act.bn.training or not self.want_grad:
             return None
-        slab = self.buf(rows * act.C * 2)
-        return slab
+        return self.buf(rows * act.C * 4)      # fp64 [rows][C][2]
 
     # ---------------- ops ----------------
     def conv(self, srcs, weight, Cout, k, stride=1, pad=0, dil=1, relu_in=False, bias=None, bias_n=None,
@@ -263,7 +277,7 @@ class Graph:
                     wa.dy, wa.lddy, wa.Cout = dy.ptr, dy.ld, Cout
                     wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, OH, OW, k, k, stride, pad, dil
                     wa.src = self.src(s, relu_in)
-                    gp, acc = self.param_grad(weight)
+                    gp, acc = self.param_grad(weight, (choff, choff + s.C))
                     wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = gp, ldw, cin_total, choff, acc
                     wa.ws_floats = lib.addk_conv_wgrad_ws(P, Cout, s.C, k * k)
                     self._wgrads.append(wa)
@@ -317,7 +331,7 @@ class Graph:
 
     def stats_slab(self, P, Cc):
         rows = self.lib.addk_conv_rows(P, Cc)
-        return self.buf(rows * Cc * 2), rows
+        return self.buf(rows * Cc * 4), rows      # fp64 [rows][C][2]
 
     def bn(self, raw, mod, slab=None, rows=0, post_relu=False, needs_grad=True):
         """Apply BatchNorm module `mod` lazily to `raw`.  Training: statistics come from `slab`."""
@@ -334,7 +348,7 @@ class Graph:
             sync = self.world is not None and getattr(mod, 'sync', False) and self.world.size > 1
             fa = L.BnFinalizeArgs()
             if sync:
-                red = self.vec(2 * Cc)
+                red = self.vec(4 * Cc)      # fp64 [C][2]
                 self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, red.ptr)
                 self.world.emit_allreduce(self, self.fwd, red)    # every rank has the same per-rank count
                 fa.partial, fa.rows = red.ptr, 1

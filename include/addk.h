@@ -80,7 +80,7 @@ typedef struct addk_conv_args {
   const float* bias;          /* [Cout] or NULL (decoder.py:21) */
   const float* bias_n;        /* [N][Cout] per-image bias or NULL (ASPP image-pool branch folded
                                  into conv1, aspp_train.py:50-59) */
-  float* stats;               /* [rows][stats_ld][2] partial (sum, sumsq) or NULL; rows = addk_conv_rows().
+  double* stats;              /* fp64 [rows][stats_ld][2] partial (sum, sumsq) or NULL; rows = addk_conv_rows().
                                  Points at this conv's first channel inside the row. */
   int32_t stats_ld;           /* channels per slab row (>= Cout; FactorizedReduce's two convs share one BN) */
   int32_t _pad;
@@ -100,7 +100,7 @@ typedef struct addk_conv_dgrad_args {
   addk_src dst;                /* the source whose gradient is produced (x,a,b,relu,ld,C) */
   float* g; int32_t ldg;       /* gradient wrt dst.x (raw), same geometry as dst */
   int32_t accumulate;          /* 0: overwrite g, 1: g += */
-  float* dab;                  /* [rows][C][2] partial (dA,dB) or NULL; rows = addk_conv_rows(N*H*W, C) */
+  double* dab;                 /* fp64 [rows][C][2] partial (dA,dB) or NULL; rows = addk_conv_rows(N*H*W, C) */
 } addk_conv_dgrad_args;
 int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream);
 
@@ -136,7 +136,7 @@ typedef struct addk_dw_bwd_args {
   addk_src src;                 /* forward input (x,a,b,relu) */
   const float* w;
   float* g; int32_t ldg; int32_t accumulate;   /* gradient wrt src.x (may be NULL: skip dgrad) */
-  float* dab;                   /* [rows][C][2] or NULL; rows = addk_dw_rows() */
+  double* dab;                  /* fp64 [rows][C][2] or NULL; rows = addk_dw_rows() */
   float* dw; int32_t dw_accumulate;            /* [C][KH*KW] */
   float* ws;                    /* [rows][C][KH*KW] partial weight gradients */
 } addk_dw_bwd_args;
@@ -147,7 +147,7 @@ int addk_dw_rows(int64_t P, int32_t C);
  * BatchNorm statistics (F.batch_norm training mode, batchnorm.py:51-53; eps=1e-5, mom=0.1).
  * ------------------------------------------------------------------------------------- */
 typedef struct addk_bn_finalize_args {
-  const float* partial;  /* [rows][C][2] (sum, sumsq) — or the all-reduced [1][C][2] */
+  const double* partial; /* fp64 [rows][C][2] (sum, sumsq) — or the all-reduced [1][C][2] */
   int32_t rows, C;
   double count;          /* number of values per channel (global batch under SyncBN) */
   const float* gamma; const float* beta;
@@ -159,7 +159,7 @@ typedef struct addk_bn_finalize_args {
 int addk_bn_finalize(const addk_bn_finalize_args* a, void* stream);
 
 /* sum the rows of a partial slab into out[C][2] (the vector that is all-reduced over RCCL) */
-int addk_slab_reduce(const float* partial, int32_t rows, int32_t C, float* out, void* stream);
+int addk_slab_reduce(const double* partial, int32_t rows, int32_t C, double* out, void* stream);
 
 /* eval mode: a = gamma/sqrt(running_var+eps), b = beta - running_mean*a */
 int addk_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -172,7 +172,7 @@ int addk_bn_eval_affine(const float* gamma, const float* beta, const float* rm, 
  * With SyncBN, `dmv` receives (dmean_tot, dvar) per channel for the cross-rank all-reduce
  * and addk_bn_bwd_coeffs_from_dmv() finishes the job. */
 typedef struct addk_bn_bwd_args {
-  const float* slab[ADDK_MAX_SLAB]; int32_t rows[ADDK_MAX_SLAB]; int32_t nslab;
+  const double* slab[ADDK_MAX_SLAB]; int32_t rows[ADDK_MAX_SLAB]; int32_t nslab;
   int32_t C; double count;
   const float* gamma; const float* mean; const float* invstd; const float* a;
   float* dgamma; float* dbeta; int32_t accumulate;
@@ -201,7 +201,7 @@ typedef struct addk_affine_sum_bwd_args {
   const float* dout; int32_t lddo;
   const float* out; int32_t ldo; int32_t relu_out;   /* forward output, needed only when relu_out */
   float* g[ADDK_MAX_TERMS]; int32_t ldg[ADDK_MAX_TERMS]; int32_t accumulate[ADDK_MAX_TERMS];
-  float* dab[ADDK_MAX_TERMS];     /* [rows][C][2] partials, rows = addk_ew_rows(P, C) */
+  double* dab[ADDK_MAX_TERMS];    /* fp64 [rows][C][2] partials, rows = addk_ew_rows(P, C) */
 } addk_affine_sum_bwd_args;
 int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stream);
 int addk_ew_rows(int64_t P, int32_t C);
@@ -229,7 +229,7 @@ typedef struct addk_resize_bwd_args {
   const float* dy_scale;        /* optional device scalar multiplying dy (loss scale) */
   addk_src src; int32_t N, H, W, OH, OW;
   float* g; int32_t ldg; int32_t accumulate;
-  float* dab;                   /* [rows][C][2] or NULL (only with a lazy+relu prologue) */
+  double* dab;                  /* fp64 [rows][C][2] or NULL (only with a lazy+relu prologue) */
 } addk_resize_bwd_args;
 int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream);
 
@@ -241,7 +241,7 @@ int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream);
  * (used for bias gradients). */
 int addk_gap_fwd(const addk_src* src, int32_t N, int32_t HW, float* y, int32_t ldy, float* ws, int32_t mean, void* stream);
 int addk_gap_bwd(const addk_src* src, int32_t N, int32_t HW, const float* dy, int32_t lddy,
-                 float* g, int32_t ldg, int32_t accumulate, float* dab, void* stream);
+                 float* g, int32_t ldg, int32_t accumulate, double* dab, void* stream);
 
 /* 3x3 pooling primitives of the registry (operations.py:9-10; cold on every shipped genotype).
  * mode 0: max, 1: avg with count_include_pad=False.  pad=1. */
@@ -258,7 +258,7 @@ int addk_nchw_to_nhwc(const float* x, int32_t N, int32_t C, int64_t HW, float* y
 int addk_nhwc_to_nchw(const addk_src* src, int32_t N, int64_t HW, float* y, void* stream);
 /* gradient of nhwc_to_nchw incl. the lazy prologue: g (+)= mask*a*dy_nchw, dab partials */
 int addk_nchw_grad_to_nhwc(const float* dy, const addk_src* src, int32_t N, int64_t HW,
-                           float* g, int32_t ldg, int32_t accumulate, float* dab, void* stream);
+                           float* g, int32_t ldg, int32_t accumulate, double* dab, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Softmax cross-entropy over NCHW logits (nn.CrossEntropyLoss(weight, ignore_index), train.py:70,231).
