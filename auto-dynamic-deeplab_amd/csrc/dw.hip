@@ -32,9 +32,13 @@ __global__ void __launch_bounds__(256) dw_fwd_kernel(const DwK p) {
   const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
   if (pl >= p.npl) return;
   const int c = 4 * q, nrem = C - c;
-  const long ohw = (long)p.OH * p.OW;
-  for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
-    int n = (int)(pp / ohw); int rem = (int)(pp - (long)n * ohw);
+  const int ohw = p.OH * p.OW;
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  if (p.src.a) { av = ld4g(p.src.a + c, nrem, p.vec); bv = ld4g(p.src.b + c, nrem, p.vec); }
+  const bool relu = p.src.relu != 0;
+  const int P = (int)p.P;
+  for (int pp = blockIdx.x * p.npl + pl; pp < P; pp += gridDim.x * p.npl) {
+    int n = pp / ohw; int rem = pp - n * ohw;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
     float4 acc = zero4();
     for (int kh = 0; kh < p.KH; ++kh) {
@@ -44,13 +48,14 @@ __global__ void __launch_bounds__(256) dw_fwd_kernel(const DwK p) {
         int iw = ow * p.stride - p.pad + kw * p.dil;
         if ((unsigned)iw >= (unsigned)p.W) continue;
         float4 v = ld4g(p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + c, nrem, p.vec);
-        v = prologue4(v, p.src.a, p.src.b, c, nrem, p.src.relu != 0, p.vec);
+        v.x = fmaf(av.x, v.x, bv.x); v.y = fmaf(av.y, v.y, bv.y); v.z = fmaf(av.z, v.z, bv.z); v.w = fmaf(av.w, v.w, bv.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         const float* wt = &wl[(kh * p.KW + kw) * C4 + c];
         acc.x = fmaf(wt[0], v.x, acc.x); acc.y = fmaf(wt[1], v.y, acc.y);
         acc.z = fmaf(wt[2], v.z, acc.z); acc.w = fmaf(wt[3], v.w, acc.w);
       }
     }
-    st4g(p.y + pp * p.ldy + c, acc, nrem, p.vec);
+    st4g(p.y + (long)pp * p.ldy + c, acc, nrem, p.vec);
   }
 }
 
@@ -70,18 +75,19 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
   const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
   const bool active = pl < p.npl;
   const int c = 4 * q, nrem = C - c;
-  const long hw = (long)p.H * p.W;
+  const int hw = p.H * p.W;
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  if (active && p.src.a) { av = ld4g(p.src.a + c, nrem, p.vec); bv = ld4g(p.src.b + c, nrem, p.vec); }
+  const int P = (int)p.P;
   float4 dwacc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) dwacc[i] = zero4();
   double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
   if (active) {
-    for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
-      int n = (int)(pp / hw); int rem = (int)(pp - (long)n * hw);
+    for (int pp = blockIdx.x * p.npl + pl; pp < P; pp += gridDim.x * p.npl) {
+      int n = pp / hw; int rem = pp - n * hw;
       int ih = rem / p.W, iw = rem - ih * p.W;
-      float4 x = ld4g(p.src.x + pp * p.src.ld + c, nrem, p.vec);
-      float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
-      if (p.src.a) { av = ld4g(p.src.a + c, nrem, p.vec); bv = ld4g(p.src.b + c, nrem, p.vec); }
+      float4 x = ld4g(p.src.x + (long)pp * p.src.ld + c, nrem, p.vec);
       float4 zp = make_float4(fmaf(av.x, x.x, bv.x), fmaf(av.y, x.y, bv.y), fmaf(av.z, x.z, bv.z), fmaf(av.w, x.w, bv.w));
       const bool r = p.src.relu != 0;
       bool m0 = !r || zp.x > 0.f, m1 = !r || zp.y > 0.f, m2 = !r || zp.z > 0.f, m3 = !r || zp.w > 0.f;
@@ -109,7 +115,7 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
       for (int e = 0; e < 4; ++e) { sA[e] += (double)get4(gm, e) * (double)get4(x, e); sB[e] += (double)get4(gm, e); }
       if (p.g) {
         float4 gv = make_float4(gm.x * av.x, gm.y * av.y, gm.z * av.z, gm.w * av.w);
-        float* gp = p.g + pp * p.ldg + c;
+        float* gp = p.g + (long)pp * p.ldg + c;
         if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vec); gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
         st4g(gp, gv, nrem, p.vec);
       }
@@ -148,12 +154,15 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
   }
 }
 
-__global__ void dw_wreduce_kernel(const float* ws, int rows, int n, float* dw, int accumulate) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += ws[(long)r * n + i];
-    dw[i] = accumulate ? dw[i] + s : s;
-  }
+// one 64-lane wave per weight element: lanes stride over the partial rows, then a fixed-order butterfly
+__global__ void __launch_bounds__(256) dw_wreduce_kernel(const float* ws, int rows, int n, float* dw, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float s = 0.f;
+  for (int r = lane; r < rows; r += 64) s += ws[(long)r * n + i];
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) dw[i] = accumulate ? dw[i] + s : s;
 }
 
 int dw_rows(long P, int C) {
@@ -172,6 +181,7 @@ static int dw_fill(DwK& k, const addk_src& src, int N, int H, int W, int OH, int
   ADDK_REQUIRE(src.x && src.C > 0 && src.C <= 1024 && src.ld >= src.C, "dw: bad source");
   ADDK_REQUIRE((src.a == nullptr) == (src.b == nullptr), "dw: a/b must come together");
   ADDK_REQUIRE(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && KH * KW <= MAXT && stride > 0 && dil > 0, "dw: bad geometry");
+  ADDK_REQUIRE((long)N * H * W < (1L << 30) && (long)N * OH * OW < (1L << 30), "dw: tensor too large for 32-bit pixel indexing");
   k.src = src; k.N = N; k.H = H; k.W = W; k.OH = OH; k.OW = OW; k.KH = KH; k.KW = KW; k.stride = stride; k.pad = pad; k.dil = dil;
   EwMap m = ew_map(src.C); k.nq = m.nq; k.npl = m.npl;
   return 0;
@@ -211,6 +221,6 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
   rc = addk_check_launch("dw_bwd");
   if (rc) return rc;
   int n = a->src.C * taps;
-  hipLaunchKernelGGL(dw_wreduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a->ws, rows, n, a->dw, a->dw_accumulate);
+  hipLaunchKernelGGL(dw_wreduce_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, a->ws, rows, n, a->dw, a->dw_accumulate);
   return addk_check_launch("dw_wreduce");
 }

@@ -16,7 +16,7 @@ struct WgK {
   addk_src src;
   float* ws;
   int taps, nzt, nyt;      // tiles: taps, z (input-channel) tiles, y (output-channel) tiles
-  int splits; long P; long chunkP;
+  int splits; int P; int chunkP;
   int vecY, vecZ;
 };
 
@@ -42,9 +42,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
   const int tap = bx % p.taps; const int yt = bx / p.taps;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = yt * BCY, c0 = zt * BCZ;
-  const long ohw = (long)p.OH * p.OW;
-  const long pbeg = (long)blockIdx.y * p.chunkP;
-  long pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
+  const int ohw = p.OH * p.OW;
+  const int pbeg = blockIdx.y * p.chunkP;
+  int pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
+  // lazy-BN scale/shift of this thread's channel quads (fixed across pixel steps)
+  float4 za[NZJ], zb[NZJ];
+#pragma unroll
+  for (int j = 0; j < NZJ; ++j) {
+    int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
+    int c = c0 + 4 * q;
+    za[j] = make_float4(1.f, 1.f, 1.f, 1.f); zb[j] = zero4();
+    if (p.src.a && row < KP && c < p.src.C) { za[j] = ld4g(p.src.a + c, p.src.C - c, p.vecZ); zb[j] = ld4g(p.src.b + c, p.src.C - c, p.vecZ); }
+  }
+  const bool zrelu = p.src.relu != 0;
 
   f32x4 acc[CTY][CTZ];
 #pragma unroll
@@ -53,28 +63,32 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
     for (int j = 0; j < CTZ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float4 ry[NYJ], rz[NZJ];
-  auto load_step = [&](long p0) {
+  auto load_step = [&](int p0) {
 #pragma unroll
     for (int j = 0; j < NYJ; ++j) {
       int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
-      long pp = p0 + row; int co = co0 + 4 * q;
+      int pp = p0 + row; int co = co0 + 4 * q;
       float4 v = zero4();
-      if (row < KP && pp < pend && co < p.Cout) v = ld4g(p.dy + pp * p.lddy + co, p.Cout - co, p.vecY);
+      if (row < KP && pp < pend && co < p.Cout) v = ld4g(p.dy + (long)pp * p.lddy + co, p.Cout - co, p.vecY);
       ry[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < NZJ; ++j) {
       int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
-      long pp = p0 + row; int c = c0 + 4 * q;
+      int pp = p0 + row; int c = c0 + 4 * q;
       float4 v = zero4();
       if (row < KP && pp < pend && c < p.src.C) {
-        int n = (int)(pp / ohw); int rem = (int)(pp - (long)n * ohw);
+        int n = pp / ohw; int rem = pp - n * ohw;
         int oh = rem / p.OW, ow = rem - oh * p.OW;
         int ih = oh * p.stride - p.pad + kh * p.dil, iw = ow * p.stride - p.pad + kw * p.dil;
         if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
           const float* xp = p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + c;
-          v = ld4g(xp, p.src.C - c, p.vecZ);
-          v = prologue4(v, p.src.a, p.src.b, c, p.src.C - c, p.src.relu != 0, p.vecZ);
+          const int nrem = p.src.C - c;
+          v = ld4g(xp, nrem, p.vecZ);
+          v.x = fmaf(za[j].x, v.x, zb[j].x); v.y = fmaf(za[j].y, v.y, zb[j].y);
+          v.z = fmaf(za[j].z, v.z, zb[j].z); v.w = fmaf(za[j].w, v.w, zb[j].w);
+          if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
         }
       }
       rz[j] = v;
@@ -97,7 +111,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
     load_step(pbeg);
     store_step();
     __syncthreads();
-    for (long p0 = pbeg; p0 < pend; p0 += KP) {
+    for (int p0 = pbeg; p0 < pend; p0 += KP) {
       const bool more = p0 + KP < pend;
       if (more) load_step(p0 + KP);
 #pragma unroll
@@ -148,8 +162,13 @@ __global__ void wgrad_reduce_kernel(const float* ws, int splits, int Cout, int t
                                     int cin_total, int w_choff, int accumulate) {
   long n = (long)Cout * taps * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(long)k * n + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four independent chains keep the loads in flight
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      s0 += ws[(long)k * n + i]; s1 += ws[(long)(k + 1) * n + i]; s2 += ws[(long)(k + 2) * n + i]; s3 += ws[(long)(k + 3) * n + i];
+    }
+    for (; k < splits; ++k) s0 += ws[(long)k * n + i];
+    float s = (s0 + s1) + (s2 + s3);
     int c = (int)(i % C); long r = i / C; int tap = (int)(r % taps); int co = (int)(r / taps);
     float* d = dw + (long)co * ldw + (long)tap * cin_total + w_choff + c;
     *d = accumulate ? *d + s : s;
@@ -177,7 +196,7 @@ int pick_splits(long P, int tiles) {
   long want = cdiv(1024, tiles);
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
-  if (s > 256) s = 256;
+  if (s > 32) s = 32;
   return (int)s;
 }
 
@@ -202,11 +221,12 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   k.src = a->src; k.ws = a->ws;
   int cty, ctz; pick_tiles(a->Cout, a->src.C, &cty, &ctz);
   k.taps = a->KH * a->KW; k.nyt = cdiv(a->Cout, 16 * cty); k.nzt = cdiv(a->src.C, 16 * ctz);
-  k.P = (long)a->N * a->OH * a->OW;
+  ADDK_REQUIRE((long)a->N * a->OH * a->OW < (1L << 30) && (long)a->N * a->H * a->W < (1L << 30), "conv_wgrad: tensor too large for 32-bit pixel indexing");
+  k.P = a->N * a->OH * a->OW;
   const int tiles = k.nyt * k.taps * k.nzt;
   k.splits = pick_splits(k.P, tiles);
   ADDK_REQUIRE(a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
-  k.chunkP = (long)cdiv(cdiv(k.P, k.splits), KP) * KP;
+  k.chunkP = cdiv(cdiv(k.P, k.splits), KP) * KP;
   k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
   k.vecZ = src_vec_ok(a->src);
   dim3 grid(tiles, k.splits);

@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import plan as _plan
-from .plan import Act, Graph, OutRef
+from .plan import Act, Graph, NbtCounter, OutRef
 
 _world = None          # set by addk.parallel.init_sync_bn()
 
@@ -73,7 +73,7 @@ class Plan:
         self.params = list(g.params)
         self.param_ptrs = [p.data_ptr() for p in self.params]
         self.serial = 0
-        self.nbt = list(g.nbt.items())
+        self.nbt = NbtCounter(g.nbt)
 
     def check_params(self):
         for p, ptr in zip(self.params, self.param_ptrs):
@@ -87,8 +87,7 @@ class Plan:
         self.in_tensors = inputs
         st = _plan.current_stream()
         self.g.run(self.g.fwd, st)
-        if self.nbt:
-            torch._foreach_add_([t for t, _ in self.nbt], [int(c) for _, c in self.nbt])
+        self.nbt.bump()
         self.serial += 1
         outs = []
         for kind, o in self.outs:

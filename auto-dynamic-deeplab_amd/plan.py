@@ -111,10 +111,11 @@ class Graph:
         self.pginit = set()
         self._pcols = {}
         self.params = []              # ordered unique params touched
-        self.nbt = {}                 # num_batches_tracked tensor -> increments per forward
+        self.nbt = {}                 # BatchNorm module -> num_batches_tracked increments per forward
         self._wgrads = []             # wgrad arg structs sharing one scratch buffer (launches are stream-ordered)
         self.nbytes = 0
         self._bufs = []               # owns every device buffer: kernels only see raw pointers
+        self.meta = []                # per-launch algorithmic work of the dense convs (bench / roofline)
 
     # ---------------- memory ----------------
     def buf(self, n, zero=False):
@@ -170,7 +171,8 @@ class Graph:
         ranges of one weight): first touch of an interval overwrites, later touches accumulate."""
         self.param(p)
         if self.pgrad[p] is None:
-            self.pgrad[p] = torch.empty_like(p)
+            views = getattr(self, 'pgrad_views', None)
+            self.pgrad[p] = views[p] if views is not None and p in views else torch.empty_like(p)
             self._pcols[p] = []
         iv = self._pcols[p]
         c0, c1 = cols if cols is not None else (0, 1 << 30)
@@ -256,6 +258,9 @@ class Graph:
         ar.stats_ld = stats_ld
         self.keep.append(ar)
         self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar))
+        self.meta.append(dict(kind='conv_fwd', idx=len(self.fwd) - 1, flops=2.0 * N * OH * OW * Cout * k * k * csum,
+                              bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
+                              shape=(N, H, W, csum, Cout, k, stride, dil)))
 
         if self.want_grad:
             srcs_l = list(srcs)
@@ -360,7 +365,7 @@ class Graph:
             if mod.track_running_stats and mod.running_mean is not None:
                 fa.running_mean, fa.running_var = mod.running_mean.data_ptr(), mod.running_var.data_ptr()
                 if mod.num_batches_tracked is not None:
-                    self.nbt[mod.num_batches_tracked] = self.nbt.get(mod.num_batches_tracked, 0) + 1
+                    self.nbt[mod] = self.nbt.get(mod, 0) + 1
             fa.momentum = 0.1 if mod.momentum is None else mod.momentum
             fa.eps = mod.eps
             fa.a, fa.b, fa.mean, fa.invstd = a.ptr, b.ptr, st.mean.ptr, st.invstd.ptr
@@ -726,3 +731,28 @@ class OutRef:
         elif self.bwd_cmd is not None:
             self.bwd_cmd[2][0] = gy.data_ptr()
         return gy
+
+
+class NbtCounter:
+    """All `num_batches_tracked` counters of a plan live in ONE int64 tensor (each module's buffer is a 0-dim view
+    of it), so a forward bumps them with a single add instead of one tiny launch per BatchNorm."""
+
+    def __init__(self, nbt):
+        self.mods = list(nbt)
+        self.counts = [int(nbt[m]) for m in self.mods]
+        self.flat = self.inc = None
+
+    def _flatten(self):
+        dev = self.mods[0].num_batches_tracked.device
+        self.flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in self.mods]).to(torch.int64)
+        for i, m in enumerate(self.mods):
+            m._buffers['num_batches_tracked'] = self.flat[i]
+        self.inc = torch.tensor(self.counts, dtype=torch.int64, device=dev)
+
+    def bump(self):
+        if not self.mods:
+            return
+        m0 = self.mods[0].num_batches_tracked
+        if self.flat is None or m0.data_ptr() != self.flat.data_ptr() or self.mods[-1].num_batches_tracked.data_ptr() != self.flat[-1].data_ptr():
+            self._flatten()          # first use, or another plan / .to() re-pointed the buffers
+        self.flat.add_(self.inc)

@@ -1,0 +1,139 @@
+"""Fused training step of the path (reference train.py:216-242): forward of all exits, CrossEntropyLoss per exit
+averaged over exits, backward, SGD(momentum, weight_decay, nesterov) — emitted as ONE static plan over flat
+parameter/gradient buffers and replayed as a single hipGraph launch (eager launch list when RCCL collectives
+sit inside the step)."""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib as L
+from . import module as _module
+from . import plan as _plan
+from .module import ensure_layout
+from .plan import Graph, NbtCounter
+
+
+def _flat_views(params, device):
+    """Re-point every parameter into one flat fp32 buffer (16-byte aligned slots, strides preserved) and build
+    matching views into a flat gradient buffer."""
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + 3) // 4 * 4
+    flat_p = torch.zeros(total, dtype=torch.float32, device=device)
+    flat_g = torch.zeros(total, dtype=torch.float32, device=device)
+    gviews = {}
+    for p, o in zip(params, offs):
+        pv = torch.as_strided(flat_p, p.shape, p.stride(), o)
+        with torch.no_grad():
+            pv.copy_(p.data)
+        p.data = pv
+        gviews[p] = torch.as_strided(flat_g, p.shape, p.stride(), o)
+    return flat_p, flat_g, gviews
+
+
+class TrainStep:
+    def __init__(self, model, batch_shape, lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, class_weight=None,
+                 ignore_index=255, use_graph=None, sync_comm=None):
+        lib = self.lib = L.load()
+        dev = next(model.parameters()).device
+        _plan.require_device(next(model.parameters()))
+        self.model, self.dev = model, dev
+        model.train()
+        for p in model.parameters():
+            ensure_layout(p)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.flat_p, self.flat_g, gviews = _flat_views(self.params, dev)
+        self.mom_buf = torch.zeros_like(self.flat_p)
+        self.lr_dev = torch.tensor([lr], dtype=torch.float32, device=dev)
+        self.hyper = (momentum, weight_decay, int(nesterov))
+        N, Cin, H, W = batch_shape
+        self.x = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
+        self.target = torch.zeros((N, H, W), dtype=torch.int64, device=dev)
+        self.world = sync_comm.size if sync_comm is not None else 1
+        g = self.g = Graph(dev, True, True, sync_comm)
+        g.pgrad_views = gviews
+        a, self.inref = g.input_nchw(self.x)
+        self.inref.bind(self.x)
+        outs = model.emit(g, a)
+        self.outs = outs
+        nex = len(outs)
+        ncls = outs[0].y.shape[1]
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.wsum = torch.zeros(1, dtype=torch.float32, device=dev)
+        ws = torch.zeros(int(lib.addk_ce_ws_floats(N, H * W)), dtype=torch.float32, device=dev)
+        cw = class_weight.to(dev).float().contiguous() if class_weight is not None else None
+        self._keep = [ws, cw]
+        cwp = cw.data_ptr() if cw is not None else None
+        g._add(g.fwd, 'loss_zero', lib.addk_fill, self.loss.data_ptr(), 1, 0.0)
+        g._add(g.fwd, 'ce_count', lib.addk_ce_count, self.target.data_ptr(), N * H * W, cwp, ignore_index, ncls,
+               self.wsum.data_ptr(), ws.data_ptr())
+        self.dlogits = []
+        for o in outs:
+            d = torch.empty_like(o.y)
+            self.dlogits.append(d)
+            g._add(g.fwd, 'ce_fwd_bwd', lib.addk_ce_fwd_bwd, o.y.data_ptr(), self.target.data_ptr(), N, ncls, H * W, cwp,
+                   ignore_index, self.wsum.data_ptr(), 1.0 / nex, self.loss.data_ptr(), d.data_ptr(), ws.data_ptr())
+            o.dy_ptr, o.dynamic = d.data_ptr(), False
+        g.finalize()
+        self.nbt = NbtCounter(g.nbt)
+        self.nbt.bump(); self.nbt.flat.sub_(self.nbt.inc)      # flatten now (pointers must be fixed before graph capture)
+        self.n_active = self.flat_p.numel()
+        self.nbytes = g.nbytes
+        if use_graph is None:
+            use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (self.world == 1 or os.environ.get('ADDK_GRAPH_DDP', '0') == '1')
+        self.graph = None
+        self.use_graph = use_graph
+        self.steps = 0
+
+    # one eager pass of the whole step on the current stream
+    def _run(self):
+        st = _plan.current_stream()
+        g = self.g
+        g.run(g.fwd, st)
+        g.run(g.bwd, st)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_g)
+        mom, wd, nest = self.hyper
+        L.check(self.lib.addk_sgd_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.mom_buf.data_ptr(), self.n_active,
+                                       self.lr_dev.data_ptr(), mom, wd, nest, 0, 1.0 / self.world, st), 'sgd_step')
+        self.nbt.flat.add_(self.nbt.inc)
+
+    def forward_backward_only(self):
+        """Forward + loss + backward without the optimizer update (parity tests)."""
+        st = _plan.current_stream()
+        self.g.run(self.g.fwd, st)
+        self.g.run(self.g.bwd, st)
+
+    def load_batch(self, images, targets):
+        self.x.copy_(images, non_blocking=True)
+        self.target.copy_(targets, non_blocking=True)
+
+    def set_lr(self, lr):
+        self.lr_dev.fill_(float(lr))
+
+    def step(self, images=None, targets=None, lr=None):
+        """Runs one optimisation step on the resident batch (or on `images`/`targets` if given) and returns the
+        loss as a device tensor (no host sync; the reference's per-step loss.item() is the caller's choice)."""
+        if images is not None:
+            self.load_batch(images, targets)
+        if lr is not None:
+            self.set_lr(lr)
+        if self.use_graph:
+            if self.graph is None:
+                # one eager step first (also warms RCCL), then capture
+                self._run()
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._run()
+            else:
+                self.graph.replay()
+        else:
+            self._run()
+        self.steps += 1
+        return self.loss
+
+    def grads(self):
+        return {p: self.g.pgrad.get(p) for p in self.params}

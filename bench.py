@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): Cityscapes-shaped 1024x2048 images/sec, forward+backward+SGD of ADD
+(searched-dense C=2, F=20, all exits active) at bs=2 per GPU, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Synthetic data (N(0,1) images, uniform labels with 5 % ignore), random-init
+weights of the named architecture, fp32 storage and arithmetic (dense contractions on the fp32 matrix cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+NETWORK_ARCH = [1, 2, 2, 2, 3, 2, 2, 1, 1, 1, 1, 2]      # train.py:75-79 (searched-dense, C=2)
+C_INDEX = [5]
+PEAK_MFMA_F32_TFLOPS = 157.3                              # MI355X_MICROARCH.md: fp32 matrix peak (spec)
+PEAK_HBM_GBS = 8000.0
+
+
+def make_args(F=20, B=5, sync_bn=False):
+    from types import SimpleNamespace
+    return SimpleNamespace(F=F, B=B, sync_bn=sync_bn)
+
+
+def synthetic_batch(n, h, w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n, 3, h, w), generator=g)
+    t = torch.randint(0, 19, (n, h, w), generator=g)
+    t[torch.rand((n, h, w), generator=g) < 0.05] = 255
+    return x.to(device), t.to(device)
+
+
+def cpu_baseline(genotype, n, h, w):
+    """The CPU oracle (PyTorch-CPU restatement pinned to the reference by tests/golden) timed on this box's host
+    cores on the same workload: one full fwd+bwd+SGD step at bs=n (a bounded sample: the reference needs
+    ~14 s per step on 8 cores).  Runs in a child process with a time limit; if the full-size step does not finish
+    the sample is shrunk to a quarter-size image and scaled by pixel count (said so in `sample`)."""
+    import subprocess
+    for hh, ww, limit in ((h, w, 150), (h // 2, w // 2, 90)):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--batch', str(n), '--height', str(hh),
+                                '--width', str(ww)], capture_output=True, text=True, timeout=limit)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode == 0 and line:
+                d = json.loads(line[-1])
+                if (hh, ww) != (h, w):
+                    d['value'] *= (hh * ww) / float(h * w)
+                    d['sample'] += ' (scaled by pixel count to %dx%d)' % (h, w)
+                return d
+        except subprocess.TimeoutExpired:
+            continue
+    return {'value': None, 'unit': 'images/sec', 'cores': None, 'kind': 'port', 'sample': 'cpu baseline did not finish in time'}
+
+
+def _cpu_baseline_child(genotype, n, h, w):
+    import oracle
+    torch.manual_seed(1)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    torch.set_num_threads(cores)
+    m = oracle.ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(), 0)
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True)
+    x, t = synthetic_batch(n, h, w, 1, 'cpu')
+    t0 = time.perf_counter()
+    ys = m(x)
+    loss = oracle.cross_entropy_mean_exits(ys, t)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '1 step fwd+bwd+SGD, bs=%d %dx%d, torch-CPU oracle, %.1f s' % (n, h, w, dt)}
+
+
+def time_launch(g, idx, reps=20):
+    """Average device time of ONE launch of plan command `idx`, with HIP events on the launch stream."""
+    name, fn, args = g.fwd[idx]
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        fn(*args, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn(*args, st)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--height', type=int, default=1024)
+    ap.add_argument('--width', type=int, default=2048)
+    ap.add_argument('--F', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    a = ap.parse_args()
+    if a.cpu_baseline_child:
+        g = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
+        print(json.dumps(_cpu_baseline_child(g, a.batch, a.height, a.width)))
+        return
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import addk
+    from addk.modeling.ADD import ADD
+    from addk.train import TrainStep
+    from addk import parallel
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', init_method='env://')
+        comm = parallel.init_sync_bn()
+    genotype = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
+    torch.manual_seed(1)
+    model = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=world > 1), 0).to(dev)
+    parallel.broadcast_params(model)
+    n, h, w = a.batch, a.height, a.width
+    ts = TrainStep(model, (n, 3, h, w), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm,
+                   use_graph=False if a.no_graph else None)
+    x, t = synthetic_batch(n, h, w, 1 + rank, dev)
+    ts.load_batch(x, t)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ts.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ts.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(ts.loss.item())
+    if rank != 0:
+        return
+    ms = dt / a.steps * 1e3
+    value = world * n * a.steps / dt
+
+    # roofline of the dominant kernel: the fp32-MFMA implicit-GEMM conv; its heaviest launch (decoder 3x3 304->256)
+    convs = [m for m in ts.g.meta if m['kind'] == 'conv_fwd']
+    top = max(convs, key=lambda m: m['flops'])
+    tk = time_launch(ts.g, top['idx'])
+    fwd_flops = sum(m['flops'] for m in convs)
+    roof = {'bound': 'mfma', 'achieved': top['flops'] / tk / 1e12, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': top['flops'] / tk / 1e12 / PEAK_MFMA_F32_TFLOPS, 'traffic': None,
+            'kernel': 'conv_kernel<PT=2,CT=8,FWD> (v_mfma_f32_16x16x4_f32)', 'launch_ms': tk * 1e3,
+            'launch_shape_NHWCinCoutKSD': list(top['shape']), 'algorithmic_gflop_per_launch': top['flops'] / 1e9,
+            'algorithmic_bytes_per_launch': top['bytes']}
+    out = {'metric': 'Cityscapes 1024x2048 images/sec fwd+bwd @ bs=2/GPU', 'value': value, 'unit': 'images/sec',
+           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'ADD F=%d searched_arch/autodeeplab C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, h, w, n),
+                      'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': world > 1,
+                      'hip_graph': bool(ts.graph is not None)},
+           'loss': loss,
+           'step_algorithmic_tflop': 3 * fwd_flops / 1e12,
+           'step_tflops_per_gpu': 3 * fwd_flops / (dt / a.steps) / 1e12,
+           'plan_device_gb': ts.nbytes / 1e9,
+           'roofline': roof}
+    if not a.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(genotype, n, h, w)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,127 @@
+"""GPU tests of the fused training step (addk.train.TrainStep), the drop-in criterion and the evaluator."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+import oracle                                                   # noqa: E402
+from _util import ARCH_C2, GENOTYPE_AUTODEEPLAB, fill_params, make_args, rand_tensor, rel_err   # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _models(dev, Fv=4, seed=600):
+    from addk.modeling.ADD import ADD
+    args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(Fv), 0)
+    mo = oracle.ADD(*args)
+    fill_params(mo, seed)
+    ma = ADD(*args)
+    ma.load_state_dict(mo.state_dict())
+    return ma.to(dev), mo
+
+
+def _batch(n, hw, seed=5):
+    x = rand_tensor(seed, 'ts_x', (n, 3) + hw)
+    r = np.random.default_rng(seed)
+    t = torch.from_numpy(r.integers(0, 19, (n,) + hw)).long()
+    t[torch.from_numpy(r.random((n,) + hw) < 0.05)] = 255
+    return x, t
+
+
+def test_criterion_matches_torch(dev):
+    from addk.loss import CrossEntropyLoss
+    x = rand_tensor(3, 'ce_x', (2, 19, 33, 65)) * 3
+    _, t = _batch(2, (33, 65))
+    w = torch.rand(19) + 0.5
+    for weight in (None, w):
+        xa = x.clone().to(dev).requires_grad_(True)
+        xo = x.clone().requires_grad_(True)
+        la = CrossEntropyLoss(weight=weight, ignore_index=255).to(dev)(xa, t.to(dev))
+        lo = nn.CrossEntropyLoss(weight=weight, ignore_index=255)(xo, t)
+        (la * 0.5).backward(); (lo * 0.5).backward()
+        assert abs(la.item() - lo.item()) < 1e-5 * abs(lo.item())
+        assert rel_err(xa.grad, xo.grad) < 1e-5
+    # generic (non-19) class count path
+    x7 = rand_tensor(3, 'ce_x7', (1, 7, 9, 11)); t7 = torch.randint(0, 7, (1, 9, 11))
+    xa = x7.clone().to(dev).requires_grad_(True); xo = x7.clone().requires_grad_(True)
+    la = CrossEntropyLoss().to(dev)(xa, t7.to(dev)); lo = nn.CrossEntropyLoss(ignore_index=255)(xo, t7)
+    la.backward(); lo.backward()
+    assert abs(la.item() - lo.item()) < 1e-5 and rel_err(xa.grad, xo.grad) < 1e-5
+
+
+def test_train_step_forward_backward_and_sgd(dev):
+    from addk.train import TrainStep
+    ma, mo = _models(dev)
+    m64 = oracle.ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4), 0)
+    m64.load_state_dict(mo.state_dict()); m64.double()
+    x, t = _batch(2, (65, 129))
+    ts = TrainStep(ma, (2, 3, 65, 129), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, use_graph=False)
+    ts.load_batch(x.to(dev), t.to(dev))
+    ts.forward_backward_only()
+    torch.cuda.synchronize()
+    res = {}
+    for name, m, xx in (('o32', mo, x), ('o64', m64, x.double())):
+        m.train()
+        loss = oracle.cross_entropy_mean_exits(m(xx), t)
+        loss.backward()
+        res[name] = (loss.item(), {k: p.grad.double() for k, p in m.named_parameters()})
+    la = ts.loss.item()
+    assert abs(la - res['o64'][0]) <= 3 * abs(res['o32'][0] - res['o64'][0]) + 1e-4 * abs(la)
+    names = {p: k for k, p in ma.named_parameters()}
+    ga = {names[p]: g.double().cpu() for p, g in ts.grads().items() if g is not None}
+    g64 = res['o64'][1]
+
+    def rel_l2(gx):
+        return (sum(float(((gx[k] - g64[k]) ** 2).sum()) for k in g64) / sum(float((g64[k] ** 2).sum()) for k in g64)) ** 0.5
+    assert set(ga) == set(g64)
+    assert rel_l2(ga) <= 2.0 * rel_l2(res['o32'][1]) + 1e-3
+    # the fused SGD kernel against torch.optim.SGD semantics applied to the SAME gradients (exact arithmetic check)
+    p0 = ts.flat_p.clone(); g0 = ts.flat_g.clone()
+    ts2_before = ts.mom_buf.clone()
+    assert float(ts2_before.abs().max()) == 0.0
+    ts.step()            # eager: fwd+bwd (same inputs -> same grads) + sgd
+    torch.cuda.synchronize()
+    d = g0 + 4e-5 * p0
+    buf = d
+    expect = p0 - 0.05 * (d + 0.9 * buf)
+    # BN running statistics changed between the two forwards, gradients did not (training BN ignores them)
+    assert rel_err(ts.flat_g, g0) < 1e-6
+    assert rel_err(ts.flat_p, expect) < 1e-6
+    assert rel_err(ts.mom_buf, buf) < 1e-6
+
+
+def test_train_step_hipgraph_equals_eager(dev):
+    from addk.train import TrainStep
+    losses = {}
+    for mode in (False, True):
+        ma, _ = _models(dev)
+        x, t = _batch(2, (33, 65))
+        ts = TrainStep(ma, (2, 3, 33, 65), use_graph=mode)
+        ts.load_batch(x.to(dev), t.to(dev))
+        ls = []
+        for _ in range(4):
+            ls.append(ts.step().item())
+        losses[mode] = ls
+        assert (ts.graph is not None) == mode
+    assert losses[True] == losses[False], (losses[True], losses[False])      # deterministic kernels: bitwise equal
+    assert losses[True][-1] < losses[True][0]                                # and the loss goes down
+
+
+def test_evaluator_and_argmax(dev, golden):
+    from addk.metrics import Evaluator, argmax_logits
+    g = golden('misc')
+    ev = Evaluator(19, dev)
+    gt = torch.from_numpy(g['eval/gt'].astype(np.int64)); pr = torch.from_numpy(g['eval/pred'].astype(np.int64))
+    ev.add_batch(gt.to(dev), pr.to(dev))
+    assert np.array_equal(ev.confusion_matrix.cpu().numpy(), g['eval/cm'])
+    assert abs(ev.Mean_Intersection_over_Union() - float(g['eval/miou'])) < 1e-6
+    assert abs(float(ev.Pixel_Accuracy()) - float(g['eval/pa'])) < 1e-6
+    assert abs(float(ev.Frequency_Weighted_Intersection_over_Union()) - float(g['eval/fwiou'])) < 1e-6
+    x = rand_tensor(4, 'am', (2, 19, 17, 33))
+    assert torch.equal(argmax_logits(x.to(dev)).cpu(), x.argmax(1))
