@@ -88,6 +88,8 @@ _SIGS = {
     'addk_selftest_mfma': (i32, [vp, vp]),
     'addk_conv_fwd': (i32, [C.POINTER(ConvArgs), vp]),
     'addk_conv_rows': (i32, [i64, i32]),
+    'addk_set_conv_precision': (i32, [i32]),
+    'addk_get_conv_precision': (i32, []),
     'addk_conv_dgrad': (i32, [C.POINTER(ConvDgradArgs), vp]),
     'addk_conv_wgrad': (i32, [C.POINTER(ConvWgradArgs), vp]),
     'addk_conv_wgrad_ws': (i64, [i64, i32, i32, i32]),

@@ -14,6 +14,7 @@
 // bank-conflict free (row*36 mod 64 walks the 16 multiples of 4).
 //
 // Reference call sites: see include/addk.h (addk_conv_fwd / addk_conv_dgrad).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -44,14 +45,38 @@ struct ConvK {
 constexpr int BK = 32;
 constexpr int BKP = 36;
 
-template <int PT, int CT, int MODE>
+// PREC_F32: exact fp32 products on v_mfma_f32_16x16x4_f32.
+// PREC_B3:  every fp32 operand x is split at LDS-staging time into bf16 hi = rn(x), lo = rn(x - hi) and a product is
+//           evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the dropped lo*lo term
+//           is <= 2^-16 relative): 3 bf16 MFMAs at 16x the fp32 matrix rate = 5.3x the exact path, error ~1e-5 relative
+//           per product, two orders below the 1e-3 parity bound.  Rows are 32 bf16 + 16 pad (96 B): ds_read_b128
+//           fragment reads of a 16-lane group then fall on 16 distinct 16-B slots of the 256-B bank row.
+enum { PREC_F32 = 0, PREC_B3 = 1 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int RS = 48;      // bf16 elements per LDS row in the split path
+
+__device__ __forceinline__ void split4(float4 v, bf16x4& h, bf16x4& l) {
+  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+  l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+  l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+}
+
+template <int PT, int CT, int MODE, int PREC>
 __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   constexpr int BP = 64 * PT;
   constexpr int BC = 16 * CT;
   constexpr int NAJ = 2 * PT;             // float4 A slots per thread
   constexpr int NBJ = (CT + 1) / 2;       // float4 B slots per thread
-  __shared__ __attribute__((aligned(16))) float As[BP * BKP];
-  __shared__ __attribute__((aligned(16))) float Bs[BC * BKP];
+  // one LDS arena: fp32 path [BP+BC][36] floats; split path hi and lo panels of [BP+BC][48] bf16 (same bytes per row pair)
+  constexpr int LDS_BYTES = PREC == PREC_F32 ? (BP + BC) * BKP * 4 : (BP + BC) * RS * 2 * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  float* As = reinterpret_cast<float*>(lds_raw);
+  float* Bs = As + BP * BKP;
+  __bf16* Ah = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* Al = Ah + BP * RS;
+  __bf16* Bh = Al + BP * RS;
+  __bf16* Bl = Bh + BC * RS;
   __shared__ double red[4][BC][2];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -84,6 +109,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 ra[NAJ], rb[NBJ];
+    unsigned amask = 0;          // bit j: ra[j] holds an in-bounds pixel (the lazy prologue applies; padding stays 0)
     int s = 0, tap = 0, c0 = 0, choff = 0;
 
     auto load_chunk = [&](int s_, int tap_, int c0_, int choff_) {
@@ -91,6 +117,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       const int kh = tap_ / p.KW, kw = tap_ - kh * p.KW;
       const int c = c0_ + 4 * aq;
       const int nrem = S.C - c;          // valid channels from c on
+      amask = 0;
 #pragma unroll
       for (int j = 0; j < NAJ; ++j) {
         float4 v = zero4();
@@ -111,7 +138,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
           if (ok) {
             const float* src = S.x + ((long)(rn[j] * p.H + ih) * p.W + iw) * S.ld + c;
             v = ld4g(src, nrem, p.vecA);
-            v = prologue4(v, S.a, S.b, c, nrem, S.relu != 0, p.vecA);
+            amask |= 1u << j;
           }
         }
         ra[j] = v;
@@ -142,7 +169,58 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
         }
       }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int s_, int c0_) {
+      {   // lazy prologue of the producer's BatchNorm/ReLU, applied here (after the MFMAs of the previous chunk)
+        const addk_src S = p.src[s_];
+        if (S.a || S.relu) {
+          const int c = c0_ + 4 * aq;
+          const int nrem = S.C - c;
+          if (nrem > 0) {
+            float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+            if (S.a) { av = ld4g(S.a + c, nrem, p.vecA); bv = ld4g(S.b + c, nrem, p.vecA); }
+#pragma unroll
+            for (int j = 0; j < NAJ; ++j) {
+              if (amask & (1u << j)) {
+                float4 v = ra[j];
+                v.x = fmaf(av.x, v.x, bv.x); v.y = fmaf(av.y, v.y, bv.y); v.z = fmaf(av.z, v.z, bv.z); v.w = fmaf(av.w, v.w, bv.w);
+                if (S.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
+                ra[j] = v;
+              }
+            }
+          }
+        }
+      }
+      if (PREC == PREC_B3) {
+#pragma unroll
+        for (int j = 0; j < NAJ; ++j) {
+          bf16x4 h, l; split4(ra[j], h, l);
+          *reinterpret_cast<bf16x4*>(&Ah[(ar + 32 * j) * RS + 4 * aq]) = h;
+          *reinterpret_cast<bf16x4*>(&Al[(ar + 32 * j) * RS + 4 * aq]) = l;
+        }
+        if (MODE == MODE_FWD) {
+#pragma unroll
+          for (int j = 0; j < NBJ; ++j) {
+            int slot = t + 256 * j, row = slot >> 3, q = slot & 7;
+            if (row < BC) {
+              bf16x4 h, l; split4(rb[j], h, l);
+              *reinterpret_cast<bf16x4*>(&Bh[row * RS + 4 * q]) = h;
+              *reinterpret_cast<bf16x4*>(&Bl[row * RS + 4 * q]) = l;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NBJ; ++j) {
+            int slot = t + 256 * j, k = slot / (4 * CT), ng = slot - k * (4 * CT);
+            if (k < BK) {
+              bf16x4 h, l; split4(rb[j], h, l);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { Bh[(4 * ng + e) * RS + k] = h[e]; Bl[(4 * ng + e) * RS + k] = l[e]; }
+            }
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < NAJ; ++j) st4(&As[(ar + 32 * j) * BKP + 4 * aq], ra[j]);
       if (MODE == MODE_FWD) {
@@ -166,7 +244,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
     };
 
     load_chunk(s, tap, c0, choff);
-    store_chunk();
+    store_chunk(s, c0);
     __syncthreads();
     while (true) {
       // current chunk extent, then advance the iterator
@@ -178,6 +256,27 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       const bool more = s2 < p.nsrc;
       if (more) load_chunk(s2, tap2, c2, ch2);
 
+      if (PREC == PREC_B3) {
+        bf16x8 wh[CT], wl[CT], xh[PT], xl[PT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          wh[i] = *reinterpret_cast<const bf16x8*>(&Bh[(i * 16 + li) * RS + 8 * kq]);
+          wl[i] = *reinterpret_cast<const bf16x8*>(&Bl[(i * 16 + li) * RS + 8 * kq]);
+        }
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+          xh[j] = *reinterpret_cast<const bf16x8*>(&Ah[((wave * PT + j) * 16 + li) * RS + 8 * kq]);
+          xl[j] = *reinterpret_cast<const bf16x8*>(&Al[((wave * PT + j) * 16 + li) * RS + 8 * kq]);
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int j = 0; j < PT; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+          }
+      } else
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (u < nu) {
@@ -200,7 +299,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       __syncthreads();
       if (!more) break;
       s = s2; tap = tap2; c0 = c2; choff = ch2;
-      store_chunk();
+      store_chunk(s, c0);
       __syncthreads();
     }
 
@@ -290,14 +389,26 @@ int pick_ct(int Cn) {
 }
 int pick_pt(long P) { return P >= 128L * 512 ? 2 : 1; }
 
+// Precision of the dense contractions: exact fp32 MFMA by default (the parity path); the 3-term split-bf16 form
+// (~1.5e-5 relative per product) is opt-in through addk_set_conv_precision(1) or ADDK_MATH=bf16x3.
+int g_prec = -1;
+int conv_precision() {
+  if (g_prec < 0) { const char* e = getenv("ADDK_MATH"); g_prec = (e && e[0] == 'b') ? PREC_B3 : PREC_F32; }
+  return g_prec;
+}
+
 template <int MODE>
 int launch(ConvK& k, hipStream_t st) {
   const int ct = pick_ct(k.Cn), pt = pick_pt(k.P);
   const int BP = 64 * pt;
   k.ntiles = cdiv(k.P, BP);
   dim3 grid(k.ntiles < 1024 ? k.ntiles : 1024, cdiv(k.Cn, 16 * ct));
+  const int prec = conv_precision();
 #define ADDK_CASE(PT_, CT_) \
-  if (pt == PT_ && ct == CT_) { hipLaunchKernelGGL((conv_kernel<PT_, CT_, MODE>), grid, dim3(256), 0, st, k); return addk_check_launch("conv"); }
+  if (pt == PT_ && ct == CT_) { \
+    if (prec == PREC_B3) hipLaunchKernelGGL((conv_kernel<PT_, CT_, MODE, PREC_B3>), grid, dim3(256), 0, st, k); \
+    else hipLaunchKernelGGL((conv_kernel<PT_, CT_, MODE, PREC_F32>), grid, dim3(256), 0, st, k); \
+    return addk_check_launch("conv"); }
   ADDK_CASE(1, 2) ADDK_CASE(1, 3) ADDK_CASE(1, 4) ADDK_CASE(1, 5) ADDK_CASE(1, 8)
   ADDK_CASE(2, 2) ADDK_CASE(2, 3) ADDK_CASE(2, 4) ADDK_CASE(2, 5) ADDK_CASE(2, 8)
 #undef ADDK_CASE
@@ -315,6 +426,13 @@ __global__ void mfma_selftest_kernel(float* out) {
 }
 
 }  // namespace
+
+extern "C" int addk_set_conv_precision(int mode) {
+  if (mode != PREC_F32 && mode != PREC_B3) { addk_set_error("conv precision must be 0 (fp32) or 1 (bf16x3)"); return ADDK_ERR_INVALID; }
+  g_prec = mode;
+  return ADDK_OK;
+}
+extern "C" int addk_get_conv_precision(void) { return conv_precision(); }
 
 extern "C" int addk_selftest_mfma(float* out256, void* stream) {
   hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out256);

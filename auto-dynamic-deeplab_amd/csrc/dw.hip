@@ -121,36 +121,32 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
       }
     }
   }
-  // fixed-order block reduction over pixel lanes (deterministic)
-  for (int r = 0; r < p.npl; ++r) {
-    if (active && pl == r) {
+  // Block reduction over pixel lanes, deterministic and cheap: per tap every thread drops its float4 into an
+  // [npl][C4] LDS panel, then one thread per channel adds the npl rows in fixed order.
 #pragma unroll
-      for (int tp = 0; tp < NT; ++tp)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = get4(dwacc[tp], e);
-          float* d = &redt[(c + e) * NT + tp];
-          *d = (r == 0) ? v : *d + v;
-        }
+  for (int tp = 0; tp < NT; ++tp) {
+    if (active) *reinterpret_cast<float4*>(&redt[pl * C4 + c]) = dwacc[tp];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      float s = 0.f;
+      for (int r = 0; r < p.npl; ++r) s += redt[r * C4 + ch];
+      p.ws[((long)blockIdx.x * C + ch) * NT + tp] = s;
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < C * NT; i += 256) p.ws[(long)blockIdx.x * C * NT + i] = redt[i];
-  __syncthreads();
   if (p.dab) {
-    double* redd = reinterpret_cast<double*>(redt);      // [C4][2] doubles fit in the [C4][NT] float tile (NT >= 4)
-    for (int r = 0; r < p.npl; ++r) {
-      if (active && pl == r) {
+    double* redd = reinterpret_cast<double*>(redt);      // [npl][C4][2] doubles
+    if (active) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          double* d = &redd[(c + e) * 2];
-          d[0] = (r == 0) ? sA[e] : d[0] + sA[e];
-          d[1] = (r == 0) ? sB[e] : d[1] + sB[e];
-        }
-      }
-      __syncthreads();
+      for (int e = 0; e < 4; ++e) { redd[((pl * C4) + c + e) * 2] = sA[e]; redd[((pl * C4) + c + e) * 2 + 1] = sB[e]; }
     }
-    for (int i = threadIdx.x; i < C * 2; i += 256) p.dab[(long)blockIdx.x * C * 2 + i] = redd[i];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      double a = 0.0, b = 0.0;
+      for (int r = 0; r < p.npl; ++r) { a += redd[(r * C4 + ch) * 2]; b += redd[(r * C4 + ch) * 2 + 1]; }
+      p.dab[((long)blockIdx.x * C + ch) * 2] = a;
+      p.dab[((long)blockIdx.x * C + ch) * 2 + 1] = b;
+    }
   }
 }
 
@@ -213,7 +209,7 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
   k.vec = src_vec_ok(a->src) && aligned16(a->dy) && a->lddy % 4 == 0 && (!a->g || (aligned16(a->g) && a->ldg % 4 == 0));
   const int taps = a->KH * a->KW, C4 = k.nq * 4;
   const int rows = dw_rows(k.P, a->src.C);
-  size_t sh = (size_t)(taps * C4 + C4 * (taps > 4 ? taps : 4)) * sizeof(float);
+  size_t sh = (size_t)(taps * C4 + k.npl * C4 * 4) * sizeof(float);     // tap weights + [npl][C4] reduction panel (fp64 pairs)
   hipStream_t st = (hipStream_t)stream;
   if (taps == 9) hipLaunchKernelGGL(dw_bwd_kernel<9>, dim3(rows), dim3(256), sh, st, k);
   else if (taps == 25) hipLaunchKernelGGL(dw_bwd_kernel<25>, dim3(rows), dim3(256), sh, st, k);

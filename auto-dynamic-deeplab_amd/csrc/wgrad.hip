@@ -63,7 +63,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
     for (int j = 0; j < CTZ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float4 ry[NYJ], rz[NZJ];
+  unsigned zmask = 0;
   auto load_step = [&](int p0) {
+    zmask = 0;
 #pragma unroll
     for (int j = 0; j < NYJ; ++j) {
       int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
@@ -85,10 +87,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
           const float* xp = p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + c;
           const int nrem = p.src.C - c;
           v = ld4g(xp, nrem, p.vecZ);
-          v.x = fmaf(za[j].x, v.x, zb[j].x); v.y = fmaf(za[j].y, v.y, zb[j].y);
-          v.z = fmaf(za[j].z, v.z, zb[j].z); v.w = fmaf(za[j].w, v.w, zb[j].w);
-          if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
+          zmask |= 1u << j;
         }
       }
       rz[j] = v;
@@ -103,7 +102,15 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
 #pragma unroll
     for (int j = 0; j < NZJ; ++j) {
       int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
-      if (row < KP) st4(&Zs[row * LZ + 4 * q], rz[j]);
+      float4 v = rz[j];
+      if (zmask & (1u << j)) {      // lazy prologue, applied after the MFMAs of the previous step
+        const int nrem = p.src.C - (c0 + 4 * q);
+        v.x = fmaf(za[j].x, v.x, zb[j].x); v.y = fmaf(za[j].y, v.y, zb[j].y);
+        v.z = fmaf(za[j].z, v.z, zb[j].z); v.w = fmaf(za[j].w, v.w, zb[j].w);
+        if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
+      }
+      if (row < KP) st4(&Zs[row * LZ + 4 * q], v);
     }
   };
 
@@ -175,6 +182,23 @@ __global__ void wgrad_reduce_kernel(const float* ws, int splits, int Cout, int t
   }
 }
 
+// many slices, few elements: one wave per element, lanes stride over the slices, fixed-order butterfly
+__global__ void __launch_bounds__(256) wgrad_reduce_wave_kernel(const float* ws, int splits, int Cout, int taps, int C, float* dw, int ldw,
+                                                                int cin_total, int w_choff, int accumulate) {
+  const long n = (long)Cout * taps * C;
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < splits; k += 64) s += ws[(long)k * n + i];
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) {
+    int c = (int)(i % C); long r = i / C; int tap = (int)(r % taps); int co = (int)(r / taps);
+    float* d = dw + (long)co * ldw + (long)tap * cin_total + w_choff + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
 int pick_cty(int Cout) {
   const int cands[5] = {8, 5, 4, 3, 2};
   int best = 2; long bc = -1;
@@ -192,11 +216,11 @@ void pick_tiles(int Cout, int C, int* cty, int* ctz) {
   if (*cty == 8 && *ctz == 5) *ctz = 4;   // 8x5 accumulator tiles would not leave room for the staging registers
 }
 int pick_splits(long P, int tiles) {
-  long maxs = cdiv(P, 4 * KP);            // at least 4 staged steps per block
-  long want = cdiv(1024, tiles);
+  long maxs = cdiv(P, 2 * KP);            // at least 2 staged steps per block
+  long want = cdiv(1536, tiles);          // ~6 resident blocks per CU keep enough loads in flight for the HBM-bound shapes
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
-  if (s > 32) s = 32;
+  if (s > 1024) s = 1024;
   return (int)s;
 }
 
@@ -244,8 +268,13 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   int rc = addk_check_launch("conv_wgrad");
   if (rc) return rc;
   long n = (long)a->Cout * k.taps * a->src.C;
-  int rb = cdiv(n, 256); if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, a->ws, k.splits, a->Cout, k.taps, a->src.C,
-                     a->dw, a->ldw, a->cin_total, a->w_choff, a->accumulate);
+  if (k.splits > 16 && n <= 65536) {
+    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, a->ws, k.splits, a->Cout, k.taps, a->src.C,
+                       a->dw, a->ldw, a->cin_total, a->w_choff, a->accumulate);
+  } else {
+    int rb = cdiv(n, 256); if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, a->ws, k.splits, a->Cout, k.taps, a->src.C,
+                       a->dw, a->ldw, a->cin_total, a->w_choff, a->accumulate);
+  }
   return addk_check_launch("conv_wgrad_reduce");
 }

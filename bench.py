@@ -48,7 +48,7 @@ def cpu_baseline(genotype, n, h, w):
     ~14 s per step on 8 cores).  Runs in a child process with a time limit; if the full-size step does not finish
     the sample is shrunk to a quarter-size image and scaled by pixel count (said so in `sample`)."""
     import subprocess
-    for hh, ww, limit in ((h, w, 150), (h // 2, w // 2, 90)):
+    for hh, ww, limit in ((h // 2, w // 2, 100), (h // 4, w // 4, 60)):
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--batch', str(n), '--height', str(hh),
                                 '--width', str(ww)], capture_output=True, text=True, timeout=limit)
@@ -60,6 +60,7 @@ def cpu_baseline(genotype, n, h, w):
                     d['sample'] += ' (scaled by pixel count to %dx%d)' % (h, w)
                 return d
         except subprocess.TimeoutExpired:
+            sys.stderr.write('[bench] cpu baseline at %dx%d exceeded %ds\n' % (hh, ww, limit))
             continue
     return {'value': None, 'unit': 'images/sec', 'cores': None, 'kind': 'port', 'sample': 'cpu baseline did not finish in time'}
 
@@ -68,6 +69,7 @@ def _cpu_baseline_child(genotype, n, h, w):
     import oracle
     torch.manual_seed(1)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    cores = max(1, min(cores, 16))          # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(cores)
     m = oracle.ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(), 0)
     m.train()
@@ -111,6 +113,7 @@ def main():
     ap.add_argument('--F', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--math', choices=['fp32', 'bf16x3'], default='fp32', help='dense-conv arithmetic (default: exact fp32 MFMA)')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_child:
@@ -128,6 +131,7 @@ def main():
     from addk.modeling.ADD import ADD
     from addk.train import TrainStep
     from addk import parallel
+    addk.set_precision(a.math)
     comm = None
     if world > 1:
         import torch.distributed as dist
@@ -178,7 +182,7 @@ def main():
             'algorithmic_bytes_per_launch': top['bytes']}
     out = {'metric': 'Cityscapes 1024x2048 images/sec fwd+bwd @ bs=2/GPU', 'value': value, 'unit': 'images/sec',
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.math == 'fp32' else 'f32 storage, split-bf16 (3-term) MFMA products, f32 accumulate', 'data': 'synthetic',
            'config': {'workload': 'ADD F=%d searched_arch/autodeeplab C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, h, w, n),
                       'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': world > 1,
                       'hip_graph': bool(ts.graph is not None)},

@@ -86,6 +86,11 @@ typedef struct addk_conv_args {
   int32_t _pad;
 } addk_conv_args;
 int addk_conv_fwd(const addk_conv_args* a, void* stream);
+/* Arithmetic of the dense contractions (fwd and dgrad): 0 = exact fp32 products on v_mfma_f32_16x16x4_f32 (default,
+ * the parity path); 1 = split-bf16: x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with
+ * fp32 accumulation (~1.5e-5 relative per product).  Process-wide; also ADDK_MATH=bf16x3 in the environment. */
+int addk_set_conv_precision(int mode);
+int addk_get_conv_precision(void);
 /* number of partial-statistics rows a launch with these shapes writes (<= 1024) */
 int addk_conv_rows(int64_t P, int32_t Cout);
 
