@@ -11,11 +11,21 @@ namespace {
 __device__ __forceinline__ void slab_sum(const double* slab, int rows, int C, int c, int rg, double& s0, double& s1,
                                          double (*sh)[32][2]) {
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int r = rg; r < rows; r += 32) {
-      const double* v = slab + ((long)r * C + c) * 2;
-      a += v[0]; b += v[1];
+  if (c < C) {
+    // independent 16-B loads: unroll so several are in flight per thread
+    int r = rg;
+    for (; r + 96 < rows; r += 128) {
+      const double2 v0 = *reinterpret_cast<const double2*>(slab + ((long)r * C + c) * 2);
+      const double2 v1 = *reinterpret_cast<const double2*>(slab + ((long)(r + 32) * C + c) * 2);
+      const double2 v2 = *reinterpret_cast<const double2*>(slab + ((long)(r + 64) * C + c) * 2);
+      const double2 v3 = *reinterpret_cast<const double2*>(slab + ((long)(r + 96) * C + c) * 2);
+      a += (v0.x + v1.x) + (v2.x + v3.x); b += (v0.y + v1.y) + (v2.y + v3.y);
     }
+    for (; r < rows; r += 32) {
+      const double2 v = *reinterpret_cast<const double2*>(slab + ((long)r * C + c) * 2);
+      a += v.x; b += v.y;
+    }
+  }
   const int cl = threadIdx.x & 31;
   sh[rg][cl][0] = a; sh[rg][cl][1] = b;
   __syncthreads();

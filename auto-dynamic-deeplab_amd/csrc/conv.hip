@@ -84,17 +84,18 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   const int n0 = blockIdx.y * BC;
   const int aq = t & 7, ar = t >> 3;
   const int ntaps = p.KH * p.KW;
-  const long ohw = (long)p.OH * p.OW;
+  const int ohw = p.OH * p.OW;
+  const int P32 = (int)p.P;
   double tot0 = 0.0, tot1 = 0.0;
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int rn[NAJ], rh[NAJ], rw[NAJ];
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) {
-      long pp = (long)tile * BP + ar + 32 * j;
-      if (pp < p.P) {
-        int n = (int)(pp / ohw);
-        int rem = (int)(pp - (long)n * ohw);
+      int pp = tile * BP + ar + 32 * j;
+      if (pp < P32) {
+        int n = pp / ohw;
+        int rem = pp - n * ohw;
         int oh = rem / p.OW, ow = rem - oh * p.OW;
         rn[j] = n;
         if (MODE == MODE_FWD) { rh[j] = oh * p.stride - p.pad; rw[j] = ow * p.stride - p.pad; }
@@ -312,18 +313,18 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
-        const long pp = (long)tile * BP + (wave * PT + j) * 16 + li;
-        const bool pv = pp < p.P && nrem > 0;
+        const int pp = tile * BP + (wave * PT + j) * 16 + li;
+        const bool pv = pp < P32 && nrem > 0;
         float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         if (MODE == MODE_FWD) {
           if (pv) {
             if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
             if (p.bias_n) {
-              int n = (int)(pp / ohw);
+              int n = pp / ohw;
               float4 b = ld4g(p.bias_n + (long)n * p.Cn + c, nrem, false);
               v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
             }
-            st4g(p.y + pp * p.ldy + c, v, nrem, p.vecY);
+            st4g(p.y + (long)pp * p.ldy + c, v, nrem, p.vecY);
             if (want_red) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
           }
         } else {
           if (pv) {
-            float4 x = ld4g(p.dst.x + pp * p.dst.ld + c, nrem, p.vecY);
+            float4 x = ld4g(p.dst.x + (long)pp * p.dst.ld + c, nrem, p.vecY);
             float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
             if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, p.vecY); bv = ld4g(p.dst.b + c, nrem, p.vecY); }
             float4 g;
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
               set4(g, e, m ? dz * ae : 0.f);
               if (want_red && m) { s1[e] += (double)dz * (double)xe; s2v[e] += (double)dz; }
             }
-            float* gp = p.y + pp * p.ldy + c;
+            float* gp = p.y + (long)pp * p.ldy + c;
             if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vecY); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
             st4g(gp, g, nrem, p.vecY);
           }
@@ -476,6 +477,7 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
   k.vecB = aligned16(a->w) && a->ldw % 4 == 0 && a->cin_total % 4 == 0 && a->w_choff % 4 == 0 && chan4;
   k.vecY = aligned16(a->y) && a->ldy % 4 == 0;
   k.P = (long)a->N * a->OH * a->OW;
+  ADDK_REQUIRE(k.P < (1L << 30) && (long)a->N * a->H * a->W < (1L << 30), "conv_fwd: tensor too large for 32-bit pixel indexing");
   return launch<MODE_FWD>(k, (hipStream_t)stream);
 }
 
@@ -498,5 +500,6 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
   k.vecB = aligned16(a->w) && a->ldw % 4 == 0 && a->cin_total % 4 == 0 && a->w_choff % 4 == 0 && a->dst.C % 4 == 0;
   k.vecY = aligned16(a->g) && a->ldg % 4 == 0 && src_vec_ok(a->dst);
   k.P = (long)a->N * a->H * a->W;
+  ADDK_REQUIRE(k.P < (1L << 30) && (long)a->N * a->OH * a->OW < (1L << 30), "conv_dgrad: tensor too large for 32-bit pixel indexing");
   return launch<MODE_DGRAD>(k, (hipStream_t)stream);
 }

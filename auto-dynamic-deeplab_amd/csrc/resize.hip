@@ -142,15 +142,39 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
         }
       } else {
         float4 dz = zero4();
-        for (int oh = hlo; oh <= hhi; ++oh) {
-          float wh = tap_weight(oh, ih, sh, p.H);
-          if (wh == 0.f) continue;
-          for (int ow = wlo; ow <= whi; ++ow) {
-            float ww = tap_weight(ow, iw, sw, p.W);
-            if (ww == 0.f) continue;
-            float4 d = ld4g(p.dy + ((long)(n * p.OH + oh) * p.OW + ow) * p.lddy + c, nrem, p.vec);
-            float k = wh * ww;
-            dz.x = fmaf(k, d.x, dz.x); dz.y = fmaf(k, d.y, dz.y); dz.z = fmaf(k, d.z, dz.z); dz.w = fmaf(k, d.w, dz.w);
+        const int nh = hhi - hlo + 1, nw = whi - wlo + 1;
+        if (nh <= 8 && nw <= 8) {
+          // up to x2 up-sampling: per-axis weights in registers (static indexing), then at most 8x8 taps
+          float wh8[8], ww8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            wh8[k] = k < nh ? tap_weight(hlo + k, ih, sh, p.H) : 0.f;
+            ww8[k] = k < nw ? tap_weight(wlo + k, iw, sw, p.W) : 0.f;
+          }
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            if (wh8[a] != 0.f) {
+#pragma unroll
+              for (int b = 0; b < 8; ++b) {
+                if (ww8[b] != 0.f) {
+                  float4 d = ld4g(p.dy + ((long)(n * p.OH + hlo + a) * p.OW + wlo + b) * p.lddy + c, nrem, p.vec);
+                  float k = wh8[a] * ww8[b];
+                  dz.x = fmaf(k, d.x, dz.x); dz.y = fmaf(k, d.y, dz.y); dz.z = fmaf(k, d.z, dz.z); dz.w = fmaf(k, d.w, dz.w);
+                }
+              }
+            }
+          }
+        } else {
+          for (int oh = hlo; oh <= hhi; ++oh) {
+            float wh = tap_weight(oh, ih, sh, p.H);
+            if (wh == 0.f) continue;
+            for (int ow = wlo; ow <= whi; ++ow) {
+              float ww = tap_weight(ow, iw, sw, p.W);
+              if (ww == 0.f) continue;
+              float4 d = ld4g(p.dy + ((long)(n * p.OH + oh) * p.OW + ow) * p.lddy + c, nrem, p.vec);
+              float k = wh * ww;
+              dz.x = fmaf(k, d.x, dz.x); dz.y = fmaf(k, d.y, dz.y); dz.z = fmaf(k, d.z, dz.z); dz.w = fmaf(k, d.w, dz.w);
+            }
           }
         }
         dz.x *= gs; dz.y *= gs; dz.z *= gs; dz.w *= gs;

@@ -165,6 +165,134 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
   }
 }
 
+// Output-split variant for the 256-wide heads (ASPP / decoder): the four waves form a 2x2 grid over a
+// (32*TY) x (32*TZ) output tile, every wave walks ALL staged pixels and owns a TYxTZ block of 16x16 accumulators
+// (32-64 VGPRs instead of the 128 of the pixel-split form), so 2-3 blocks fit a CU and staging overlaps the MFMAs;
+// no cross-wave reduction is needed.
+template <int TY, int TZ>
+__global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK p) {
+  constexpr int BCY = 32 * TY, BCZ = 32 * TZ;
+  constexpr int LY = ldpad(BCY), LZ = ldpad(BCZ);
+  constexpr int NYJ = (KP * BCY / 4 + 255) / 256;
+  constexpr int NZJ = (KP * BCZ / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[KP * LY + KP * LZ];
+  float* Ys = lds;
+  float* Zs = lds + KP * LY;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int wy = wave >> 1, wz = wave & 1;
+  int bx = blockIdx.x;
+  const int zt = bx % p.nzt; bx /= p.nzt;
+  const int tap = bx % p.taps; const int yt = bx / p.taps;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int co0 = yt * BCY, c0 = zt * BCZ;
+  const int ohw = p.OH * p.OW;
+  const int pbeg = blockIdx.y * p.chunkP;
+  int pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
+  float4 za[NZJ], zb[NZJ];
+#pragma unroll
+  for (int j = 0; j < NZJ; ++j) {
+    int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
+    int c = c0 + 4 * q;
+    za[j] = make_float4(1.f, 1.f, 1.f, 1.f); zb[j] = zero4();
+    if (p.src.a && row < KP && c < p.src.C) { za[j] = ld4g(p.src.a + c, p.src.C - c, p.vecZ); zb[j] = ld4g(p.src.b + c, p.src.C - c, p.vecZ); }
+  }
+  const bool zrelu = p.src.relu != 0;
+
+  f32x4 acc[TY][TZ];
+#pragma unroll
+  for (int i = 0; i < TY; ++i)
+#pragma unroll
+    for (int j = 0; j < TZ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ry[NYJ], rz[NZJ];
+  unsigned zmask = 0;
+  auto load_step = [&](int p0) {
+    zmask = 0;
+#pragma unroll
+    for (int j = 0; j < NYJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
+      int pp = p0 + row; int co = co0 + 4 * q;
+      float4 v = zero4();
+      if (row < KP && pp < pend && co < p.Cout) v = ld4g(p.dy + (long)pp * p.lddy + co, p.Cout - co, p.vecY);
+      ry[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NZJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
+      int pp = p0 + row; int c = c0 + 4 * q;
+      float4 v = zero4();
+      if (row < KP && pp < pend && c < p.src.C) {
+        int n = pp / ohw; int rem = pp - n * ohw;
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        int ih = oh * p.stride - p.pad + kh * p.dil, iw = ow * p.stride - p.pad + kw * p.dil;
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+          v = ld4g(p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + c, p.src.C - c, p.vecZ);
+          zmask |= 1u << j;
+        }
+      }
+      rz[j] = v;
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int j = 0; j < NYJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
+      if (row < KP) st4(&Ys[row * LY + 4 * q], ry[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NZJ; ++j) {
+      int slot = t + 256 * j, row = slot / (BCZ / 4), q = slot - row * (BCZ / 4);
+      float4 v = rz[j];
+      if (zmask & (1u << j)) {
+        const int nrem = p.src.C - (c0 + 4 * q);
+        v.x = fmaf(za[j].x, v.x, zb[j].x); v.y = fmaf(za[j].y, v.y, zb[j].y);
+        v.z = fmaf(za[j].z, v.z, zb[j].z); v.w = fmaf(za[j].w, v.w, zb[j].w);
+        if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
+      }
+      if (row < KP) st4(&Zs[row * LZ + 4 * q], v);
+    }
+  };
+
+  if (pbeg < pend) {
+    load_step(pbeg);
+    store_step();
+    __syncthreads();
+    for (int p0 = pbeg; p0 < pend; p0 += KP) {
+      const bool more = p0 + KP < pend;
+      if (more) load_step(p0 + KP);
+#pragma unroll 4
+      for (int ks = 0; ks < KP / 4; ++ks) {
+        const int px = ks * 4 + kq;
+        float yf[TY], zf[TZ];
+#pragma unroll
+        for (int i = 0; i < TY; ++i) yf[i] = Ys[px * LY + (wy * TY + i) * 16 + li];
+#pragma unroll
+        for (int j = 0; j < TZ; ++j) zf[j] = Zs[px * LZ + (wz * TZ + j) * 16 + li];
+#pragma unroll
+        for (int i = 0; i < TY; ++i)
+#pragma unroll
+          for (int j = 0; j < TZ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[i], zf[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) { store_step(); __syncthreads(); }
+    }
+  }
+  const int C = p.src.C;
+  float* wsb = p.ws + (long)blockIdx.y * p.Cout * p.taps * C;
+#pragma unroll
+  for (int i = 0; i < TY; ++i)
+#pragma unroll
+    for (int j = 0; j < TZ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int co = co0 + (wy * TY + i) * 16 + kq * 4 + r, c = c0 + (wz * TZ + j) * 16 + li;
+        if (co < p.Cout && c < C) wsb[((long)co * p.taps + tap) * C + c] = acc[i][j][r];
+      }
+}
+
 __global__ void wgrad_reduce_kernel(const float* ws, int splits, int Cout, int taps, int C, float* dw, int ldw,
                                     int cin_total, int w_choff, int accumulate) {
   long n = (long)Cout * taps * C;
@@ -214,7 +342,11 @@ int pick_ctz(int C) {
 void pick_tiles(int Cout, int C, int* cty, int* ctz) {
   *cty = pick_cty(Cout); *ctz = pick_ctz(C);
   if (*cty == 8 && *ctz == 5) *ctz = 4;   // 8x5 accumulator tiles would not leave room for the staging registers
+  if (Cout >= 128 && Cout % 128 == 0 && C >= 48) {   // wide heads: output-split kernel, 128 x 64 tiles
+    *cty = 8; *ctz = 4;
+  }
 }
+bool use_output_split(int Cout, int C) { return Cout >= 128 && Cout % 128 == 0 && C >= 48; }
 int pick_splits(long P, int tiles) {
   long maxs = cdiv(P, 2 * KP);            // at least 2 staged steps per block
   long want = cdiv(1536, tiles);          // ~6 resident blocks per CU keep enough loads in flight for the HBM-bound shapes
@@ -256,6 +388,10 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   dim3 grid(tiles, k.splits);
   hipStream_t st = (hipStream_t)stream;
   bool done = false;
+  if (use_output_split(a->Cout, a->src.C)) {
+    hipLaunchKernelGGL((wgrad_os_kernel<4, 2>), grid, dim3(256), 0, st, k);
+    done = true;
+  }
 #define ADDK_CASE(Y_, Z_) \
   if (!done && cty == Y_ && ctz == Z_) { hipLaunchKernelGGL((wgrad_kernel<Y_, Z_>), grid, dim3(256), 0, st, k); done = true; }
   ADDK_CASE(2, 1) ADDK_CASE(2, 3) ADDK_CASE(2, 4) ADDK_CASE(2, 5)
