@@ -377,14 +377,22 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   }
 }
 
-int pick_ct(int Cn) {
-  // smallest padding first, larger tiles on ties (fewer re-reads of the pixel tile)
+int pick_ct(int Cn, long ntiles) {
+  // smallest padding first, larger tiles on ties (fewer re-reads of the pixel tile) ...
   const int cands[5] = {8, 5, 4, 3, 2};
   int best = 2; long best_cost = -1;
   for (int k = 0; k < 5; ++k) {
     int ct = cands[k];
     long cols = (long)cdiv(Cn, 16 * ct) * 16 * ct;
     if (best_cost < 0 || cols < best_cost) { best_cost = cols; best = ct; }
+  }
+  // ... but a launch needs a few hundred workgroups to fill 256 CUs: on the small maps (levels 2-3) trade up to 25 %
+  // channel padding for more, narrower column blocks (the pixel tile is re-read from L2, not HBM)
+  for (int k = 0; k < 5 && ntiles * cdiv(Cn, 16 * best) < 512; ++k) {
+    int ct = cands[k];
+    if (ct >= best) continue;
+    long cols = (long)cdiv(Cn, 16 * ct) * 16 * ct;
+    if (cols * 4 <= best_cost * 5 && ntiles * cdiv(Cn, 16 * ct) > ntiles * cdiv(Cn, 16 * best)) best = ct;
   }
   return best;
 }
@@ -400,9 +408,10 @@ int conv_precision() {
 
 template <int MODE>
 int launch(ConvK& k, hipStream_t st) {
-  const int ct = pick_ct(k.Cn), pt = pick_pt(k.P);
+  const int pt = pick_pt(k.P);
   const int BP = 64 * pt;
   k.ntiles = cdiv(k.P, BP);
+  const int ct = pick_ct(k.Cn, k.ntiles);
   dim3 grid(k.ntiles < 1024 ? k.ntiles : 1024, cdiv(k.Cn, 16 * ct));
   const int prec = conv_precision();
 #define ADDK_CASE(PT_, CT_) \

@@ -163,9 +163,9 @@ __global__ void __launch_bounds__(256) dw_wreduce_kernel(const float* ws, int ro
 
 int dw_rows(long P, int C) {
   EwMap m = ew_map(C);
-  long r = P / ((long)m.npl * 8);
+  long r = P / ((long)m.npl * 2);      // >= 4 resident blocks per CU on the level-1 maps
   if (r < 1) r = 1;
-  if (r > 512) r = 512;
+  if (r > 1024) r = 1024;
   return (int)r;
 }
 
@@ -191,7 +191,7 @@ extern "C" int addk_dw_fwd(const addk_dw_args* a, void* stream) {
   k.w = a->w; k.y = a->y; k.ldy = a->ldy;
   k.P = (long)a->N * a->OH * a->OW;
   k.vec = src_vec_ok(a->src) && aligned16(a->y) && a->ldy % 4 == 0;
-  long blocks = cdiv(k.P, k.npl * 4); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  long blocks = cdiv(k.P, k.npl); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
   size_t sh = (size_t)a->KH * a->KW * k.nq * 4 * sizeof(float);
   hipLaunchKernelGGL(dw_fwd_kernel, dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, k);
   return addk_check_launch("dw_fwd");

@@ -147,16 +147,16 @@ __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, const f
 }
 
 int ew_blocks(long P, int npl) {
-  long b = cdiv(P, (long)npl * 4);
+  long b = cdiv(P, (long)npl);
   if (b < 1) b = 1;
-  if (b > 2048) b = 2048;
+  if (b > 8192) b = 8192;
   return (int)b;
 }
 int ew_rows(long P, int C) {
   EwMap m = ew_map(C);
-  long r = P / ((long)m.npl * 8);
+  long r = P / ((long)m.npl * 2);
   if (r < 1) r = 1;
-  if (r > 512) r = 512;
+  if (r > 1024) r = 1024;
   return (int)r;
 }
 

@@ -35,14 +35,16 @@ __global__ void __launch_bounds__(256) gap_partial_kernel(const GapK p) {
   for (int i = threadIdx.x; i < C; i += 256) p.ws[((long)n * p.rows + r) * C + i] = redt[i];
 }
 
-__global__ void gap_final_kernel(const float* ws, int N, int rows, int C, float inv, float* y, int ldy) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N * C) {
-    int n = i / C, c = i - n * C;
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += ws[((long)n * rows + r) * C + c];
-    y[(long)n * ldy + c] = (float)(s * inv);
-  }
+// one wave per (image, channel): lanes stride over the partial rows, fixed-order butterfly
+__global__ void __launch_bounds__(256) gap_final_kernel(const float* ws, int N, int rows, int C, float inv, float* y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double s = 0.0;
+  for (int r = lane; r < rows; r += 64) s += ws[((long)n * rows + r) * C + c];
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) y[(long)n * ldy + c] = (float)(s * inv);
 }
 
 __global__ void __launch_bounds__(256) gap_bwd_kernel(const GapK p) {
@@ -222,9 +224,9 @@ __global__ void __launch_bounds__(256) nchw_grad_kernel(const float* dy, const a
 
 int rows_for(long P, int C) {
   EwMap m = ew_map(C);
-  long r = P / ((long)m.npl * 8);
+  long r = P / ((long)m.npl * 2);
   if (r < 1) r = 1;
-  if (r > 512) r = 512;
+  if (r > 1024) r = 1024;
   return (int)r;
 }
 
@@ -241,7 +243,7 @@ extern "C" int addk_gap_fwd(const addk_src* src, int32_t N, int32_t HW, float* y
   hipLaunchKernelGGL(gap_partial_kernel, dim3(k.rows, N), dim3(256), (size_t)m.nq * 4 * sizeof(float), st, k);
   int rc = addk_check_launch("gap_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(gap_final_kernel, dim3(cdiv((long)N * src->C, 256)), dim3(256), 0, st, ws, N, k.rows, src->C, mean ? 1.f / (float)HW : 1.f, y, ldy);
+  hipLaunchKernelGGL(gap_final_kernel, dim3(cdiv((long)N * src->C, 4)), dim3(256), 0, st, ws, N, k.rows, src->C, mean ? 1.f / (float)HW : 1.f, y, ldy);
   return addk_check_launch("gap_final");
 }
 

@@ -214,9 +214,9 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
 
 int rs_rows(long P, int C) {
   EwMap m = ew_map(C);
-  long r = P / ((long)m.npl * 8);
+  long r = P / ((long)m.npl * 2);
   if (r < 1) r = 1;
-  if (r > 512) r = 512;
+  if (r > 1024) r = 1024;
   return (int)r;
 }
 
@@ -237,7 +237,7 @@ extern "C" int addk_resize_fwd(const addk_resize_args* a, void* stream) {
     ADDK_REQUIRE(a->ldy >= a->src.C, "resize_fwd: short ldy");
     EwMap m = ew_map(a->src.C); k.nq = m.nq; k.npl = m.npl;
     k.vec = src_vec_ok(a->src) && aligned16(a->y) && a->ldy % 4 == 0;
-    long b = cdiv(k.P, (long)m.npl * 2); if (b > 4096) b = 4096; if (b < 1) b = 1;
+    long b = cdiv(k.P, (long)m.npl); if (b > 8192) b = 8192; if (b < 1) b = 1;
     hipLaunchKernelGGL(resize_fwd_kernel, dim3((unsigned)b), dim3(256), 0, st, k);
   }
   return addk_check_launch("resize_fwd");

@@ -348,7 +348,7 @@ void pick_tiles(int Cout, int C, int* cty, int* ctz) {
 }
 bool use_output_split(int Cout, int C) { return Cout >= 128 && Cout % 128 == 0 && C >= 48; }
 int pick_splits(long P, int tiles) {
-  long maxs = cdiv(P, 2 * KP);            // at least 2 staged steps per block
+  long maxs = cdiv(P, KP);                // at least one staged step per block
   long want = cdiv(1536, tiles);          // ~6 resident blocks per CU keep enough loads in flight for the HBM-bound shapes
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
