@@ -93,6 +93,9 @@ _SIGS = {
     'addk_conv_dgrad': (i32, [C.POINTER(ConvDgradArgs), vp]),
     'addk_conv_wgrad': (i32, [C.POINTER(ConvWgradArgs), vp]),
     'addk_conv_wgrad_ws': (i64, [i64, i32, i32, i32]),
+    'addk_conv_wgrad_config': (i32, [C.POINTER(ConvWgradArgs), C.POINTER(i32)]),
+    'addk_conv_wgrad_batch_prepare': (i64, [C.POINTER(ConvWgradArgs), i32, vp, i64, C.POINTER(i64)]),
+    'addk_conv_wgrad_batch_run': (i32, [vp, C.POINTER(i64), vp]),
     'addk_dw_fwd': (i32, [C.POINTER(DwArgs), vp]),
     'addk_dw_bwd': (i32, [C.POINTER(DwBwdArgs), vp]),
     'addk_dw_rows': (i32, [i64, i32]),

@@ -87,9 +87,23 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   const int ohw = p.OH * p.OW;
   const int P32 = (int)p.P;
   double tot0 = 0.0, tot1 = 0.0;
+  // per-slot weight offsets (fixed for the whole kernel); -1 marks a slot outside the tile
+  long woff[NBJ];
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    const int slot = t + 256 * j;
+    if (MODE == MODE_FWD) {
+      const int row = slot >> 3, q = slot & 7, co = n0 + row;
+      woff[j] = (row < BC && co < p.Cn) ? (long)co * p.ldw + 4 * q : -1;
+    } else {
+      const int k = slot / (4 * CT), ng = slot - k * (4 * CT), ci = n0 + 4 * ng;
+      woff[j] = (k < BK && ci < p.Cn) ? (long)k * p.ldw + ci : -1;
+    }
+  }
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int rn[NAJ], rh[NAJ], rw[NAJ];
+    long roff[NAJ];              // element offset of (n, rh, rw) in a source with pixel stride 1 (scaled by S.ld per chunk)
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) {
       int pp = tile * BP + ar + 32 * j;
@@ -100,7 +114,8 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
         rn[j] = n;
         if (MODE == MODE_FWD) { rh[j] = oh * p.stride - p.pad; rw[j] = ow * p.stride - p.pad; }
         else                  { rh[j] = oh + p.pad;            rw[j] = ow + p.pad; }
-      } else { rn[j] = -1; rh[j] = 0; rw[j] = 0; }
+        roff[j] = ((long)n * p.H + rh[j]) * p.W + rw[j];
+      } else { rn[j] = -1; rh[j] = 0; rw[j] = 0; roff[j] = 0; }
     }
 
     f32x4 acc[CT][PT];
@@ -119,53 +134,53 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       const int c = c0_ + 4 * aq;
       const int nrem = S.C - c;          // valid channels from c on
       amask = 0;
+      const int dh = kh * p.dil, dw = kw * p.dil;
+      // wave-uniform pixel offset of this tap relative to the row base (fwd: +tap, stride-1 dgrad: -tap)
+      const long tapoff = (MODE == MODE_FWD) ? ((long)dh * p.W + dw) : -((long)dh * p.W + dw);
+      const float* sbase = S.x + c;
 #pragma unroll
       for (int j = 0; j < NAJ; ++j) {
         float4 v = zero4();
         if (rn[j] >= 0 && nrem > 0) {
-          int ih, iw; bool ok;
+          bool ok; long poff;
           if (MODE == MODE_FWD) {
-            ih = rh[j] + kh * p.dil; iw = rw[j] + kw * p.dil;
+            const int ih = rh[j] + dh, iw = rw[j] + dw;
             ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            poff = roff[j] + tapoff;
+          } else if (p.stride == 1) {
+            const int ih = rh[j] - dh, iw = rw[j] - dw;
+            ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            poff = roff[j] + tapoff;
           } else {
-            int th = rh[j] - kh * p.dil, tw = rw[j] - kw * p.dil;
-            ok = th >= 0 && tw >= 0;
-            if (p.stride > 1) {
-              ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
-              ih = th / p.stride; iw = tw / p.stride;
-            } else { ih = th; iw = tw; }
+            const int th = rh[j] - dh, tw = rw[j] - dw;
+            ok = th >= 0 && tw >= 0 && (th % p.stride == 0) && (tw % p.stride == 0);
+            const int ih = th / p.stride, iw = tw / p.stride;
             ok = ok && ih < p.H && iw < p.W;
+            poff = ((long)rn[j] * p.H + ih) * p.W + iw;
           }
           if (ok) {
-            const float* src = S.x + ((long)(rn[j] * p.H + ih) * p.W + iw) * S.ld + c;
-            v = ld4g(src, nrem, p.vecA);
+            v = ld4g(sbase + poff * S.ld, nrem, p.vecA);
             amask |= 1u << j;
           }
         }
         ra[j] = v;
       }
       if (MODE == MODE_FWD) {
+        const float* wb = p.w + ((long)tap_ * p.cin_total + p.w_choff + choff_ + c0_);      // wave-uniform
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
-          int slot = t + 256 * j, row = slot >> 3, q = slot & 7;
-          int cc = c0_ + 4 * q, co = n0 + row;
+          const int cc = c0_ + 4 * ((t + 256 * j) & 7);
           float4 v = zero4();
-          if (row < BC && co < p.Cn && cc < S.C) {
-            const float* wp = p.w + (long)co * p.ldw + (long)tap_ * p.cin_total + p.w_choff + choff_ + cc;
-            v = ld4g(wp, S.C - cc, p.vecB);
-          }
+          if (woff[j] >= 0 && cc < S.C) v = ld4g(wb + woff[j], S.C - cc, p.vecB);
           rb[j] = v;
         }
       } else {
+        const float* wb = p.w + ((long)c0_ * p.ldw + (long)tap_ * p.cin_total + p.w_choff);  // wave-uniform
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
-          int slot = t + 256 * j, k = slot / (4 * CT), ng = slot - k * (4 * CT);
-          int co = c0_ + k, ci = n0 + 4 * ng;
+          const int slot = t + 256 * j, k = slot / (4 * CT), ng = slot - k * (4 * CT);
           float4 v = zero4();
-          if (k < BK && co < S.C && ci < p.Cn) {
-            const float* wp = p.w + (long)co * p.ldw + (long)tap_ * p.cin_total + p.w_choff + ci;
-            v = ld4g(wp, p.Cn - ci, p.vecB);
-          }
+          if (woff[j] >= 0 && c0_ + k < S.C) v = ld4g(wb + woff[j], p.Cn - (n0 + 4 * ng), p.vecB);
           rb[j] = v;
         }
       }

@@ -18,13 +18,23 @@ struct WgK {
   int taps, nzt, nyt;      // tiles: taps, z (input-channel) tiles, y (output-channel) tiles
   int splits; int P; int chunkP;
   int vecY, vecZ;
+  // reduction target (used by the batched reduce)
+  float* dw; int ldw, cin_total, w_choff, accumulate;
 };
 
 constexpr int KP = 64;
 constexpr int ldpad(int bc) { return (bc % 32 == 16) ? bc : bc + 16; }
 
-template <int CTY, int CTZ>
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
+// Batched form: `work[b] = (op, bx, by, -)` lets ONE launch cover the weight gradients of many convolutions
+// (they are mutually independent and individually too small to fill 256 CUs); `ops == nullptr` is the plain launch.
+template <int CTY, int CTZ, bool BATCH>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
+  if (BATCH) {      // wave-uniform: keep the descriptor in scalar registers like a kernel argument
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK& p = BATCH ? ops[op] : pv;
   constexpr int BCY = 16 * CTY, BCZ = 16 * CTZ;
   constexpr int LY = ldpad(BCY), LZ = ldpad(BCZ);
   constexpr int NYJ = (KP * BCY / 4 + 255) / 256;
@@ -37,13 +47,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
   float* Zs = lds + KP * LY;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
-  int bx = blockIdx.x;
+  int bx = blk_x;
   const int zt = bx % p.nzt; bx /= p.nzt;
   const int tap = bx % p.taps; const int yt = bx / p.taps;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = yt * BCY, c0 = zt * BCZ;
   const int ohw = p.OH * p.OW;
-  const int pbeg = blockIdx.y * p.chunkP;
+  const int pbeg = blk_y * p.chunkP;
   int pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
   // lazy-BN scale/shift of this thread's channel quads (fixed across pixel steps)
   float4 za[NZJ], zb[NZJ];
@@ -157,7 +167,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
   }
   // workspace layout: [split][co][tap][c] over the real (unpadded) extents
   const int C = p.src.C;
-  float* wsb = p.ws + (long)blockIdx.y * p.Cout * p.taps * C;
+  float* wsb = p.ws + (long)blk_y * p.Cout * p.taps * C;
   for (int idx = t; idx < TILE; idx += 256) {
     int r = idx / BCZ, cc = idx - r * BCZ;
     int co = co0 + r, c = c0 + cc;
@@ -169,8 +179,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK p) {
 // (32*TY) x (32*TZ) output tile, every wave walks ALL staged pixels and owns a TYxTZ block of 16x16 accumulators
 // (32-64 VGPRs instead of the 128 of the pixel-split form), so 2-3 blocks fit a CU and staging overlaps the MFMAs;
 // no cross-wave reduction is needed.
-template <int TY, int TZ>
-__global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK p) {
+template <int TY, int TZ, bool BATCH>
+__global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
+  if (BATCH) {
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK& p = BATCH ? ops[op] : pv;
   constexpr int BCY = 32 * TY, BCZ = 32 * TZ;
   constexpr int LY = ldpad(BCY), LZ = ldpad(BCZ);
   constexpr int NYJ = (KP * BCY / 4 + 255) / 256;
@@ -181,13 +197,13 @@ __global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
   const int wy = wave >> 1, wz = wave & 1;
-  int bx = blockIdx.x;
+  int bx = blk_x;
   const int zt = bx % p.nzt; bx /= p.nzt;
   const int tap = bx % p.taps; const int yt = bx / p.taps;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = yt * BCY, c0 = zt * BCZ;
   const int ohw = p.OH * p.OW;
-  const int pbeg = blockIdx.y * p.chunkP;
+  const int pbeg = blk_y * p.chunkP;
   int pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
   float4 za[NZJ], zb[NZJ];
 #pragma unroll
@@ -281,7 +297,7 @@ __global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK p) {
     }
   }
   const int C = p.src.C;
-  float* wsb = p.ws + (long)blockIdx.y * p.Cout * p.taps * C;
+  float* wsb = p.ws + (long)blk_y * p.Cout * p.taps * C;
 #pragma unroll
   for (int i = 0; i < TY; ++i)
 #pragma unroll
@@ -327,6 +343,41 @@ __global__ void __launch_bounds__(256) wgrad_reduce_wave_kernel(const float* ws,
   }
 }
 
+// batched reduce: rwork[b] = (op, first element, mode): mode 1 = one wave per element (4 per block), 0 = thread per element
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const WgK* __restrict__ ops, const int4* __restrict__ rwork) {
+  const int4 wk = rwork[blockIdx.x];
+  const WgK p = ops[wk.x];
+  const int C = p.src.C;
+  const long n = (long)p.Cout * p.taps * C;
+  long i; float s;
+  bool writer;
+  if (wk.z) {
+    const int lane = threadIdx.x & 63;
+    i = (long)wk.y + (threadIdx.x >> 6);
+    if (i >= n) return;
+    s = 0.f;
+    for (int k = lane; k < p.splits; k += 64) s += p.ws[(long)k * n + i];
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    writer = lane == 0;
+  } else {
+    i = (long)wk.y + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < p.splits; k += 4) {
+      s0 += p.ws[(long)k * n + i]; s1 += p.ws[(long)(k + 1) * n + i]; s2 += p.ws[(long)(k + 2) * n + i]; s3 += p.ws[(long)(k + 3) * n + i];
+    }
+    for (; k < p.splits; ++k) s0 += p.ws[(long)k * n + i];
+    s = (s0 + s1) + (s2 + s3);
+    writer = true;
+  }
+  if (writer) {
+    int c = (int)(i % C); long r = i / C; int tap = (int)(r % p.taps); int co = (int)(r / p.taps);
+    float* d = p.dw + (long)co * p.ldw + (long)tap * p.cin_total + p.w_choff + c;
+    *d = p.accumulate ? *d + s : s;
+  }
+}
+
 int pick_cty(int Cout) {
   const int cands[5] = {8, 5, 4, 3, 2};
   int best = 2; long bc = -1;
@@ -347,9 +398,12 @@ void pick_tiles(int Cout, int C, int* cty, int* ctz) {
   }
 }
 bool use_output_split(int Cout, int C) { return Cout >= 128 && Cout % 128 == 0 && C >= 48; }
-int pick_splits(long P, int tiles) {
-  long maxs = cdiv(P, KP);                // at least one staged step per block
-  long want = cdiv(1536, tiles);          // ~6 resident blocks per CU keep enough loads in flight for the HBM-bound shapes
+// `budget` = workgroups this conv should contribute.  A lone launch needs ~1536 of them to fill the chip even if that
+// leaves a block a single 64-pixel step; inside a batch the other convs provide the parallelism, so each block gets
+// >= 8 steps and the per-block epilogue (cross-wave combine + partial tile written to the workspace) is amortised.
+int pick_splits(long P, int tiles, int budget = 1536, int min_steps = 1) {
+  long maxs = cdiv(P, (long)min_steps * KP);
+  long want = cdiv(budget, tiles);
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
   if (s > 1024) s = 1024;
@@ -364,36 +418,42 @@ extern "C" int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_
   return (int64_t)pick_splits(P, tiles) * Cout * taps * C;
 }
 
-extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
-  ADDK_REQUIRE(a && a->dy && a->src.x && a->dw && a->ws, "conv_wgrad: null pointer");
+static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, int& tiles, bool check_ws, int budget = 1536, int min_steps = 1) {
+  ADDK_REQUIRE(a && a->dy && a->src.x && a->dw && (a->ws || !check_ws), "conv_wgrad: null pointer");
   ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0 && a->Cout > 0 && a->src.C > 0, "conv_wgrad: empty shape");
   ADDK_REQUIRE(a->lddy >= a->Cout && a->src.ld >= a->src.C, "conv_wgrad: short stride");
   ADDK_REQUIRE(a->w_choff + a->src.C <= a->cin_total && a->ldw >= a->KH * a->KW * a->cin_total, "conv_wgrad: weight layout");
   ADDK_REQUIRE((a->src.a == nullptr) == (a->src.b == nullptr), "conv_wgrad: a/b must come together");
-  WgK k;
   k.dy = a->dy; k.lddy = a->lddy; k.Cout = a->Cout;
   k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
   k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
   k.src = a->src; k.ws = a->ws;
-  int cty, ctz; pick_tiles(a->Cout, a->src.C, &cty, &ctz);
+  pick_tiles(a->Cout, a->src.C, &cty, &ctz);
   k.taps = a->KH * a->KW; k.nyt = cdiv(a->Cout, 16 * cty); k.nzt = cdiv(a->src.C, 16 * ctz);
   ADDK_REQUIRE((long)a->N * a->OH * a->OW < (1L << 30) && (long)a->N * a->H * a->W < (1L << 30), "conv_wgrad: tensor too large for 32-bit pixel indexing");
   k.P = a->N * a->OH * a->OW;
-  const int tiles = k.nyt * k.taps * k.nzt;
-  k.splits = pick_splits(k.P, tiles);
-  ADDK_REQUIRE(a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  tiles = k.nyt * k.taps * k.nzt;
+  k.splits = pick_splits(k.P, tiles, budget, min_steps);
+  ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   k.chunkP = cdiv(cdiv(k.P, k.splits), KP) * KP;
   k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
   k.vecZ = src_vec_ok(a->src);
-  dim3 grid(tiles, k.splits);
-  hipStream_t st = (hipStream_t)stream;
+  k.dw = a->dw; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.accumulate = a->accumulate;
+  return 0;
+}
+
+static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, const WgK& k, const WgK* ops, const int4* work) {
   bool done = false;
-  if (use_output_split(a->Cout, a->src.C)) {
-    hipLaunchKernelGGL((wgrad_os_kernel<4, 2>), grid, dim3(256), 0, st, k);
+  if (kind == 1) {
+    if (ops) hipLaunchKernelGGL((wgrad_os_kernel<4, 2, true>), grid, dim3(256), 0, st, k, ops, work);
+    else hipLaunchKernelGGL((wgrad_os_kernel<4, 2, false>), grid, dim3(256), 0, st, k, ops, work);
     done = true;
   }
 #define ADDK_CASE(Y_, Z_) \
-  if (!done && cty == Y_ && ctz == Z_) { hipLaunchKernelGGL((wgrad_kernel<Y_, Z_>), grid, dim3(256), 0, st, k); done = true; }
+  if (!done && cty == Y_ && ctz == Z_) { \
+    if (ops) hipLaunchKernelGGL((wgrad_kernel<Y_, Z_, true>), grid, dim3(256), 0, st, k, ops, work); \
+    else hipLaunchKernelGGL((wgrad_kernel<Y_, Z_, false>), grid, dim3(256), 0, st, k, ops, work); \
+    done = true; }
   ADDK_CASE(2, 1) ADDK_CASE(2, 3) ADDK_CASE(2, 4) ADDK_CASE(2, 5)
   ADDK_CASE(3, 1) ADDK_CASE(3, 3) ADDK_CASE(3, 4) ADDK_CASE(3, 5)
   ADDK_CASE(4, 1) ADDK_CASE(4, 3) ADDK_CASE(4, 4) ADDK_CASE(4, 5)
@@ -401,7 +461,15 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   ADDK_CASE(8, 1) ADDK_CASE(8, 3) ADDK_CASE(8, 4)
 #undef ADDK_CASE
   if (!done) { addk_set_error("conv_wgrad: no tile config"); return ADDK_ERR_UNSUPPORTED; }
-  int rc = addk_check_launch("conv_wgrad");
+  return addk_check_launch("conv_wgrad");
+}
+
+extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
+  WgK k; int cty, ctz, tiles;
+  int rc = wg_fill(a, k, cty, ctz, tiles, true);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  rc = wg_launch(use_output_split(a->Cout, a->src.C) ? 1 : 0, cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
   if (rc) return rc;
   long n = (long)a->Cout * k.taps * a->src.C;
   if (k.splits > 16 && n <= 65536) {
@@ -413,4 +481,65 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
                        a->dw, a->ldw, a->cin_total, a->w_choff, a->accumulate);
   }
   return addk_check_launch("conv_wgrad_reduce");
+}
+
+// ---- batched weight gradients -------------------------------------------------------------------------------------
+extern "C" int addk_conv_wgrad_config(const addk_conv_wgrad_args* a, int32_t* cfg) {
+  WgK k; int cty, ctz, tiles;
+  int rc = wg_fill(a, k, cty, ctz, tiles, false);
+  if (rc) return rc;
+  cfg[0] = use_output_split(a->Cout, a->src.C) ? 1 : 0; cfg[1] = cty; cfg[2] = ctz; cfg[3] = tiles * k.splits;
+  return 0;
+}
+
+extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  if (!a || n <= 0 || !meta) { addk_set_error("wgrad_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
+  long nblocks = 0, nrblocks = 0;
+  int kind0 = -1, cty0 = 0, ctz0 = 0;
+  int budget = 8192 / n; if (budget < 32) budget = 32; if (budget > 1536) budget = 1536;
+  const int min_steps = n >= 4 ? 8 : 1;
+  for (int i = 0; i < n; ++i) {
+    WgK k; int cty, ctz, tiles;
+    int rc = wg_fill(&a[i], k, cty, ctz, tiles, host_blob != nullptr, budget, min_steps);
+    if (rc) return rc;
+    int kind = use_output_split(a[i].Cout, a[i].src.C) ? 1 : 0;
+    if (i == 0) { kind0 = kind; cty0 = cty; ctz0 = ctz; }
+    if (kind != kind0 || cty != cty0 || ctz != ctz0) { addk_set_error("wgrad_batch_prepare: mixed tile configurations"); return ADDK_ERR_INVALID; }
+    nblocks += (long)tiles * k.splits;
+    long ne = (long)a[i].Cout * k.taps * a[i].src.C;
+    nrblocks += (k.splits > 16 && ne <= 65536) ? cdiv(ne, 4) : cdiv(ne, 256);
+  }
+  const int64_t off_work = ((int64_t)n * sizeof(WgK) + 15) / 16 * 16;
+  const int64_t off_rwork = off_work + nblocks * (int64_t)sizeof(int4);
+  const int64_t total = off_rwork + nrblocks * (int64_t)sizeof(int4);
+  meta[0] = kind0; meta[1] = cty0; meta[2] = ctz0; meta[3] = n; meta[4] = off_work; meta[5] = nblocks; meta[6] = off_rwork; meta[7] = nrblocks;
+  if (!host_blob) return total;
+  if (blob_bytes < total) { addk_set_error("wgrad_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
+  WgK* ops = reinterpret_cast<WgK*>(host_blob);
+  int4* work = reinterpret_cast<int4*>(reinterpret_cast<char*>(host_blob) + off_work);
+  int4* rwork = reinterpret_cast<int4*>(reinterpret_cast<char*>(host_blob) + off_rwork);
+  long b = 0, rb = 0;
+  for (int i = 0; i < n; ++i) {
+    int cty, ctz, tiles;
+    wg_fill(&a[i], ops[i], cty, ctz, tiles, true, budget, min_steps);
+    for (int y = 0; y < ops[i].splits; ++y)
+      for (int x = 0; x < tiles; ++x) work[b++] = make_int4(i, x, y, 0);
+    long ne = (long)a[i].Cout * ops[i].taps * a[i].src.C;
+    if (ops[i].splits > 16 && ne <= 65536) { for (long e = 0; e < ne; e += 4) rwork[rb++] = make_int4(i, (int)e, 1, 0); }
+    else { for (long e = 0; e < ne; e += 256) rwork[rb++] = make_int4(i, (int)e, 0, 0); }
+  }
+  return total;
+}
+
+extern "C" int addk_conv_wgrad_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
+  ADDK_REQUIRE(dev_blob && meta && meta[3] > 0 && meta[5] > 0 && meta[7] > 0, "wgrad_batch_run: bad args");
+  const WgK* ops = reinterpret_cast<const WgK*>(dev_blob);
+  const int4* work = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(dev_blob) + meta[4]);
+  const int4* rwork = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(dev_blob) + meta[6]);
+  hipStream_t st = (hipStream_t)stream;
+  WgK dummy{};
+  int rc = wg_launch((int)meta[0], (int)meta[1], (int)meta[2], dim3((unsigned)meta[5], 1), st, dummy, ops, work);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)meta[7]), dim3(256), 0, st, ops, rwork);
+  return addk_check_launch("conv_wgrad_batch_reduce");
 }

@@ -31,7 +31,7 @@ class SyncBNComm:
         t = vec.view()
         if lst is g.fwd:
             t = t.view(torch.float64)
-        lst.append(('allreduce', self._allreduce, (t,)))
+        g._add(lst, 'allreduce', self._allreduce, t, rd=[vec], wr=[vec], pin=True)     # RCCL call: main stream only
 
 
 def init_sync_bn(group=None):

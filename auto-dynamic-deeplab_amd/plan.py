@@ -93,8 +93,85 @@ class Act:
     C = property(lambda s: s.raw.C)
 
 
-def _vp(x):
-    return C.c_void_p(x) if x else None
+class Cmd:
+    """One kernel launch of a plan: fn(*args, stream).  `rd`/`wr` are the memory regions it reads / writes
+    (keys from `_region`), used to schedule independent launches on parallel HIP streams."""
+    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin')
+
+    def __init__(self, name, fn, args, rd=(), wr=(), pin=False):
+        self.name, self.fn, self.args = name, fn, list(args)
+        self.rd, self.wr = [k for k in (_region(x) for x in rd) if k], [k for k in (_region(x) for x in wr) if k]
+        self.stream, self.waits, self.event, self.pin = 0, (), None, pin
+
+    def __iter__(self):                # unpacks like the (name, fn, args) triple it replaces
+        return iter((self.name, self.fn, self.args))
+
+    def __getitem__(self, i):
+        return (self.name, self.fn, self.args)[i]
+
+
+def _region(x):
+    """(buffer id, lo, hi): channel interval inside the pixel row for NHWC views, whole buffer otherwise."""
+    if x is None:
+        return None
+    if isinstance(x, TRef):
+        lo = x.off % x.ld if x.ld else 0
+        return (id(x.buf), lo, lo + x.C)
+    if isinstance(x, Vec):
+        return (id(x.buf), 0, 1 << 30)
+    if isinstance(x, Buf):
+        return (id(x), 0, 1 << 30)
+    if isinstance(x, torch.Tensor):
+        return (x.untyped_storage().data_ptr(), 0, 1 << 30)
+    if isinstance(x, tuple):
+        return x
+    raise TypeError(type(x))
+
+
+def _overlap(a, b):
+    return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+
+
+def schedule(cmds, nstreams):
+    """Assign every command a stream and the cross-stream waits it needs.  A command follows the stream of its most
+    recent dependency when that dependency is still the tail of its stream (a chain stays on one stream, no event);
+    otherwise it opens on the least recently used stream and waits on events.  Program order inside a stream plus the
+    recorded waits preserve every RAW/WAW/WAR relation of the sequential list."""
+    writers, readers = {}, {}            # buffer id -> [(region, idx)]
+    tail = [-1] * nstreams               # index of the last command on each stream
+    synced = [[-1] * nstreams for _ in range(nstreams)]   # synced[s][t]: latest index of stream t that s already waits for
+    for i, c in enumerate(cmds):
+        deps = set()
+        for k in c.rd:
+            deps.update(j for r, j in writers.get(k[0], ()) if _overlap(r, k))
+        for k in c.wr:
+            deps.update(j for r, j in writers.get(k[0], ()) if _overlap(r, k))
+            deps.update(j for r, j in readers.get(k[0], ()) if _overlap(r, k))
+        if c.pin or nstreams == 1:
+            st = 0
+        elif deps:
+            last = max(deps)
+            ls = cmds[last].stream
+            st = ls if tail[ls] == last else min(range(nstreams), key=lambda t: tail[t])
+        else:
+            st = min(range(nstreams), key=lambda t: tail[t])
+        waits = []
+        for j in sorted(deps, reverse=True):
+            t = cmds[j].stream
+            if t != st and synced[st][t] < j:
+                waits.append(j)
+                synced[st][t] = j
+        c.stream, c.waits = st, tuple(waits)
+        tail[st] = i
+        for k in c.wr:
+            writers[k[0]] = [(r, j) for r, j in writers.get(k[0], ()) if not (r[1] >= k[1] and r[2] <= k[2])] + [(k, i)]
+            readers[k[0]] = [(r, j) for r, j in readers.get(k[0], ()) if not _overlap(r, k)]
+        for k in c.rd:
+            readers.setdefault(k[0], []).append((k, i))
+    need = set(j for c in cmds for j in c.waits)
+    for j in need:
+        cmds[j].event = True
+    return cmds
 
 
 class Graph:
@@ -115,6 +192,7 @@ class Graph:
         self._wgrads = []             # wgrad arg structs sharing one scratch buffer (launches are stream-ordered)
         self.nbytes = 0
         self._bufs = []               # owns every device buffer: kernels only see raw pointers
+        self.nstreams = 1             # set by finalize(nstreams=k)
         self.meta = []                # per-launch algorithmic work of the dense convs (bench / roofline)
 
     # ---------------- memory ----------------
@@ -187,25 +265,113 @@ class Graph:
         self.pginit.add(p)
         return self.pgrad[p].data_ptr(), acc
 
-    def finalize(self):
-        """Emit the backward list (reverse op order) and allocate the scratch shared by all wgrad launches."""
+    def finalize(self, nstreams=1):
+        """Emit the backward list (reverse op order), schedule both lists on `nstreams` streams and allocate one wgrad
+        scratch per stream (launches of one stream are ordered, so they can share it)."""
         for em in reversed(self._bwd_emitters):
             em()
         self._bwd_emitters = []
-        if self._wgrads:
-            ws = self.buf(max(w.ws_floats for w in self._wgrads))
-            for w in self._wgrads:
-                w.ws = ws.ptr
+        self.nstreams = max(1, int(nstreams))
+        self._emit_batched_wgrads()
+        for lst in (self.fwd, self.bwd):
+            for i, c in enumerate(lst):
+                if not isinstance(c, Cmd):           # commands appended as plain triples (e.g. collectives): pinned to the main stream
+                    lst[i] = Cmd(c[0], c[1], c[2], pin=True)
+            schedule(lst, self.nstreams)
+            for c in lst:
+                if c.event:
+                    c.event = torch.cuda.Event()
+
+    def _emit_batched_wgrads(self):
+        """All weight gradients of the backward pass are deferred to its end and launched in a few batches: one launch
+        per tile configuration covers every conv that uses it (their dy / activation buffers are never reused, so
+        deferral is safe).  Two gradients that accumulate into the same weight columns (the ASPP/decoder head is
+        shared by the exits) must not sit in the same batch: the second goes to a later wave."""
+        if not self._wgrads:
+            return
+        lib = self.lib
+        waves = []          # [ {cfg: [(wa, rd, grad)]} , set(regions) ]
+        for wa, rd, grad, region in self._wgrads:
+            cfg = (C.c_int32 * 4)()
+            L.check(lib.addk_conv_wgrad_config(C.byref(wa), cfg), 'conv_wgrad_config')
+            key = (cfg[0], cfg[1], cfg[2])
+            for groups, used in waves:
+                if not any(r[0] == region[0] and r[1] < region[2] and region[1] < r[2] for r in used):
+                    break
+            else:
+                groups, used = {}, []
+                waves.append((groups, used))
+            used.append(region)
+            groups.setdefault(key, []).append((wa, rd, grad))
+        for groups, _ in waves:
+            for key, items in groups.items():
+                n = len(items)
+                arr = (L.ConvWgradArgs * n)()
+                for i, (wa, _, _) in enumerate(items):
+                    ws = self.buf(wa.ws_floats)
+                    wa.ws = ws.ptr
+                    arr[i] = wa
+                meta = (C.c_int64 * 8)()
+                size = lib.addk_conv_wgrad_batch_prepare(arr, n, None, 0, meta)
+                if size < 0:
+                    L.check(int(size), 'conv_wgrad_batch_prepare')
+                host = (C.c_uint8 * size)()
+                rc = lib.addk_conv_wgrad_batch_prepare(arr, n, host, size, meta)
+                if rc < 0:
+                    L.check(int(rc), 'conv_wgrad_batch_prepare')
+                if self.device.type == 'cuda':
+                    blob = torch.frombuffer(host, dtype=torch.uint8).to(self.device)
+                else:                       # dry-run planning on CPU (tests)
+                    blob = torch.frombuffer(host, dtype=torch.uint8).clone()
+                self.keep += [arr, meta, blob]
+                self.nbytes += int(size)
+                self._add(self.bwd, 'conv_wgrad_batch', lib.addk_conv_wgrad_batch_run, blob.data_ptr(), meta,
+                          rd=[r for _, rd, _ in items for r in rd], wr=[g for _, _, g in items])
 
     # ---------------- command helpers ----------------
-    def _add(self, lst, name, fn, *args):
-        lst.append((name, fn, args))
+    def _add(self, lst, name, fn, *args, rd=(), wr=(), pin=False):
+        c = Cmd(name, fn, args, rd, wr, pin)
+        lst.append(c)
+        return c
 
     def run(self, cmds, stream):
+        """Sequential replay on one stream."""
         for name, fn, args in cmds:
             rc = fn(*args, stream)
             if rc:
                 L.check(rc, name)
+
+    def run_parallel(self, cmds, main):
+        """Replay a scheduled list on `nstreams` HIP streams (stream 0 = `main`, a torch.cuda.Stream): independent
+        branches of the cell DAG overlap, which is what fills 256 CUs when single launches are small.  Works eagerly
+        and under hipGraph capture (fork/join through events)."""
+        ns = self.nstreams
+        if ns == 1:
+            return self.run(cmds, main.cuda_stream)
+        streams = [main] + self._side_streams()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for s in streams[1:]:
+            s.wait_event(fork)
+        ptrs = [s.cuda_stream for s in streams]
+        for c in cmds:
+            s = streams[c.stream]
+            for j in c.waits:
+                s.wait_event(cmds[j].event)
+            rc = c.fn(*c.args, ptrs[c.stream])
+            if rc:
+                L.check(rc, c.name)
+            if c.event is not None:
+                c.event.record(s)
+        for s in streams[1:]:
+            e = torch.cuda.Event()
+            e.record(s)
+            main.wait_event(e)
+
+    def _side_streams(self):
+        if getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.nstreams - 1)]
+        return self._streams
 
     def src(self, act, relu_in=False):
         s = L.Src()
@@ -214,6 +380,11 @@ class Graph:
             s.a, s.b = act.bn.a.ptr, act.bn.b.ptr
         s.ld, s.C, s.relu = act.raw.ld, act.raw.C, int(bool(act.relu or relu_in))
         return s
+
+    @staticmethod
+    def lz(act):
+        """Memory regions a consumer of lazy activation `act` reads."""
+        return [act.raw] + ([act.bn.a, act.bn.b] if act.bn is not None else [])
 
     def _dab(self, act, rows):
         """Allocate a (dA,dB) partial slab for a lazy source whose BN is in training mode."""
@@ -257,7 +428,8 @@ class Graph:
         ar.stats = stats.ptr if stats is not None else None
         ar.stats_ld = stats_ld
         self.keep.append(ar)
-        self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar))
+        self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
+                  rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats])
         self.meta.append(dict(kind='conv_fwd', idx=len(self.fwd) - 1, flops=2.0 * N * OH * OW * Cout * k * k * csum,
                               bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
                               shape=(N, H, W, csum, Cout, k, stride, dil)))
@@ -285,8 +457,7 @@ class Graph:
                     gp, acc = self.param_grad(weight, (choff, choff + s.C))
                     wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = gp, ldw, cin_total, choff, acc
                     wa.ws_floats = lib.addk_conv_wgrad_ws(P, Cout, s.C, k * k)
-                    self._wgrads.append(wa)
-                    self._add(self.bwd, 'conv_wgrad', lib.addk_conv_wgrad, C.byref(wa))
+                    self._wgrads.append((wa, [dy] + self.lz(s), self.pgrad[weight], (id(weight), choff, choff + s.C)))
                     # data gradient
                     if s.needs_grad:
                         da = L.ConvDgradArgs()
@@ -300,9 +471,10 @@ class Graph:
                         slab = self._dab(s, rows)
                         if slab is not None:
                             da.dab = slab.ptr
-                            s.bn.slabs.append((slab.ptr, rows))
+                            s.bn.slabs.append((slab, rows))
                         self.keep.append(da)
-                        self._add(self.bwd, 'conv_dgrad', lib.addk_conv_dgrad, C.byref(da))
+                        self._add(self.bwd, 'conv_dgrad', lib.addk_conv_dgrad, C.byref(da), rd=[dy, weight] + self.lz(s),
+                                  wr=[gs, slab])
                     choff += s.C
             self._bwd_emitters.append(emit_bwd)
         return out
@@ -315,14 +487,14 @@ class Graph:
         rows = lib.addk_ew_rows(dy.P, dy.C)
         ws = self.buf(rows * dy.C)
         self.keep.append(s)
-        self._add(self.bwd, 'bias_grad', lib.addk_gap_fwd, C.byref(s), 1, dy.P, tmp.ptr, dy.C, ws.ptr, 0)
+        self._add(self.bwd, 'bias_grad', lib.addk_gap_fwd, C.byref(s), 1, dy.P, tmp.ptr, dy.C, ws.ptr, 0, rd=[dy], wr=[tmp, ws])
         gp, acc = self.param_grad(bias)
         one = L.AffineSumArgs()
         t = L.Src(); t.x, t.ld, t.C = tmp.ptr, dy.C, dy.C
         one.term[0] = t; one.nterm = 1; one.P = 1; one.C = dy.C
         one.out, one.ldo, one.relu_out, one.accumulate = gp, dy.C, 0, acc
         self.keep.append(one)
-        self._add(self.bwd, 'bias_grad_acc', lib.addk_affine_sum_fwd, C.byref(one))
+        self._add(self.bwd, 'bias_grad_acc', lib.addk_affine_sum_fwd, C.byref(one), rd=[tmp], wr=[self.pgrad[bias]])
 
     def _colsum_n(self, dy, gbn):
         """per-image bias gradient: g[n,c] = sum_{p in image n} dy[p,c]."""
@@ -332,7 +504,8 @@ class Graph:
         ws = self.buf(dy.N * rows * dy.C)
         assert self.acc_flag(gbn) == 0
         self.keep.append(s)
-        self._add(self.bwd, 'bias_n_grad', lib.addk_gap_fwd, C.byref(s), dy.N, dy.H * dy.W, gbn.ptr, gbn.ld, ws.ptr, 0)
+        self._add(self.bwd, 'bias_n_grad', lib.addk_gap_fwd, C.byref(s), dy.N, dy.H * dy.W, gbn.ptr, gbn.ld, ws.ptr, 0,
+                  rd=[dy], wr=[gbn, ws])
 
     def stats_slab(self, P, Cc):
         rows = self.lib.addk_conv_rows(P, Cc)
@@ -354,7 +527,7 @@ class Graph:
             fa = L.BnFinalizeArgs()
             if sync:
                 red = self.vec(4 * Cc)      # fp64 [C][2]
-                self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, red.ptr)
+                self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, red.ptr, rd=[slab], wr=[red])
                 self.world.emit_allreduce(self, self.fwd, red)    # every rank has the same per-rank count
                 fa.partial, fa.rows = red.ptr, 1
                 st.count = count * self.world.size
@@ -370,10 +543,13 @@ class Graph:
             fa.eps = mod.eps
             fa.a, fa.b, fa.mean, fa.invstd = a.ptr, b.ptr, st.mean.ptr, st.invstd.ptr
             self.keep.append(fa)
-            self._add(self.fwd, 'bn_finalize', lib.addk_bn_finalize, C.byref(fa))
+            self._add(self.fwd, 'bn_finalize', lib.addk_bn_finalize, C.byref(fa),
+                      rd=[red if sync else slab, mod.weight, mod.bias],
+                      wr=[a, b, st.mean, st.invstd] + ([mod.running_mean, mod.running_var] if fa.running_mean else []))
         else:
             self._add(self.fwd, 'bn_eval_affine', lib.addk_bn_eval_affine, gam, bet, mod.running_mean.data_ptr(),
-                      mod.running_var.data_ptr(), mod.eps, Cc, a.ptr, b.ptr)
+                      mod.running_var.data_ptr(), mod.eps, Cc, a.ptr, b.ptr,
+                      rd=[mod.weight, mod.bias, mod.running_mean, mod.running_var], wr=[a, b])
         act = Act(raw, st, post_relu, needs_grad and self.want_grad)
 
         if self.want_grad and training:
@@ -386,7 +562,7 @@ class Graph:
                 ba = L.BnBwdArgs()
                 assert len(st.slabs) <= L.MAX_SLAB, 'too many consumers of one BatchNorm output (%d)' % len(st.slabs)
                 for i, (p, r) in enumerate(st.slabs):
-                    ba.slab[i], ba.rows[i] = p, r
+                    ba.slab[i], ba.rows[i] = p.ptr, r
                 ba.nslab, ba.C, ba.count = len(st.slabs), Cc, st.count
                 ba.gamma, ba.mean, ba.invstd, ba.a = gam, st.mean.ptr, st.invstd.ptr, a.ptr
                 if mod.weight is not None:
@@ -394,21 +570,26 @@ class Graph:
                     bp, acc2 = self.param_grad(mod.bias)
                     assert acc == acc2
                     ba.dgamma, ba.dbeta, ba.accumulate = gp, bp, acc
+                    pg = [self.pgrad[mod.weight], self.pgrad[mod.bias]]
+                else:
+                    pg = []
+                rd_bn = [sl for sl, _ in st.slabs] + [mod.weight, st.mean, st.invstd, a]
                 c1, c2 = self.vec(Cc), self.vec(Cc)
                 sync = self.world is not None and getattr(mod, 'sync', False) and self.world.size > 1
                 self.keep.append(ba)
                 if sync:
                     dmv = self.vec(2 * Cc)
                     ba.dmv = dmv.ptr
-                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba))
+                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [dmv])
                     self.world.emit_allreduce(self, self.bwd, dmv)
-                    self._add(self.bwd, 'bn_bwd_coeffs', lib.addk_bn_bwd_coeffs_from_dmv, dmv.ptr, Cc, st.count, c1.ptr, c2.ptr)
+                    self._add(self.bwd, 'bn_bwd_coeffs', lib.addk_bn_bwd_coeffs_from_dmv, dmv.ptr, Cc, st.count, c1.ptr, c2.ptr,
+                              rd=[dmv], wr=[c1, c2])
                 else:
                     ba.c1, ba.c2 = c1.ptr, c2.ptr
-                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba))
+                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2])
                 # dy_raw = G + c1 + c2*x, in place on the accumulated gradient
                 self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, None, c1.ptr, c2.ptr,
-                          raw.P, Cc, g.ptr, g.ld)
+                          raw.P, Cc, g.ptr, g.ld, rd=[g, raw, c1, c2], wr=[g])
             self._bwd_emitters.append(emit_bwd)
         return act
 
@@ -442,7 +623,7 @@ class Graph:
         ar.N, ar.H, ar.W, ar.OH, ar.OW, ar.KH, ar.KW, ar.stride, ar.pad, ar.dil = N, H, W, OH, OW, k, k, stride, pad, dil
         ar.w, ar.y, ar.ldy = wptr, out.ptr, out.ld
         self.keep.append(ar)
-        self._add(self.fwd, 'dw_fwd', lib.addk_dw_fwd, C.byref(ar))
+        self._add(self.fwd, 'dw_fwd', lib.addk_dw_fwd, C.byref(ar), rd=self.lz(src) + [conv_mod.weight], wr=[out])
         act = Act(out, None, False, self.want_grad)
         if self.want_grad:
             def emit_bwd():
@@ -461,13 +642,16 @@ class Graph:
                     slab = self._dab(src, rows)
                     if slab is not None:
                         ba.dab = slab.ptr
-                        src.bn.slabs.append((slab.ptr, rows))
+                        src.bn.slabs.append((slab, rows))
+                else:
+                    gs = slab = None
                 gp, acc = self.param_grad(conv_mod.weight)
                 ba.dw, ba.dw_accumulate = gp, acc
                 ws = self.buf(rows * Cc * k * k)
                 ba.ws = ws.ptr
                 self.keep.append(ba)
-                self._add(self.bwd, 'dw_bwd', lib.addk_dw_bwd, C.byref(ba))
+                self._add(self.bwd, 'dw_bwd', lib.addk_dw_bwd, C.byref(ba), rd=[dy, conv_mod.weight] + self.lz(src),
+                          wr=[gs, slab, self.pgrad[conv_mod.weight], ws])
             self._bwd_emitters.append(emit_bwd)
         return act
 
@@ -486,7 +670,7 @@ class Graph:
         ar.nterm, ar.P, ar.C = len(terms), out.P, out.C
         ar.out, ar.ldo, ar.relu_out, ar.accumulate = out.ptr, out.ld, int(relu_out), 0
         self.keep.append(ar)
-        self._add(self.fwd, 'affine_sum', lib.addk_affine_sum_fwd, C.byref(ar))
+        self._add(self.fwd, 'affine_sum', lib.addk_affine_sum_fwd, C.byref(ar), rd=[r for t in terms for r in self.lz(t)], wr=[out])
         ng = self.want_grad and any(t.needs_grad for t in terms)
         act = Act(out, None, False, ng)
         if ng:
@@ -496,6 +680,7 @@ class Graph:
                 do = self.grad(out)
                 ba = L.AffineSumBwdArgs()
                 rows = lib.addk_ew_rows(out.P, out.C)
+                wr_ = []
                 for i, t in enumerate(terms):
                     ba.term[i] = self.src(t)
                     if t.needs_grad:
@@ -504,12 +689,14 @@ class Graph:
                         slab = self._dab(t, rows)
                         if slab is not None:
                             ba.dab[i] = slab.ptr
-                            t.bn.slabs.append((slab.ptr, rows))
+                            t.bn.slabs.append((slab, rows))
+                        wr_ += [gt, slab]
                 ba.nterm, ba.P, ba.C = len(terms), out.P, out.C
                 ba.dout, ba.lddo = do.ptr, do.ld
                 ba.out, ba.ldo, ba.relu_out = out.ptr, out.ld, int(relu_out)
                 self.keep.append(ba)
-                self._add(self.bwd, 'affine_sum_bwd', lib.addk_affine_sum_bwd, C.byref(ba))
+                self._add(self.bwd, 'affine_sum_bwd', lib.addk_affine_sum_bwd, C.byref(ba),
+                          rd=[do, out] + [r for t in terms for r in self.lz(t)], wr=wr_)
             self._bwd_emitters.append(emit_bwd)
         return act
 
@@ -532,7 +719,7 @@ class Graph:
         ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
         ar.y, ar.ldy, ar.nchw_out = out.ptr, out.ld, 0
         self.keep.append(ar)
-        self._add(self.fwd, 'resize_fwd', lib.addk_resize_fwd, C.byref(ar))
+        self._add(self.fwd, 'resize_fwd', lib.addk_resize_fwd, C.byref(ar), rd=self.lz(src), wr=[out])
         res = Act(out, None if relu else src.bn, False, src.needs_grad)
         if self.want_grad and src.needs_grad:
             def emit_bwd():
@@ -545,14 +732,15 @@ class Graph:
                 ba.N, ba.H, ba.W, ba.OH, ba.OW = N, H, W, OH, OW
                 gs = self.grad(src.raw)
                 ba.g, ba.ldg, ba.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
+                slab = None
                 if relu:
                     rows = lib.addk_ew_rows(N * H * W, Cc)
                     slab = self._dab(src, rows)
                     if slab is not None:
                         ba.dab = slab.ptr
-                        src.bn.slabs.append((slab.ptr, rows))
+                        src.bn.slabs.append((slab, rows))
                 self.keep.append(ba)
-                self._add(self.bwd, 'resize_bwd', lib.addk_resize_bwd, C.byref(ba))
+                self._add(self.bwd, 'resize_bwd', lib.addk_resize_bwd, C.byref(ba), rd=[dy] + self.lz(src), wr=[gs, slab])
             self._bwd_emitters.append(emit_bwd)
         return res
 
@@ -568,7 +756,7 @@ class Graph:
         ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
         ar.y, ar.ldy, ar.nchw_out = y.data_ptr(), 0, 1
         self.keep.append(ar)
-        self._add(self.fwd, 'resize_nchw', lib.addk_resize_fwd, C.byref(ar))
+        self._add(self.fwd, 'resize_nchw', lib.addk_resize_fwd, C.byref(ar), rd=self.lz(src), wr=[y])
         out = OutRef(y)
         if self.want_grad and src.needs_grad:
             def emit_bwd():
@@ -584,7 +772,7 @@ class Graph:
                 ba.g, ba.ldg, ba.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
                 self.keep.append(ba)
                 out.bwd_args = ba
-                self._add(self.bwd, 'resize_nchw_bwd', lib.addk_resize_bwd, C.byref(ba))
+                self._add(self.bwd, 'resize_nchw_bwd', lib.addk_resize_bwd, C.byref(ba), rd=self.lz(src), wr=[gs])
             self._bwd_emitters.append(emit_bwd)
         return out
 
@@ -596,7 +784,7 @@ class Graph:
         rows = lib.addk_ew_rows(H * W, Cc)
         ws = self.buf(N * rows * Cc)
         self.keep.append(s)
-        self._add(self.fwd, 'gap_fwd', lib.addk_gap_fwd, C.byref(s), N, H * W, out.ptr, out.ld, ws.ptr, 1)
+        self._add(self.fwd, 'gap_fwd', lib.addk_gap_fwd, C.byref(s), N, H * W, out.ptr, out.ld, ws.ptr, 1, rd=self.lz(src), wr=[out, ws])
         act = Act(out, None, False, self.want_grad and src.needs_grad)
         if act.needs_grad:
             def emit_bwd():
@@ -608,9 +796,9 @@ class Graph:
                 rows2 = lib.addk_ew_rows(N * H * W, Cc)
                 slab = self._dab(src, rows2)
                 if slab is not None:
-                    src.bn.slabs.append((slab.ptr, rows2))
+                    src.bn.slabs.append((slab, rows2))
                 self._add(self.bwd, 'gap_bwd', lib.addk_gap_bwd, C.byref(s), N, H * W, dy.ptr, dy.ld, gs.ptr, gs.ld, acc,
-                          slab.ptr if slab is not None else None)
+                          slab.ptr if slab is not None else None, rd=[dy] + self.lz(src), wr=[gs, slab])
             self._bwd_emitters.append(emit_bwd)
         return act
 
@@ -621,7 +809,8 @@ class Graph:
         out = self.tensor(N, OH, OW, Cc)
         s = self.src(src)
         self.keep.append(s)
-        self._add(self.fwd, 'pool3_fwd', lib.addk_pool3_fwd, C.byref(s), N, H, W, OH, OW, stride, mode, out.ptr, out.ld)
+        self._add(self.fwd, 'pool3_fwd', lib.addk_pool3_fwd, C.byref(s), N, H, W, OH, OW, stride, mode, out.ptr, out.ld,
+                  rd=self.lz(src), wr=[out])
         act = Act(out, None, False, self.want_grad and src.needs_grad)
         if act.needs_grad:
             assert src.bn is None or not src.bn.training, 'pool3 backward through a lazy training BN is not built (cold path)'
@@ -632,7 +821,7 @@ class Graph:
                 dy = self.grad(out)
                 gs = self.grad(src.raw)
                 self._add(self.bwd, 'pool3_bwd', lib.addk_pool3_bwd, C.byref(s), N, H, W, OH, OW, stride, mode, dy.ptr, dy.ld,
-                          gs.ptr, gs.ld, self.acc_flag(gs))
+                          gs.ptr, gs.ld, self.acc_flag(gs), rd=[dy] + self.lz(src), wr=[gs])
             self._bwd_emitters.append(emit_bwd)
         return act
 
@@ -646,7 +835,7 @@ class Graph:
         N, Cc, H, W = x.shape
         t = self.tensor(N, H, W, Cc, ld)
         inref = InRef(tuple(x.shape))
-        self._add(self.fwd, 'nchw_to_nhwc', _in_stage, lib, inref, N, Cc, H * W, t.ptr, t.ld)
+        self._add(self.fwd, 'nchw_to_nhwc', _in_stage, lib, inref, N, Cc, H * W, t.ptr, t.ld, wr=[t])
         act = Act(t, None, False, requires_grad and self.want_grad)
         if act.needs_grad:
             gx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=self.device)
@@ -659,7 +848,7 @@ class Graph:
                 g = self.grad(t)
                 s = L.Src(); s.x, s.ld, s.C = g.ptr, g.ld, g.C
                 self.keep.append(s)
-                self._add(self.bwd, 'in_grad_to_nchw', lib.addk_nhwc_to_nchw, C.byref(s), N, H * W, gx.data_ptr())
+                self._add(self.bwd, 'in_grad_to_nchw', lib.addk_nhwc_to_nchw, C.byref(s), N, H * W, gx.data_ptr(), rd=[g], wr=[gx])
             self._bwd_emitters.append(emit_bwd)
         return act, inref
 
@@ -670,7 +859,7 @@ class Graph:
         y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=self.device)
         s = self.src(act)
         self.keep.append(s)
-        self._add(self.fwd, 'nhwc_to_nchw', lib.addk_nhwc_to_nchw, C.byref(s), N, H * W, y.data_ptr())
+        self._add(self.fwd, 'nhwc_to_nchw', lib.addk_nhwc_to_nchw, C.byref(s), N, H * W, y.data_ptr(), rd=self.lz(act), wr=[y])
         out = OutRef(y)
         if self.want_grad and act.needs_grad:
             def emit_bwd():
@@ -679,11 +868,9 @@ class Graph:
                 rows = lib.addk_ew_rows(N * H * W, Cc)
                 slab = self._dab(act, rows)
                 if slab is not None:
-                    act.bn.slabs.append((slab.ptr, rows))
-                cmd = ['out_grad', lib.addk_nchw_grad_to_nhwc, [None, C.byref(s), N, H * W, gs.ptr, gs.ld, acc,
-                                                                slab.ptr if slab is not None else None]]
-                out.bwd_cmd = cmd
-                self.bwd.append(cmd)
+                    act.bn.slabs.append((slab, rows))
+                out.bwd_cmd = self._add(self.bwd, 'out_grad', lib.addk_nchw_grad_to_nhwc, None, C.byref(s), N, H * W, gs.ptr, gs.ld,
+                                        acc, slab.ptr if slab is not None else None, rd=self.lz(act), wr=[gs, slab])
             self._bwd_emitters.append(emit_bwd)
         return out
 
@@ -729,7 +916,7 @@ class OutRef:
         if self.bwd_args is not None:
             self.bwd_args.dy = gy.data_ptr()
         elif self.bwd_cmd is not None:
-            self.bwd_cmd[2][0] = gy.data_ptr()
+            self.bwd_cmd.args[0] = gy.data_ptr()
         return gy
 
 

@@ -35,7 +35,7 @@ def _flat_views(params, device):
 
 class TrainStep:
     def __init__(self, model, batch_shape, lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, class_weight=None,
-                 ignore_index=255, use_graph=None, sync_comm=None):
+                 ignore_index=255, use_graph=None, sync_comm=None, nstreams=None):
         lib = self.lib = L.load()
         dev = next(model.parameters()).device
         _plan.require_device(next(model.parameters()))
@@ -66,17 +66,20 @@ class TrainStep:
         cw = class_weight.to(dev).float().contiguous() if class_weight is not None else None
         self._keep = [ws, cw]
         cwp = cw.data_ptr() if cw is not None else None
-        g._add(g.fwd, 'loss_zero', lib.addk_fill, self.loss.data_ptr(), 1, 0.0)
+        g._add(g.fwd, 'loss_zero', lib.addk_fill, self.loss.data_ptr(), 1, 0.0, wr=[self.loss])
         g._add(g.fwd, 'ce_count', lib.addk_ce_count, self.target.data_ptr(), N * H * W, cwp, ignore_index, ncls,
-               self.wsum.data_ptr(), ws.data_ptr())
+               self.wsum.data_ptr(), ws.data_ptr(), rd=[self.target], wr=[self.wsum, ws])
         self.dlogits = []
         for o in outs:
             d = torch.empty_like(o.y)
             self.dlogits.append(d)
             g._add(g.fwd, 'ce_fwd_bwd', lib.addk_ce_fwd_bwd, o.y.data_ptr(), self.target.data_ptr(), N, ncls, H * W, cwp,
-                   ignore_index, self.wsum.data_ptr(), 1.0 / nex, self.loss.data_ptr(), d.data_ptr(), ws.data_ptr())
+                   ignore_index, self.wsum.data_ptr(), 1.0 / nex, self.loss.data_ptr(), d.data_ptr(), ws.data_ptr(),
+                   rd=[o.y, self.target, self.wsum], wr=[self.loss, d, ws])
             o.dy_ptr, o.dynamic = d.data_ptr(), False
-        g.finalize()
+        if nstreams is None:
+            nstreams = int(os.environ.get('ADDK_STREAMS', '1'))    # >1: independent branches on parallel streams (+5 % eager; opt-in)
+        g.finalize(nstreams)
         self.nbt = NbtCounter(g.nbt)
         self.nbt.bump(); self.nbt.flat.sub_(self.nbt.inc)      # flatten now (pointers must be fixed before graph capture)
         self.n_active = self.flat_p.numel()
@@ -89,10 +92,11 @@ class TrainStep:
 
     # one eager pass of the whole step on the current stream
     def _run(self):
-        st = _plan.current_stream()
+        main = torch.cuda.current_stream()
+        st = main.cuda_stream
         g = self.g
-        g.run(g.fwd, st)
-        g.run(g.bwd, st)
+        g.run_parallel(g.fwd, main)
+        g.run_parallel(g.bwd, main)
         if self.world > 1:
             torch.distributed.all_reduce(self.flat_g)
         mom, wd, nest = self.hyper
@@ -102,9 +106,9 @@ class TrainStep:
 
     def forward_backward_only(self):
         """Forward + loss + backward without the optimizer update (parity tests)."""
-        st = _plan.current_stream()
-        self.g.run(self.g.fwd, st)
-        self.g.run(self.g.bwd, st)
+        main = torch.cuda.current_stream()
+        self.g.run_parallel(self.g.fwd, main)
+        self.g.run_parallel(self.g.bwd, main)
 
     def load_batch(self, images, targets):
         self.x.copy_(images, non_blocking=True)

@@ -123,6 +123,15 @@ typedef struct addk_conv_wgrad_args {
 int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream);
 int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_t taps);
 
+/* Batched weight gradients.  The weight gradients of a backward pass are mutually independent and, for the 40-160
+ * channel cell convolutions, individually far too small to fill 256 CUs (HBM-ideal 5 us, launch-latency bound at
+ * 30-50 us): `n` of them that share a tile configuration run as ONE launch driven by a device-resident work list, plus
+ * one batched reduce.  cfg = {kind, cty, ctz, blocks}; prepare() fills a host blob (descriptors + work lists) to be
+ * copied to the device once at plan time (call with host_blob == NULL to get its size); meta[8] is host-side. */
+int addk_conv_wgrad_config(const addk_conv_wgrad_args* a, int32_t* cfg);
+int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int addk_conv_wgrad_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Depthwise k x k convolution (groups == C), stride 1 or 2, pad k/2*dil: the depthwise
  * halves of SepConv (operations.py:52,56).  w is [C][KH*KW] (torch [C,1,KH,KW]).

@@ -56,6 +56,9 @@ def _syncbn_math(rank, world):
 
     class G:
         fwd = cmds
+
+        def _add(self, lst, name, fn, *args, **kw):
+            lst.append((name, fn, args))
     g = G()
     comm.emit_allreduce(g, g.fwd, Vec(buf, 0, 4 * C))
     for name, fn, args in cmds:

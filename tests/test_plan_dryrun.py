@@ -79,7 +79,7 @@ def test_add_plan_structure_train(dry):
     assert bn['bn_bwd'] == 312 and bn['dw_bwd'] == 168 and bn['affine_sum_bwd'] == 60
     loss = sum(o.sum() for o in outs)
     loss.backward()
-    assert dry['conv_wgrad'] > 318
+    assert 1 <= dry['conv_wgrad_batch'] <= 40            # ~640 weight gradients in a few batched launches
     assert m.stem0[0].weight.grad is not None and m.aspp.conv1.weight.grad is not None
     assert int(m.aspp.bn1.num_batches_tracked) == 2 and int(m.stem0[1].num_batches_tracked) == 1     # shared head: Q4
 
