@@ -223,6 +223,17 @@ int rs_rows(long P, int C) {
 }  // namespace
 
 extern "C" int addk_resize_fwd(const addk_resize_args* a, void* stream) {
+  if (a && a->src.C > 1024 && !a->nchw_out) {      // wide concat buffers (F=40, level 3: 1600 channels): 1024-channel slices
+    for (int c0 = 0; c0 < a->src.C; c0 += 1024) {
+      addk_resize_args b = *a;
+      b.src.x = a->src.x + c0; b.src.C = a->src.C - c0 < 1024 ? a->src.C - c0 : 1024;
+      if (a->src.a) { b.src.a = a->src.a + c0; b.src.b = a->src.b + c0; }
+      b.y = a->y + c0;
+      int rc = addk_resize_fwd(&b, stream);
+      if (rc) return rc;
+    }
+    return ADDK_OK;
+  }
   ADDK_REQUIRE(a && a->src.x && a->y && a->src.C > 0 && a->src.C <= 1024 && a->src.ld >= a->src.C, "resize_fwd: bad args");
   ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "resize_fwd: empty shape");
   ADDK_REQUIRE((a->src.a == nullptr) == (a->src.b == nullptr), "resize_fwd: a/b must come together");
@@ -244,6 +255,18 @@ extern "C" int addk_resize_fwd(const addk_resize_args* a, void* stream) {
 }
 
 extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
+  if (a && a->src.C > 1024 && !a->nchw_in && !a->dab) {
+    for (int c0 = 0; c0 < a->src.C; c0 += 1024) {
+      addk_resize_bwd_args b = *a;
+      b.src.C = a->src.C - c0 < 1024 ? a->src.C - c0 : 1024;
+      if (a->src.x) b.src.x = a->src.x + c0;
+      if (a->src.a) { b.src.a = a->src.a + c0; b.src.b = a->src.b + c0; }
+      b.dy = a->dy + c0; b.g = a->g + c0;
+      int rc = addk_resize_bwd(&b, stream);
+      if (rc) return rc;
+    }
+    return ADDK_OK;
+  }
   ADDK_REQUIRE(a && a->dy && a->g && a->src.C > 0 && a->src.C <= 1024 && a->ldg >= a->src.C, "resize_bwd: bad args");
   ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "resize_bwd: empty shape");
   ADDK_REQUIRE(!(a->src.relu || a->dab) || (a->src.x && a->src.ld >= a->src.C), "resize_bwd: prologue needs the forward input");

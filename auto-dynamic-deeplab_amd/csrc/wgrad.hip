@@ -390,14 +390,26 @@ int pick_ctz(int C) {
   for (int k = 0; k < 4; ++k) { long cols = (long)cdiv(C, 16 * cands[k]) * 16 * cands[k]; if (bc < 0 || cols < bc) { bc = cols; best = cands[k]; } }
   return best;
 }
+// 0: pixel-split kernel; 1: output-split 128x64 (wide heads); 2: output-split 96x96 (80-channel cells);
+// 3: output-split 64x64 (64-channel stem); 4: output-split 128x128 (wide heads with >= 128 input channels)
+int os_kind(int Cout, int C) {
+  if (Cout >= 128 && Cout % 128 == 0 && C >= 48) return 1;
+  if (Cout > 64 && Cout <= 96 && C > 64 && C <= 96) return 2;
+  if (Cout > 48 && Cout <= 64 && C > 48 && C <= 64) return 3;
+  return 0;
+}
 void pick_tiles(int Cout, int C, int* cty, int* ctz) {
   *cty = pick_cty(Cout); *ctz = pick_ctz(C);
   if (*cty == 8 && *ctz == 5) *ctz = 4;   // 8x5 accumulator tiles would not leave room for the staging registers
-  if (Cout >= 128 && Cout % 128 == 0 && C >= 48) {   // wide heads: output-split kernel, 128 x 64 tiles
-    *cty = 8; *ctz = 4;
+  switch (os_kind(Cout, C)) {
+    case 1: *cty = 8; *ctz = 4; break;
+    case 4: *cty = 8; *ctz = 8; break;
+    case 2: *cty = 6; *ctz = 6; break;
+    case 3: *cty = 4; *ctz = 4; break;
+    default: break;
   }
 }
-bool use_output_split(int Cout, int C) { return Cout >= 128 && Cout % 128 == 0 && C >= 48; }
+bool use_output_split(int Cout, int C) { return os_kind(Cout, C) != 0; }
 // `budget` = workgroups this conv should contribute.  A lone launch needs ~1536 of them to fill the chip even if that
 // leaves a block a single 64-pixel step; inside a batch the other convs provide the parallelism, so each block gets
 // >= 8 steps and the per-block epilogue (cross-wave combine + partial tile written to the workspace) is amortised.
@@ -444,11 +456,13 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
 
 static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, const WgK& k, const WgK* ops, const int4* work) {
   bool done = false;
-  if (kind == 1) {
-    if (ops) hipLaunchKernelGGL((wgrad_os_kernel<4, 2, true>), grid, dim3(256), 0, st, k, ops, work);
-    else hipLaunchKernelGGL((wgrad_os_kernel<4, 2, false>), grid, dim3(256), 0, st, k, ops, work);
-    done = true;
-  }
+#define ADDK_OS(K_, TY_, TZ_) \
+  if (kind == K_) { \
+    if (ops) hipLaunchKernelGGL((wgrad_os_kernel<TY_, TZ_, true>), grid, dim3(256), 0, st, k, ops, work); \
+    else hipLaunchKernelGGL((wgrad_os_kernel<TY_, TZ_, false>), grid, dim3(256), 0, st, k, ops, work); \
+    done = true; }
+  ADDK_OS(1, 4, 2) ADDK_OS(2, 3, 3) ADDK_OS(3, 2, 2) ADDK_OS(4, 4, 4)
+#undef ADDK_OS
 #define ADDK_CASE(Y_, Z_) \
   if (!done && cty == Y_ && ctz == Z_) { \
     if (ops) hipLaunchKernelGGL((wgrad_kernel<Y_, Z_, true>), grid, dim3(256), 0, st, k, ops, work); \
@@ -469,7 +483,7 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   int rc = wg_fill(a, k, cty, ctz, tiles, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = wg_launch(use_output_split(a->Cout, a->src.C) ? 1 : 0, cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
+  rc = wg_launch(os_kind(a->Cout, a->src.C), cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
   if (rc) return rc;
   long n = (long)a->Cout * k.taps * a->src.C;
   if (k.splits > 16 && n <= 65536) {
@@ -488,7 +502,7 @@ extern "C" int addk_conv_wgrad_config(const addk_conv_wgrad_args* a, int32_t* cf
   WgK k; int cty, ctz, tiles;
   int rc = wg_fill(a, k, cty, ctz, tiles, false);
   if (rc) return rc;
-  cfg[0] = use_output_split(a->Cout, a->src.C) ? 1 : 0; cfg[1] = cty; cfg[2] = ctz; cfg[3] = tiles * k.splits;
+  cfg[0] = os_kind(a->Cout, a->src.C); cfg[1] = cty; cfg[2] = ctz; cfg[3] = tiles * k.splits;
   return 0;
 }
 
@@ -502,7 +516,7 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
     WgK k; int cty, ctz, tiles;
     int rc = wg_fill(&a[i], k, cty, ctz, tiles, host_blob != nullptr, budget, min_steps);
     if (rc) return rc;
-    int kind = use_output_split(a[i].Cout, a[i].src.C) ? 1 : 0;
+    int kind = os_kind(a[i].Cout, a[i].src.C);
     if (i == 0) { kind0 = kind; cty0 = cty; ctz0 = ctz; }
     if (kind != kind0 || cty != cty0 || ctz != ctz0) { addk_set_error("wgrad_batch_prepare: mixed tile configurations"); return ADDK_ERR_INVALID; }
     nblocks += (long)tiles * k.splits;

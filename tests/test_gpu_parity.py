@@ -337,6 +337,21 @@ def test_add_whole_net_frozen_bn_gradients(dev):
     assert n > 400
 
 
+@pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])
+def test_add_f40_config5_eval(dev, gname):
+    """BASELINE config 5 architecture (F=40, searched_arch/40_5e_38_lr genotypes, three unsorted pairs: Q1), eval forward
+    against the oracle at a small input."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'searched_arch', '40_5e_38_lr', gname + '.npy'))
+    ma, mo, _ = _build_add(dev, 40, ARCH_C2, seed=900, genotype=g)
+    ma.eval(); mo.eval()
+    x = rand_tensor(91, 'f40_x', (1, 3, 65, 129))
+    with torch.no_grad():
+        ya, yo = ma(x.to(dev)), mo(x)
+    for i, (a, o) in enumerate(zip(ya, yo)):
+        _chk('F40_%s/eval%d' % (gname, i), a, o)
+
+
 def test_dynamic_inference_and_entropy(dev, golden):
     from addk.modeling.ADD import EDM
     from addk.modeling.operations import normalized_shannon_entropy
