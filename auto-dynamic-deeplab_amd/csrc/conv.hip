@@ -38,6 +38,7 @@ struct ConvK {
   addk_src dst;     // dgrad epilogue
   int accumulate;
   int vecA, vecB, vecY;
+  int red32;        // 1: per-tile lane reduction in fp32 (large P); 0: fp64 end to end (tiny batches, e.g. the 2-sample ASPP pool BN)
   long P;
   int ntiles;
 };
@@ -101,7 +102,13 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
     }
   }
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so workgroup b
+  // takes tile (b % 8) * (ntiles / 8) + b / 8: every XCD walks a contiguous range of pixel tiles and the rows a k x k
+  // tap re-reads (one image row above / below = a few tiles away) are served from that XCD's L2.  Speed only.
+  const int tpx = p.ntiles >> 3;
+  const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
+  for (int tlin = blockIdx.x; tlin < p.ntiles; tlin += gridDim.x) {
+    const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
     int rn[NAJ], rh[NAJ], rw[NAJ];
     long roff[NAJ];              // element offset of (n, rh, rw) in a source with pixel stride 1 (scaled by S.ld per chunk)
 #pragma unroll
@@ -306,10 +313,11 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
 #pragma unroll
           for (int i = 0; i < CT; ++i)
 #pragma unroll
-            for (int j = 0; j < PT; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].x, xf[j].x, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].y, xf[j].y, acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].x, xf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].y, xf[j].y, acc[i][j], 0, 0, 0);
         }
       }
       __syncthreads();
@@ -368,12 +376,22 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
         }
       }
       if (want_red) {
+        if (p.red32) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          double a = s1[e], b = s2v[e];
+          for (int e = 0; e < 4; ++e) {
+            float a = (float)s1[e], b = (float)s2v[e];
 #pragma unroll
-          for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-          if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = a; red[wave][i * 16 + kq * 4 + e][1] = b; }
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = a; red[wave][i * 16 + kq * 4 + e][1] = b; }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            double a = s1[e], b = s2v[e];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = a; red[wave][i * 16 + kq * 4 + e][1] = b; }
+          }
         }
       }
     }
@@ -426,6 +444,7 @@ int launch(ConvK& k, hipStream_t st) {
   const int pt = pick_pt(k.P);
   const int BP = 64 * pt;
   k.ntiles = cdiv(k.P, BP);
+  k.red32 = k.P >= 4096;
   const int ct = pick_ct(k.Cn, k.ntiles);
   dim3 grid(k.ntiles < 1024 ? k.ntiles : 1024, cdiv(k.Cn, 16 * ct));
   const int prec = conv_precision();
