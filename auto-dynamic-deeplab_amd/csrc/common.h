@@ -70,3 +70,7 @@ struct EwMap { int nq, npl; };
 static inline EwMap ew_map(int C) {
   EwMap m; m.nq = (C + 3) / 4; if (m.nq > 256) m.nq = 256; m.npl = 256 / m.nq; if (m.npl < 1) m.npl = 1; return m;
 }
+
+// pw.hip: register-stationary 1x1 convolution; 0 = launched, 1 = shape not covered (fall back), <0 = error
+int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream);
+int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream);

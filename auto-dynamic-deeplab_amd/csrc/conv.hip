@@ -439,6 +439,12 @@ int conv_precision() {
   return g_prec;
 }
 
+bool pw_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADDK_PW"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+
 template <int MODE>
 int launch(ConvK& k, hipStream_t st) {
   const int pt = pick_pt(k.P);
@@ -446,7 +452,7 @@ int launch(ConvK& k, hipStream_t st) {
   k.ntiles = cdiv(k.P, BP);
   k.red32 = k.P >= 4096;
   const int ct = pick_ct(k.Cn, k.ntiles);
-  dim3 grid(k.ntiles < 1024 ? k.ntiles : 1024, cdiv(k.Cn, 16 * ct));
+  dim3 grid(addk_conv_rows(k.P, k.Cn), cdiv(k.Cn, 16 * ct));   // workgroups beyond ntiles only write their (zero) slab row
   const int prec = conv_precision();
 #define ADDK_CASE(PT_, CT_) \
   if (pt == PT_ && ct == CT_) { \
@@ -485,7 +491,7 @@ extern "C" int addk_selftest_mfma(float* out256, void* stream) {
 
 extern "C" int addk_conv_rows(int64_t P, int32_t Cout) {
   (void)Cout;
-  int nt = cdiv(P, 64 * pick_pt(P));
+  int nt = cdiv(P, 64);           // one slab row per workgroup; every conv kernel launches exactly this many in x
   return nt < 1024 ? nt : 1024;
 }
 
@@ -509,6 +515,10 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
   }
   ADDK_REQUIRE(a->w_choff + ctot <= a->cin_total, "conv_fwd: sources exceed cin_total");
   ADDK_REQUIRE(a->ldw >= a->KH * a->KW * a->cin_total, "conv_fwd: ldw too small");
+  if (conv_precision() == PREC_F32 && pw_enabled()) {      // small pointwise shapes: register-stationary kernel (pw.hip)
+    int r = addk_pw_try_fwd(a, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), stream);
+    if (r <= 0) return r;
+  }
   k.nsrc = a->nsrc;
   k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
   k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
@@ -530,6 +540,10 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
   ADDK_REQUIRE(a->lddy >= a->Cout && a->ldg >= a->dst.C && a->dst.ld >= a->dst.C, "conv_dgrad: short stride");
   ADDK_REQUIRE(a->w_choff + a->dst.C <= a->cin_total && a->ldw >= a->KH * a->KW * a->cin_total, "conv_dgrad: weight layout");
   ADDK_REQUIRE((a->dst.a == nullptr) == (a->dst.b == nullptr), "conv_dgrad: a/b must come together");
+  if (conv_precision() == PREC_F32 && pw_enabled()) {
+    int r = addk_pw_try_dgrad(a, addk_conv_rows((long)a->N * a->H * a->W, a->dst.C), stream);
+    if (r <= 0) return r;
+  }
   ConvK k;
   k.nsrc = 1;
   k.src[0] = addk_src{a->dy, nullptr, nullptr, a->lddy, a->Cout, 0, 0};

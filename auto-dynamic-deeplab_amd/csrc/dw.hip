@@ -121,16 +121,20 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
       }
     }
   }
-  // Block reduction over pixel lanes, deterministic and cheap: per tap every thread drops its float4 into an
-  // [npl][C4] LDS panel, then one thread per channel adds the npl rows in fixed order.
+  // Block reduction over pixel lanes, deterministic and cheap: TG taps at a time every thread drops its float4s into an
+  // [TG][npl][C4] LDS panel, then one thread per (tap, channel) adds the npl rows in fixed order (2 barriers per group).
+  constexpr int TG = NT == 9 ? 3 : 5;
 #pragma unroll
-  for (int tp = 0; tp < NT; ++tp) {
-    if (active) *reinterpret_cast<float4*>(&redt[pl * C4 + c]) = dwacc[tp];
+  for (int t0 = 0; t0 < NT; t0 += TG) {
+#pragma unroll
+    for (int u = 0; u < TG; ++u)
+      if (active) *reinterpret_cast<float4*>(&redt[(u * p.npl + pl) * C4 + c]) = dwacc[t0 + u];
     __syncthreads();
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
+    for (int i = threadIdx.x; i < TG * C; i += 256) {
+      const int u = i / C, ch = i - u * C;
       float s = 0.f;
-      for (int r = 0; r < p.npl; ++r) s += redt[r * C4 + ch];
-      p.ws[((long)blockIdx.x * C + ch) * NT + tp] = s;
+      for (int r = 0; r < p.npl; ++r) s += redt[(u * p.npl + r) * C4 + ch];
+      p.ws[((long)blockIdx.x * C + ch) * NT + t0 + u] = s;
     }
     __syncthreads();
   }
@@ -209,7 +213,7 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
   k.vec = src_vec_ok(a->src) && aligned16(a->dy) && a->lddy % 4 == 0 && (!a->g || (aligned16(a->g) && a->ldg % 4 == 0));
   const int taps = a->KH * a->KW, C4 = k.nq * 4;
   const int rows = dw_rows(k.P, a->src.C);
-  size_t sh = (size_t)(taps * C4 + k.npl * C4 * 4) * sizeof(float);     // tap weights + [npl][C4] reduction panel (fp64 pairs)
+  size_t sh = (size_t)(taps * C4 + k.npl * C4 * 5) * sizeof(float);     // tap weights + [TG<=5][npl][C4] reduction panel (>= the fp64 (dA,dB) panel)
   hipStream_t st = (hipStream_t)stream;
   if (taps == 9) hipLaunchKernelGGL(dw_bwd_kernel<9>, dim3(rows), dim3(256), sh, st, k);
   else if (taps == 25) hipLaunchKernelGGL(dw_bwd_kernel<25>, dim3(rows), dim3(256), sh, st, k);

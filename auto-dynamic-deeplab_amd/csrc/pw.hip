@@ -1,0 +1,219 @@
+// Pointwise (1x1, stride 1) convolution with register-stationary weights — the pointwise halves of SepConv and the
+// 40/80/160-channel glue convs, forward and data gradient.  These launches are far too small to amortise the LDS
+// staging + two barriers per 32-channel chunk of the general implicit-GEMM kernel (measured: 25-30 us each against an
+// HBM-ideal 5-10 us).  Here there is NO LDS and NO barrier in the main loop:
+//   * a wave keeps its whole weight panel as MFMA A-fragments in registers (K <= 160, <= 3 column tiles of 16),
+//   * it walks 16-pixel tiles; the MFMA B-fragment of a tile is loaded straight from global memory, 16 B per lane
+//     (lane (pixel li, quarter kq) holds k = 16g + 4kq + {0..3}; the k order inside a 16-channel group is a permutation
+//     that weights and pixels share, so the sum is unchanged), two tiles in flight per wave,
+//   * the lazy BatchNorm/ReLU prologue is applied to the fragment in registers,
+//   * the epilogue stores 16 B per lane and keeps the BN statistics / (dA,dB) sums in per-lane fp64 registers for the
+//     whole kernel; one butterfly + cross-wave LDS reduction at the very end writes the block's slab row.
+#include "common.h"
+
+namespace {
+
+enum { PW_FWD = 0, PW_DGRAD = 1 };
+
+struct PwK {
+  addk_src src;            // fwd: input (x,a,b,relu); dgrad: dy (no prologue)
+  int K;                   // reduction length (fwd: Cin, dgrad: Cout_fwd)
+  int Cn;                  // GEMM N (fwd: Cout, dgrad: channels of dst)
+  const float* w; int ldw; int w_off;     // fwd: w[(n)*ldw + w_off + k]; dgrad: w[(k)*ldw + w_off + n]
+  float* y; int ldy;
+  const float* bias;
+  double* slab; int slab_ld;
+  addk_src dst; int accumulate;          // dgrad epilogue
+  int P; int ntiles16; int rows;       // rows: slab rows the caller allocated (>= gridDim.x; the extra rows are zero-filled)
+};
+
+template <int CT, int KG, int MODE>     // CT column tiles of 16, KG groups of 16 reduction channels
+__global__ void __launch_bounds__(256) pw_kernel(const PwK p) {
+  __shared__ double red[4][CT * 16][2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.y * (CT * 16);
+
+  // ---- weight panel -> registers (A operand: row = output channel li of tile i, k = 16g + 4kq + e) ----
+  float4 wf[CT][KG];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const int n = n0 + i * 16 + li, k = 16 * g + 4 * kq;
+      float4 v = zero4();
+      if (n < p.Cn) {
+        if (MODE == PW_FWD) {
+          v = ld4g(p.w + (long)n * p.ldw + p.w_off + k, p.K - k, (p.ldw & 3) == 0 && (p.w_off & 3) == 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < p.K) set4(v, e, p.w[(long)(k + e) * p.ldw + p.w_off + n]);
+        }
+      }
+      wf[i][g] = v;
+    }
+  // lazy prologue coefficients of this lane's k slots
+  float4 pa[KG], pb[KG];
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    const int k = 16 * g + 4 * kq;
+    pa[g] = make_float4(1.f, 1.f, 1.f, 1.f); pb[g] = zero4();
+    if (p.src.a && k < p.K) { pa[g] = ld4g(p.src.a + k, p.K - k, true); pb[g] = ld4g(p.src.b + k, p.K - k, true); }
+  }
+  const bool relu = p.src.relu != 0;
+  const bool pro = relu || p.src.a != nullptr;
+
+  double s1[CT][4], s2[CT][4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[i][e] = 0.0; s2[i][e] = 0.0; }
+
+  const int wstride = gridDim.x * 4;
+  float4 xf[KG], xn[KG];
+  auto load_tile = [&](int tile, float4 (&x)[KG]) {
+    const int pp = tile * 16 + li;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const int k = 16 * g + 4 * kq;
+      x[g] = (pp < p.P && k < p.K) ? ld4g(p.src.x + (long)pp * p.src.ld + k, p.K - k, true) : zero4();
+    }
+  };
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < p.ntiles16) load_tile(tile, xf);
+  for (; tile < p.ntiles16; tile += wstride) {
+    const int nxt = tile + wstride;
+    if (nxt < p.ntiles16) load_tile(nxt, xn);
+    const int pp = tile * 16 + li;
+    if (pro) {
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        float4 v = xf[g];
+        v.x = fmaf(pa[g].x, v.x, pb[g].x); v.y = fmaf(pa[g].y, v.y, pb[g].y); v.z = fmaf(pa[g].z, v.z, pb[g].z); v.w = fmaf(pa[g].w, v.w, pb[g].w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const int nrem = p.K - (16 * g + 4 * kq);
+        if (pp >= p.P || nrem <= 0) v = zero4();
+        else if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
+        xf[g] = v;
+      }
+    }
+    f32x4 acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(wf[i][g], e), get4(xf[g], e), acc[i], 0, 0, 0);
+    }
+    // ---- epilogue: lane holds channels n0 + i*16 + kq*4 + {0..3} of pixel pp ----
+    if (pp < p.P) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int c = n0 + i * 16 + kq * 4;
+        const int nrem = p.Cn - c;
+        if (nrem <= 0) continue;
+        float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        if (MODE == PW_FWD) {
+          if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+          st4g(p.y + (long)pp * p.ldy + c, v, nrem, true);
+          if (p.slab) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double f = e < nrem ? (double)get4(v, e) : 0.0; s1[i][e] += f; s2[i][e] += f * f; }
+          }
+        } else {
+          float4 x = ld4g(p.dst.x + (long)pp * p.dst.ld + c, nrem, true);
+          float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+          if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, true); bv = ld4g(p.dst.b + c, nrem, true); }
+          float4 g4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), dz = get4(v, e);
+            const bool m = (e < nrem) && (!p.dst.relu || fmaf(ae, xe, be) > 0.f);
+            set4(g4, e, m ? dz * ae : 0.f);
+            if (p.slab && m) { s1[i][e] += (double)dz * (double)xe; s2[i][e] += (double)dz; }
+          }
+          float* gp = p.y + (long)pp * p.ldy + c;
+          if (p.accumulate) { float4 o = ld4g(gp, nrem, true); g4.x += o.x; g4.y += o.y; g4.z += o.z; g4.w += o.w; }
+          st4g(gp, g4, nrem, true);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) xf[g] = xn[g];
+  }
+
+  if (p.slab) {     // once per kernel: butterfly over the 16 pixel lanes, then the four waves through LDS (fixed order)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double a = s1[i][e], b = s2[i][e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = a; red[wave][i * 16 + kq * 4 + e][1] = b; }
+      }
+    __syncthreads();
+    if (t < CT * 16 && n0 + t < p.Cn) {
+      double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+      o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
+      o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
+      for (int r = blockIdx.x + gridDim.x; r < p.rows; r += gridDim.x) {     // rows no workgroup owns
+        double* z = p.slab + ((long)r * p.slab_ld + n0 + t) * 2;
+        z[0] = 0.0; z[1] = 0.0;
+      }
+    }
+  }
+}
+
+template <int MODE>
+int pw_launch(PwK& k, int rows, hipStream_t st) {
+  const int kg = cdiv(k.K, 16);
+  // up to 3 column tiles per block (K <= 80: <= 60 weight VGPRs)
+  int ct = 3;
+  if (cdiv(k.Cn, 16) < ct) ct = cdiv(k.Cn, 16);
+  if (ct < 1) ct = 1;
+  k.rows = rows;
+  int gx = rows;                           // measured: fewer, fatter workgroups are slower (14 -> 36 us); parallelism wins
+  if (gx > cdiv(k.ntiles16, 4)) gx = cdiv(k.ntiles16, 4);
+  if (gx < 1) gx = 1;
+  dim3 grid(gx, cdiv(k.Cn, 16 * ct));
+#define ADDK_PW(CT_, KG_) \
+  if (ct == CT_ && kg == KG_) { hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE>), grid, dim3(256), 0, st, k); return addk_check_launch("pw_conv"); }
+  ADDK_PW(1, 3) ADDK_PW(2, 3) ADDK_PW(3, 3)
+  ADDK_PW(1, 5) ADDK_PW(2, 5) ADDK_PW(3, 5)
+#undef ADDK_PW
+  return 1;       // no instantiation: caller falls back to the general kernel
+}
+
+}  // namespace
+
+// Returns 0 when the launch was taken, 1 when the shape is not covered (caller falls back), <0 on error.
+int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream) {
+  if (a->nsrc != 1 || a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->bias_n) return 1;
+  const addk_src& s = a->src[0];
+  const int kg = cdiv(s.C, 16);
+  if (!(kg == 3 || kg == 5) || !src_vec_ok(s) || !aligned16(a->y) || a->ldy % 4 || a->Cout % 4 || a->H != a->OH || a->W != a->OW) return 1;
+  if (!aligned16(a->w)) return 1;
+  PwK k{};
+  k.src = s; k.K = s.C; k.Cn = a->Cout; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
+  k.y = a->y; k.ldy = a->ldy; k.bias = a->bias;
+  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.P = a->N * a->OH * a->OW; k.ntiles16 = cdiv(k.P, 16);
+  return pw_launch<PW_FWD>(k, rows, (hipStream_t)stream);
+}
+
+int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
+  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->H != a->OH || a->W != a->OW) return 1;
+  const int kg = cdiv(a->Cout, 16);
+  addk_src dy{a->dy, nullptr, nullptr, a->lddy, a->Cout, 0, 0};
+  if (!(kg == 3 || kg == 5) || !src_vec_ok(dy) || !src_vec_ok(a->dst) || !aligned16(a->g) || a->ldg % 4) return 1;
+  PwK k{};
+  k.src = dy; k.K = a->Cout; k.Cn = a->dst.C; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
+  k.y = a->g; k.ldy = a->ldg; k.slab = (double*)a->dab; k.slab_ld = a->dst.C;
+  k.dst = a->dst; k.accumulate = a->accumulate;
+  k.P = a->N * a->H * a->W; k.ntiles16 = cdiv(k.P, 16);
+  return pw_launch<PW_DGRAD>(k, rows, (hipStream_t)stream);
+}

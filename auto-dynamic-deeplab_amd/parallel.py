@@ -14,9 +14,10 @@ from . import module as _module
 
 
 class SyncBNComm:
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         assert dist.is_initialized(), 'init_process_group first'
         self.group = group
+        self.force = force          # run the exchange even at world_size 1 (exercises the N>1 kernels on one GPU)
         self.size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.calls = 0
@@ -34,9 +35,9 @@ class SyncBNComm:
         g._add(lst, 'allreduce', self._allreduce, t, rd=[vec], wr=[vec], pin=True)     # RCCL call: main stream only
 
 
-def init_sync_bn(group=None):
+def init_sync_bn(group=None, force=False):
     """Enable cross-rank statistics for every SynchronizedBatchNorm2d emitted from now on."""
-    comm = SyncBNComm(group)
+    comm = SyncBNComm(group, force)
     _module.set_world(comm)
     return comm
 

@@ -523,7 +523,7 @@ class Graph:
         bet = self.param(mod.bias) if mod.bias is not None else None
         if training:
             st.mean, st.invstd = self.vec(Cc), self.vec(Cc)
-            sync = self.world is not None and getattr(mod, 'sync', False) and self.world.size > 1
+            sync = self.world is not None and getattr(mod, 'sync', False) and (self.world.size > 1 or self.world.force)
             fa = L.BnFinalizeArgs()
             if sync:
                 red = self.vec(4 * Cc)      # fp64 [C][2]
@@ -575,7 +575,7 @@ class Graph:
                     pg = []
                 rd_bn = [sl for sl, _ in st.slabs] + [mod.weight, st.mean, st.invstd, a]
                 c1, c2 = self.vec(Cc), self.vec(Cc)
-                sync = self.world is not None and getattr(mod, 'sync', False) and self.world.size > 1
+                sync = self.world is not None and getattr(mod, 'sync', False) and (self.world.size > 1 or self.world.force)
                 self.keep.append(ba)
                 if sync:
                     dmv = self.vec(2 * Cc)

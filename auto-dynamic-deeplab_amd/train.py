@@ -52,6 +52,7 @@ class TrainStep:
         self.x = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
         self.target = torch.zeros((N, H, W), dtype=torch.int64, device=dev)
         self.world = sync_comm.size if sync_comm is not None else 1
+        self.comm = sync_comm
         g = self.g = Graph(dev, True, True, sync_comm)
         g.pgrad_views = gviews
         a, self.inref = g.input_nchw(self.x)
@@ -85,7 +86,8 @@ class TrainStep:
         self.n_active = self.flat_p.numel()
         self.nbytes = g.nbytes
         if use_graph is None:
-            use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (self.world == 1 or os.environ.get('ADDK_GRAPH_DDP', '0') == '1')
+            has_coll = sync_comm is not None and (self.world > 1 or sync_comm.force)
+            use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (not has_coll or os.environ.get('ADDK_GRAPH_DDP', '0') == '1')
         self.graph = None
         self.use_graph = use_graph
         self.steps = 0

@@ -115,6 +115,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--math', choices=['fp32', 'bf16x3'], default='fp32', help='dense-conv arithmetic (default: exact fp32 MFMA)')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--force-sync', action='store_true', help='rehearse the N>1 path (RCCL SyncBN + gradient all-reduce) at world_size 1')
     a = ap.parse_args()
     if a.cpu_baseline_child:
         g = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
@@ -133,13 +134,16 @@ def main():
     from addk import parallel
     addk.set_precision(a.math)
     comm = None
-    if world > 1:
+    if world > 1 or a.force_sync:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend='nccl', init_method='env://')
-        comm = parallel.init_sync_bn()
+        comm = parallel.init_sync_bn(force=a.force_sync)
     genotype = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
     torch.manual_seed(1)
-    model = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=world > 1), 0).to(dev)
+    model = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=comm is not None), 0).to(dev)
     parallel.broadcast_params(model)
     n, h, w = a.batch, a.height, a.width
     ts = TrainStep(model, (n, 3, h, w), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm,
@@ -166,6 +170,7 @@ def main():
         dt = float(tt.item())
     loss = float(ts.loss.item())
     if rank != 0:
+        torch.distributed.destroy_process_group()
         return
     ms = dt / a.steps * 1e3
     value = world * n * a.steps / dt
@@ -190,7 +195,7 @@ def main():
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.math == 'fp32' else 'f32 storage, split-bf16 (3-term) MFMA products, f32 accumulate', 'data': 'synthetic',
            'config': {'workload': 'ADD F=%d searched_arch/autodeeplab C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, h, w, n),
-                      'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': world > 1,
+                      'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': comm is not None,
                       'hip_graph': bool(ts.graph is not None)},
            'loss': loss,
            'step_algorithmic_tflop': 3 * fwd_flops / 1e12,
@@ -199,7 +204,9 @@ def main():
            'roofline': roof}
     if not a.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(genotype, n, h, w)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

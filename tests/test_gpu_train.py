@@ -125,3 +125,46 @@ def test_evaluator_and_argmax(dev, golden):
     assert abs(float(ev.Frequency_Weighted_Intersection_over_Union()) - float(g['eval/fwiou'])) < 1e-6
     x = rand_tensor(4, 'am', (2, 19, 17, 33))
     assert torch.equal(argmax_logits(x.to(dev)).cpu(), x.argmax(1))
+
+
+def test_syncbn_path_world1_matches_local_bn(dev):
+    """The N>1 code path on one GPU: SynchronizedBatchNorm2d + RCCL (world_size 1, exchange forced) must reproduce the
+    local-BatchNorm step (slab_reduce -> all_reduce -> bn_finalize, bn_bwd -> all_reduce(dmean,dvar) -> coefficients,
+    flat-gradient all-reduce) to rounding."""
+    import os
+    import torch.distributed as dist
+    from addk import parallel
+    from addk.modeling.ADD import ADD
+    from addk.train import TrainStep
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29611')
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        x, t = _batch(2, (65, 129))
+        res = {}
+        for sync in (False, True):
+            args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4, sync_bn=sync), 0)
+            mo = oracle.ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4), 0)
+            fill_params(mo, 600)
+            m = ADD(*args)
+            m.load_state_dict(mo.state_dict())
+            m.to(dev)
+            comm = parallel.init_sync_bn(force=True) if sync else None
+            ts = TrainStep(m, (2, 3, 65, 129), use_graph=False, sync_comm=comm)
+            ts.load_batch(x.to(dev), t.to(dev))
+            ts.forward_backward_only()
+            g0, l0 = ts.flat_g.clone(), ts.loss.item()
+            losses = [ts.step().item() for _ in range(2)]
+            res[sync] = (l0, g0, losses, comm.calls if comm else 0)
+            parallel.disable_sync_bn()
+        assert res[True][3] == 3 * 624                      # 312 forward + 312 backward exchanges per pass
+        assert abs(res[True][0] - res[False][0]) < 1e-6 * abs(res[False][0])           # forward: same statistics
+        gs, gl = res[True][1].double(), res[False][1].double()
+        assert float((gs - gl).norm() / gl.norm()) < 1e-3                                # backward: same gradient (rounding only)
+        # later steps drift apart chaotically (fp32 rounding of the exchanged (dmean, dvar) amplified by the network)
+        assert abs(res[True][2][0] - res[False][2][0]) < 1e-6 * abs(res[False][2][0])
+        assert abs(res[True][2][1] - res[False][2][1]) < 1e-3 * abs(res[False][2][1])
+    finally:
+        parallel.disable_sync_bn()
+        dist.destroy_process_group()
