@@ -55,6 +55,10 @@ class BnFinalizeArgs(C.Structure):
                 ('mean', vp), ('invstd', vp)]
 
 
+class BnEvalEntry(C.Structure):
+    _fields_ = [('gamma', vp), ('beta', vp), ('rm', vp), ('rv', vp), ('a', vp), ('b', vp), ('C', i32), ('eps', f32)]
+
+
 class BnBwdArgs(C.Structure):
     _fields_ = [('slab', vp * MAX_SLAB), ('rows', i32 * MAX_SLAB), ('nslab', i32), ('C', i32), ('count', f64),
                 ('gamma', vp), ('mean', vp), ('invstd', vp), ('a', vp), ('dgamma', vp), ('dbeta', vp),
@@ -102,6 +106,7 @@ _SIGS = {
     'addk_bn_finalize': (i32, [C.POINTER(BnFinalizeArgs), vp]),
     'addk_slab_reduce': (i32, [vp, i32, i32, vp, vp]),
     'addk_bn_eval_affine': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
+    'addk_bn_eval_affine_batch': (i32, [vp, i32, vp]),
     'addk_bn_bwd': (i32, [C.POINTER(BnBwdArgs), vp]),
     'addk_bn_bwd_coeffs_from_dmv': (i32, [vp, i32, f64, vp, vp, vp]),
     'addk_affine_sum_fwd': (i32, [C.POINTER(AffineSumArgs), vp]),

@@ -81,6 +81,17 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
   }
 }
 
+// eval mode, all BatchNorms of a plan in one launch: block b handles table entry b
+struct BnEvalEntry { const float* gamma; const float* beta; const float* rm; const float* rv; float* a; float* b; int C; float eps; };
+__global__ void bn_eval_affine_batch_kernel(const BnEvalEntry* __restrict__ tab) {
+  const BnEvalEntry e = tab[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+    float g = e.gamma ? e.gamma[c] : 1.f, be = e.beta ? e.beta[c] : 0.f;
+    float s = g / sqrtf(e.rv[c] + e.eps);
+    e.a[c] = s; e.b[c] = be - e.rm[c] * s;
+  }
+}
+
 __global__ void __launch_bounds__(1024) bn_bwd_kernel(const addk_bn_bwd_args p) {
   __shared__ double sh[32][32][2];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -144,4 +155,10 @@ extern "C" int addk_bn_bwd_coeffs_from_dmv(const float* dmv, int32_t C, double c
   ADDK_REQUIRE(dmv && c1 && c2 && C > 0 && count > 0, "bn_bwd_coeffs: bad args");
   hipLaunchKernelGGL(bn_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dmv, C, count, c1, c2);
   return addk_check_launch("bn_bwd_coeffs");
+}
+
+extern "C" int addk_bn_eval_affine_batch(const void* dev_table, int32_t n, void* stream) {
+  ADDK_REQUIRE(dev_table && n > 0, "bn_eval_affine_batch: bad args");
+  hipLaunchKernelGGL(bn_eval_affine_batch_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const BnEvalEntry*>(dev_table));
+  return addk_check_launch("bn_eval_affine_batch");
 }

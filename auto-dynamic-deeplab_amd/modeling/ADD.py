@@ -205,9 +205,11 @@ class ADD(AddkModule):
 
     # ---- trunk shared by forward / get_feature / dynamic_inference (ADD.py:283-308) ----
     def _trunk(self, g, x):
+        g.tag = 'stem'
         two = list(_emit_stems(self, g, x))
         dense, low, cur = [], None, None
         for i in range(self.num_net):
+            g.tag = 'cell'
             if i < 3:
                 two[0], two[1], fm = self.cells[i].emit(g, two[0], two[1])
                 dense.append(fm)
@@ -222,8 +224,10 @@ class ADD(AddkModule):
                 cur = self.cells[i].emit(g, list(dense[:-1]), cur)
             if i == self.low_level_layer:
                 lc = self.low_level_conv
+                g.tag = 'low'
                 low = g.conv_bn([two[1]], lc[1], lc[2], relu_in=True)
             y = cur if i > 2 else two[1]
+            g.tag = 'head'
             got = yield i, y, low
             if got is not None:                 # EDM's in-place ReLU mutated the feature (Q3)
                 if i > 2:
@@ -232,11 +236,14 @@ class ADD(AddkModule):
                     two[1] = got
 
     def _head(self, g, y, low, size, aspp_size, it, level, resize=True, adapt=True):
+        g.tag = 'aspp'
         if resize and (y.H < aspp_size[0] or y.W < aspp_size[1]):
             y = g.resize(y, aspp_size[0], aspp_size[1])
         if adapt and level != self.network_arch[-1]:
             y = self.conv_aspp[it].emit(g, y)
-        return self.decoder.emit(g, self.aspp.emit(g, y), low, size)
+        y = self.aspp.emit(g, y)
+        g.tag = 'decoder'
+        return self.decoder.emit(g, y, low, size)
 
     def emit(self, g, x):
         """reference ADD.py:277-325."""

@@ -96,12 +96,12 @@ class Act:
 class Cmd:
     """One kernel launch of a plan: fn(*args, stream).  `rd`/`wr` are the memory regions it reads / writes
     (keys from `_region`), used to schedule independent launches on parallel HIP streams."""
-    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin')
+    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag')
 
     def __init__(self, name, fn, args, rd=(), wr=(), pin=False):
         self.name, self.fn, self.args = name, fn, list(args)
         self.rd, self.wr = [k for k in (_region(x) for x in rd) if k], [k for k in (_region(x) for x in wr) if k]
-        self.stream, self.waits, self.event, self.pin = 0, (), None, pin
+        self.stream, self.waits, self.event, self.pin, self.tag = 0, (), None, pin, ''
 
     def __iter__(self):                # unpacks like the (name, fn, args) triple it replaces
         return iter((self.name, self.fn, self.args))
@@ -193,6 +193,8 @@ class Graph:
         self.nbytes = 0
         self._bufs = []               # owns every device buffer: kernels only see raw pointers
         self.nstreams = 1             # set by finalize(nstreams=k)
+        self.tag = ''                 # segment label stamped on emitted commands (stem / cell / low / aspp / decoder)
+        self._evalbn, self._evalbn_cmd = [], None
         self.meta = []                # per-launch algorithmic work of the dense convs (bench / roofline)
 
     # ---------------- memory ----------------
@@ -272,6 +274,13 @@ class Graph:
             em()
         self._bwd_emitters = []
         self.nstreams = max(1, int(nstreams))
+        if self._evalbn:
+            n = len(self._evalbn)
+            arr = (L.BnEvalEntry * n)(*self._evalbn)
+            host = torch.frombuffer(arr, dtype=torch.uint8)
+            tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
+            self.keep += [arr, tab]
+            self._evalbn_cmd.args[0], self._evalbn_cmd.args[1] = tab.data_ptr(), n
         self._emit_batched_wgrads()
         for lst in (self.fwd, self.bwd):
             for i, c in enumerate(lst):
@@ -331,6 +340,7 @@ class Graph:
     # ---------------- command helpers ----------------
     def _add(self, lst, name, fn, *args, rd=(), wr=(), pin=False):
         c = Cmd(name, fn, args, rd, wr, pin)
+        c.tag = self.tag
         lst.append(c)
         return c
 
@@ -547,9 +557,15 @@ class Graph:
                       rd=[red if sync else slab, mod.weight, mod.bias],
                       wr=[a, b, st.mean, st.invstd] + ([mod.running_mean, mod.running_var] if fa.running_mean else []))
         else:
-            self._add(self.fwd, 'bn_eval_affine', lib.addk_bn_eval_affine, gam, bet, mod.running_mean.data_ptr(),
-                      mod.running_var.data_ptr(), mod.eps, Cc, a.ptr, b.ptr,
-                      rd=[mod.weight, mod.bias, mod.running_mean, mod.running_var], wr=[a, b])
+            # inference: (a, b) of ALL BatchNorms come from one batched launch placed where the first one is emitted
+            e = L.BnEvalEntry()
+            e.gamma, e.beta, e.rm, e.rv = gam, bet, mod.running_mean.data_ptr(), mod.running_var.data_ptr()
+            e.a, e.b, e.C, e.eps = a.ptr, b.ptr, Cc, mod.eps
+            if not self._evalbn:
+                self._evalbn_cmd = self._add(self.fwd, 'bn_eval_affine_batch', lib.addk_bn_eval_affine_batch, None, 0)
+            self._evalbn.append(e)
+            self._evalbn_cmd.rd += [_region(t) for t in (mod.weight, mod.bias, mod.running_mean, mod.running_var) if t is not None]
+            self._evalbn_cmd.wr += [_region(a), _region(b)]
         act = Act(raw, st, post_relu, needs_grad and self.want_grad)
 
         if self.want_grad and training:

@@ -179,6 +179,10 @@ int addk_slab_reduce(const double* partial, int32_t rows, int32_t C, double* out
 int addk_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                         float eps, int32_t C, float* a, float* b, void* stream);
 
+/* The same for every BatchNorm of an inference plan in ONE launch: `dev_table` is a device array of n entries
+ * {gamma, beta, running_mean, running_var, a, b (pointers), int32 C, float eps} (56 bytes each). */
+int addk_bn_eval_affine_batch(const void* dev_table, int32_t n, void* stream);
+
 /* Backward of the statistics + affine:  given the partial (dA,dB) slabs of every consumer,
  *   dgamma (+)= invstd*(dA - mean*dB), dbeta (+)= dB,
  *   dmean_tot = -a*dB - 2*mean*dvar,  dvar = -0.5*gamma*(dA-mean*dB)*invstd^3,
