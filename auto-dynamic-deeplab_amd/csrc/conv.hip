@@ -41,6 +41,10 @@ struct ConvK {
   int red32;        // 1: per-tile lane reduction in fp32 (large P); 0: fp64 end to end (tiny batches, e.g. the 2-sample ASPP pool BN)
   long P;
   int ntiles;
+  // strided dgrad, one launch per input-pixel parity class: M-side pixels are (sub*i+ph, sub*j+pw) on an MH x MW grid
+  // and only the taps of `taplist` can reach them (kill: the class has no tap at all -> zero gradient)
+  int sub, ph, pw, MH, MW, ntaps_l, kill;
+  int taplist[9];
 };
 
 constexpr int BK = 32;
@@ -84,8 +88,10 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   const int li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.y * BC;
   const int aq = t & 7, ar = t >> 3;
-  const int ntaps = p.KH * p.KW;
-  const int ohw = p.OH * p.OW;
+  const bool cls = MODE == MODE_DGRAD && p.sub > 1;
+  const int ntaps = cls ? p.ntaps_l : p.KH * p.KW;
+  const int ohw = cls ? p.MH * p.MW : p.OH * p.OW;
+  const int mw = cls ? p.MW : p.OW;
   const int P32 = (int)p.P;
   double tot0 = 0.0, tot1 = 0.0;
   // per-slot weight offsets (fixed for the whole kernel); -1 marks a slot outside the tile
@@ -117,7 +123,8 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       if (pp < P32) {
         int n = pp / ohw;
         int rem = pp - n * ohw;
-        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        int oh = rem / mw, ow = rem - oh * mw;
+        if (cls) { oh = oh * p.sub + p.ph; ow = ow * p.sub + p.pw; }
         rn[j] = n;
         if (MODE == MODE_FWD) { rh[j] = oh * p.stride - p.pad; rw[j] = ow * p.stride - p.pad; }
         else                  { rh[j] = oh + p.pad;            rw[j] = ow + p.pad; }
@@ -135,8 +142,9 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
     unsigned amask = 0;          // bit j: ra[j] holds an in-bounds pixel (the lazy prologue applies; padding stays 0)
     int s = 0, tap = 0, c0 = 0, choff = 0;
 
-    auto load_chunk = [&](int s_, int tap_, int c0_, int choff_) {
+    auto load_chunk = [&](int s_, int tapi_, int c0_, int choff_) {
       const addk_src S = p.src[s_];
+      const int tap_ = cls ? p.taplist[tapi_] : tapi_;
       const int kh = tap_ / p.KW, kw = tap_ - kh * p.KW;
       const int c = c0_ + 4 * aq;
       const int nrem = S.C - c;          // valid channels from c on
@@ -160,7 +168,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
             poff = roff[j] + tapoff;
           } else {
             const int th = rh[j] - dh, tw = rw[j] - dw;
-            ok = th >= 0 && tw >= 0 && (th % p.stride == 0) && (tw % p.stride == 0);
+            ok = th >= 0 && tw >= 0 && (th % p.stride == 0) && (tw % p.stride == 0) && !(cls && p.kill);
             const int ih = th / p.stride, iw = tw / p.stride;
             ok = ok && ih < p.H && iw < p.W;
             poff = ((long)rn[j] * p.H + ih) * p.W + iw;
@@ -336,8 +344,12 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
-        const int pp = tile * BP + (wave * PT + j) * 16 + li;
+        int pp = tile * BP + (wave * PT + j) * 16 + li;
         const bool pv = pp < P32 && nrem > 0;
+        if (cls && pv) {      // class-local pixel -> position in the full gradient map
+          const int n = pp / ohw, rem = pp - n * ohw, i2 = rem / mw, j2 = rem - i2 * mw;
+          pp = (n * p.OH + i2 * p.sub + p.ph) * p.OW + j2 * p.sub + p.pw;
+        }
         float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         if (MODE == MODE_FWD) {
           if (pv) {
@@ -446,13 +458,13 @@ bool pw_enabled() {
 }
 
 template <int MODE>
-int launch(ConvK& k, hipStream_t st) {
+int launch(ConvK& k, hipStream_t st, int grid_x = 0) {
   const int pt = pick_pt(k.P);
   const int BP = 64 * pt;
   k.ntiles = cdiv(k.P, BP);
   k.red32 = k.P >= 4096;
   const int ct = pick_ct(k.Cn, k.ntiles);
-  dim3 grid(addk_conv_rows(k.P, k.Cn), cdiv(k.Cn, 16 * ct));   // workgroups beyond ntiles only write their (zero) slab row
+  dim3 grid(grid_x > 0 ? grid_x : addk_conv_rows(k.P, k.Cn), cdiv(k.Cn, 16 * ct));   // workgroups beyond ntiles only write their (zero) slab row
   const int prec = conv_precision();
 #define ADDK_CASE(PT_, CT_) \
   if (pt == PT_ && ct == CT_) { \
@@ -525,6 +537,7 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
   k.Cn = a->Cout; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.ldy = a->ldy;
   k.w = a->w; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n; k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
   k.accumulate = 0; k.dst = addk_src{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  k.sub = 1; k.ph = k.pw = 0; k.MH = k.MW = 0; k.ntaps_l = 0; k.kill = 0;
   bool chan4 = true;
   for (int i = 0; i < a->nsrc; ++i) chan4 = chan4 && (a->src[i].C % 4 == 0);
   k.vecB = aligned16(a->w) && a->ldw % 4 == 0 && a->cin_total % 4 == 0 && a->w_choff % 4 == 0 && chan4;
@@ -558,5 +571,30 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
   k.vecY = aligned16(a->g) && a->ldg % 4 == 0 && src_vec_ok(a->dst);
   k.P = (long)a->N * a->H * a->W;
   ADDK_REQUIRE(k.P < (1L << 30) && (long)a->N * a->OH * a->OW < (1L << 30), "conv_dgrad: tensor too large for 32-bit pixel indexing");
+  k.sub = 1; k.ph = k.pw = 0; k.MH = k.MW = 0; k.ntaps_l = 0; k.kill = 0;
+  const int rows = addk_conv_rows(k.P, a->dst.C);
+  if (a->stride == 2 && a->KH * a->KW <= 9 && rows % 4 == 0 && a->H >= 2 && a->W >= 2) {
+    // Stride 2: an input pixel only receives the taps whose offset matches its parity, (1,2,2,4) of the 9 taps of a 3x3
+    // for the four (row, column) parity classes.  One launch per class over that class's quarter of the pixels does
+    // 9/4 tap-chunks per pixel instead of 9 masked ones; each class writes its own quarter of the (dA,dB) slab rows.
+    const long Pfull = k.P;
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) {
+        ConvK c = k;
+        c.sub = 2; c.ph = ph; c.pw = pw;
+        c.MH = (a->H - ph + 1) / 2; c.MW = (a->W - pw + 1) / 2;
+        c.P = (long)a->N * c.MH * c.MW;
+        c.ntaps_l = 0;
+        for (int kh = 0; kh < a->KH; ++kh)
+          for (int kw = 0; kw < a->KW; ++kw)
+            if ((ph + a->pad - kh * a->dil) % 2 == 0 && (pw + a->pad - kw * a->dil) % 2 == 0) c.taplist[c.ntaps_l++] = kh * a->KW + kw;
+        if (c.ntaps_l == 0) { c.taplist[0] = 0; c.ntaps_l = 1; c.kill = 1; }
+        if (c.slab) c.slab = k.slab + (long)(ph * 2 + pw) * (rows / 4) * k.slab_ld * 2;
+        int rc = launch<MODE_DGRAD>(c, (hipStream_t)stream, rows / 4);
+        if (rc) return rc;
+      }
+    (void)Pfull;
+    return ADDK_OK;
+  }
   return launch<MODE_DGRAD>(k, (hipStream_t)stream);
 }

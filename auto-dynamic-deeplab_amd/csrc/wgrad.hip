@@ -6,6 +6,7 @@
 // order [pixel][channel]; MFMA fragments are read with ds_read_b32, rows padded so that the two pixel
 // rows a 32-lane group touches fall on disjoint banks).  Wave partials are combined through LDS in a
 // fixed order and the per-slice tiles go to a workspace that addk reduces deterministically into dW.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -309,6 +310,163 @@ __global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK pv, const WgK* 
       }
 }
 
+// Halo-patch variant for the wide 3x3 stride-1 convolutions (decoder, ASPP dilated branches, stem1): a block owns
+// (64*NT output channels) x (16 input channels) x ALL NINE taps and walks its pixel range one 64-pixel row segment at a
+// time.  Per segment it stages dy[64 px][64*NT] once and the three activation rows oh-d, oh, oh+d of the 16 channels
+// ([3][64+2d px][16], BatchNorm/ReLU applied on the way in, zero padding after it) once, and every tap reads its
+// shifted window of that patch from LDS: 64*NT + 48 floats fetched per pixel for 9*16*64*NT MACs, against 64*NT+64 per
+// pixel PER TAP for the per-tap kernels above (2.5x the arithmetic intensity at NT=2, 1/9 of the global load
+// instructions).  Wave w keeps co tiles [w*NT, w*NT+NT) x 9 taps = 9*NT 16x16 accumulators.
+constexpr int H3_KP = 64;
+constexpr int H3_ZW = H3_KP + 2 * 18;       // widest patch row (dilation 18)
+
+template <int NT, bool BATCH>
+__global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
+  if (BATCH) {
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK& p = BATCH ? ops[op] : pv;
+  constexpr int BCO = 64 * NT, LY = BCO + 16, YQ = BCO / 4, YRS = 256 / YQ;
+  constexpr int NYJ = H3_KP / YRS;
+  constexpr int NZJ = (3 * H3_ZW * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Ys[H3_KP * LY];
+  __shared__ __attribute__((aligned(16))) float Zs[3 * H3_ZW * 16];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
+  const int co0 = yt * BCO, c0 = zt * 16;
+  const int d = p.dil, ZW = H3_KP + 2 * d;
+  const int spr = (p.OW + H3_KP - 1) / H3_KP;          // segments per image row
+  const int nseg = p.N * p.OH * spr;
+  const int sbeg = blk_y * p.chunkP;
+  int send = sbeg + p.chunkP; if (send > nseg) send = nseg;
+
+  // fixed slot geometry
+  const int yq = t & (YQ - 1), yrow0 = t / YQ;
+  const int co = co0 + 4 * yq;
+  const bool co_ok = co < p.Cout;
+  const int zq = t & 3, zc = c0 + 4 * zq, nremz = p.src.C - zc;
+  int zr[NZJ], zj[NZJ];
+#pragma unroll
+  for (int k = 0; k < NZJ; ++k) {
+    const int pix = (t + 256 * k) >> 2;
+    zr[k] = pix / ZW; zj[k] = pix - zr[k] * ZW;         // zr >= 3 marks a slot outside the patch
+  }
+  float4 za = make_float4(1.f, 1.f, 1.f, 1.f), zb = zero4();
+  if (p.src.a && nremz > 0) { za = ld4g(p.src.a + zc, nremz, p.vecZ); zb = ld4g(p.src.b + zc, nremz, p.vecZ); }
+  const bool zrelu = p.src.relu != 0;
+  int zbase[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) zbase[tap] = (((tap / 3) * H3_ZW) + kq + (tap % 3) * d) * 16 + li;
+
+  f32x4 acc[NT][9];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Branch-free staging: every slot always issues its 16-byte load (from a safe address when it is masked) so the
+  // loads of a step go out back to back; masked slots are zeroed when they are written to LDS.
+  float4 ry[NYJ], rz[NZJ];
+  unsigned ymask = 0, zmask = 0;
+  auto load_step = [&](int seg) {
+    const int rowid = seg / spr, sx = seg - rowid * spr;
+    const int n = rowid / p.OH, oh = rowid - n * p.OH;
+    const int ow0 = sx * H3_KP;
+    const long pp0 = (long)rowid * p.OW + ow0;
+    const float* yb = p.dy + pp0 * p.lddy + co;
+    ymask = 0; zmask = 0;
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      const int row = yrow0 + k * YRS;
+      const bool ok = co_ok && ow0 + row < p.OW;
+      ry[k] = ld4(ok ? yb + (long)row * p.lddy : p.dy);
+      ymask |= (ok ? 1u : 0u) << k;
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      const int ih = oh + (zr[k] - 1) * d, iw = ow0 - d + zj[k];
+      const bool ok = zr[k] < 3 && nremz > 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rz[k] = ld4(ok ? p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + zc : p.src.x);
+      zmask |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      float4 v = ry[k];
+      const bool ok = (ymask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      st4(&Ys[(yrow0 + k * YRS) * LY + 4 * yq], v);
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      float4 v = rz[k];
+      v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
+      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const bool ok = (zmask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (zr[k] < 3) st4(&Zs[(zr[k] * H3_ZW + zj[k]) * 16 + 4 * zq], v);
+    }
+  };
+
+  if (sbeg < send) {
+    load_step(sbeg);
+    store_step();
+    __syncthreads();
+    const float* yw = &Ys[kq * LY + wave * NT * 16 + li];
+    for (int seg = sbeg; seg < send; ++seg) {
+      const bool more = seg + 1 < send;
+      if (more) load_step(seg + 1);
+      // software-pipelined fragment reads: the LDS reads of k-step s+1 are in flight while the 9*NT MFMAs of k-step s issue
+      float yfA[NT], zfA[9], yfB[NT], zfB[9];
+      auto rd = [&](int s4, float* yf, float* zf) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) yf[i] = yw[s4 * 4 * LY + i * 16];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) zf[tap] = Zs[zbase[tap] + s4 * 64];
+      };
+      auto mma = [&](const float* yf, const float* zf) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+            acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[i], zf[tap], acc[i][tap], 0, 0, 0);
+      };
+      rd(0, yfA, zfA);
+#pragma unroll
+      for (int s4 = 0; s4 < H3_KP / 4; s4 += 2) {
+        rd(s4 + 1, yfB, zfB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(yfA, zfA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s4 + 2 < H3_KP / 4) rd(s4 + 2, yfA, zfA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(yfB, zfB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      if (more) { store_step(); __syncthreads(); }
+    }
+  }
+  const int C = p.src.C;
+  float* wsb = p.ws + (long)blk_y * p.Cout * 9 * C;
+  const int c = c0 + li;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cow = co0 + (wave * NT + i) * 16 + kq * 4 + r;
+      if (cow < p.Cout && c < C) {
+        float* o = wsb + (long)cow * 9 * C + c;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) o[tap * C] = acc[i][tap][r];
+      }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* ws, int splits, int Cout, int taps, int C, float* dw, int ldw,
                                     int cin_total, int w_choff, int accumulate) {
   long n = (long)Cout * taps * C;
@@ -410,6 +568,44 @@ void pick_tiles(int Cout, int C, int* cty, int* ctz) {
   }
 }
 bool use_output_split(int Cout, int C) { return os_kind(Cout, C) != 0; }
+// 5: halo-patch kernel (3x3, stride 1, 'same' padding, wide): tiles are (64*NT co) x (16 c), the nine taps live in the block
+bool h3_ok(const addk_conv_wgrad_args* a) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ADDK_WGRAD_H3"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == a->dil && a->dil >= 1 && a->dil <= 18 &&
+         a->OH == a->H && a->OW == a->W && a->Cout % 64 == 0 && a->src.C >= 16 &&
+         aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) && (long)a->N * a->H * a->W >= 8192;
+}
+int kind_of(const addk_conv_wgrad_args* a) { return h3_ok(a) ? 5 : os_kind(a->Cout, a->src.C); }
+// Halo-patch scheduling.  A block runs `steps` row segments; blocks are dispatched in grid order as CU slots free up
+// (2 resident blocks per CU at NT=2, 3 at NT=1), so what matters is that the LAST round of blocks is nearly full:
+// pick the segment count per block that minimises  ceil(blocks / slots) * (steps + start-up)  over the whole launch.
+struct H3Op { int tiles; long nseg; };
+inline int h3_tiles(int Cout, int C) { const int nt = Cout % 128 == 0 ? 2 : 1; return (Cout / (64 * nt)) * cdiv(C, 16); }
+// at most 32 workspace slices, or as many as it takes for the op alone to offer one block per slot (few-tile convs: stem1)
+inline int h3_max_splits(int tiles) { const int s = cdiv(768, tiles); return s > 32 ? s : 32; }
+inline int h3_splits(long nseg, int steps, int tiles) {
+  int sp = cdiv(nseg, steps);
+  const int cap = h3_max_splits(tiles);
+  if (sp > cap) sp = cap;
+  return cdiv(nseg, cdiv(nseg, sp));
+}
+int h3_pick_steps(const H3Op* ops, int n, int nt) {
+  const long slots = nt == 2 ? 512 : 768;
+  int best = 64; double best_cost = -1.0;
+  for (int steps = 8; steps <= 256; ++steps) {
+    long blocks = 0; long longest = 0;
+    for (int i = 0; i < n; ++i) {
+      const int sp = h3_splits(ops[i].nseg, steps, ops[i].tiles);
+      blocks += (long)ops[i].tiles * sp;
+      const long ch = cdiv(ops[i].nseg, sp);
+      if (ch > longest) longest = ch;
+    }
+    const double cost = (double)cdiv(blocks, slots) * ((double)longest + 1.5);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = steps; }
+  }
+  return best;
+}
 // `budget` = workgroups this conv should contribute.  A lone launch needs ~1536 of them to fill the chip even if that
 // leaves a block a single 64-pixel step; inside a batch the other convs provide the parallelism, so each block gets
 // >= 8 steps and the per-block epilogue (cross-wave combine + partial tile written to the workspace) is amortised.
@@ -427,10 +623,15 @@ int pick_splits(long P, int tiles, int budget = 1536, int min_steps = 1) {
 extern "C" int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_t taps) {
   int cty, ctz; pick_tiles(Cout, C, &cty, &ctz);
   int tiles = cdiv(Cout, 16 * cty) * taps * cdiv(C, 16 * ctz);
-  return (int64_t)pick_splits(P, tiles) * Cout * taps * C;
+  int splits = pick_splits(P, tiles);
+  if (taps == 9 && Cout % 64 == 0 && C >= 16) {      // the halo-patch kernel may be chosen
+    const int hs = h3_max_splits(h3_tiles(Cout, C));
+    if (hs > splits) splits = hs;
+  }
+  return (int64_t)splits * Cout * taps * C;
 }
 
-static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, int& tiles, bool check_ws, int budget = 1536, int min_steps = 1) {
+static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, int& tiles, bool check_ws, int budget = 1536, int min_steps = 1, int h3_steps = 0) {
   ADDK_REQUIRE(a && a->dy && a->src.x && a->dw && (a->ws || !check_ws), "conv_wgrad: null pointer");
   ADDK_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0 && a->Cout > 0 && a->src.C > 0, "conv_wgrad: empty shape");
   ADDK_REQUIRE(a->lddy >= a->Cout && a->src.ld >= a->src.C, "conv_wgrad: short stride");
@@ -446,8 +647,19 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   k.P = a->N * a->OH * a->OW;
   tiles = k.nyt * k.taps * k.nzt;
   k.splits = pick_splits(k.P, tiles, budget, min_steps);
-  ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  ADDK_REQUIRE(!check_ws || h3_ok(a) || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   k.chunkP = cdiv(cdiv(k.P, k.splits), KP) * KP;
+  if (h3_ok(a)) {      // halo-patch kernel: pixel range in 64-pixel row segments, never more slices than the workspace bound
+    const int nt = a->Cout % 128 == 0 ? 2 : 1;
+    cty = 4 * nt; ctz = 1;
+    k.nyt = a->Cout / (64 * nt); k.nzt = cdiv(a->src.C, 16);
+    tiles = k.nyt * k.nzt;
+    const long nseg = (long)a->N * a->OH * cdiv(a->OW, H3_KP);
+    if (h3_steps <= 0) { H3Op o{tiles, nseg}; h3_steps = h3_pick_steps(&o, 1, nt); }
+    k.splits = h3_splits(nseg, h3_steps, tiles);
+    k.chunkP = cdiv(nseg, k.splits);
+    ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  }
   k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
   k.vecZ = src_vec_ok(a->src);
   k.dw = a->dw; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.accumulate = a->accumulate;
@@ -463,6 +675,13 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_OS(1, 4, 2) ADDK_OS(2, 3, 3) ADDK_OS(3, 2, 2) ADDK_OS(4, 4, 4)
 #undef ADDK_OS
+#define ADDK_H3(NT_) \
+  if (kind == 5 && cty == 4 * NT_) { \
+    if (ops) hipLaunchKernelGGL((wgrad_h3_kernel<NT_, true>), grid, dim3(256), 0, st, k, ops, work); \
+    else hipLaunchKernelGGL((wgrad_h3_kernel<NT_, false>), grid, dim3(256), 0, st, k, ops, work); \
+    done = true; }
+  ADDK_H3(1) ADDK_H3(2)
+#undef ADDK_H3
 #define ADDK_CASE(Y_, Z_) \
   if (!done && cty == Y_ && ctz == Z_) { \
     if (ops) hipLaunchKernelGGL((wgrad_kernel<Y_, Z_, true>), grid, dim3(256), 0, st, k, ops, work); \
@@ -483,7 +702,7 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   int rc = wg_fill(a, k, cty, ctz, tiles, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = wg_launch(os_kind(a->Cout, a->src.C), cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
+  rc = wg_launch(kind_of(a), cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
   if (rc) return rc;
   long n = (long)a->Cout * k.taps * a->src.C;
   if (k.splits > 16 && n <= 65536) {
@@ -502,7 +721,7 @@ extern "C" int addk_conv_wgrad_config(const addk_conv_wgrad_args* a, int32_t* cf
   WgK k; int cty, ctz, tiles;
   int rc = wg_fill(a, k, cty, ctz, tiles, false);
   if (rc) return rc;
-  cfg[0] = os_kind(a->Cout, a->src.C); cfg[1] = cty; cfg[2] = ctz; cfg[3] = tiles * k.splits;
+  cfg[0] = kind_of(a); cfg[1] = cty; cfg[2] = ctz; cfg[3] = tiles * k.splits;
   return 0;
 }
 
@@ -512,11 +731,23 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
   int kind0 = -1, cty0 = 0, ctz0 = 0;
   int budget = 8192 / n; if (budget < 32) budget = 32; if (budget > 1536) budget = 1536;
   const int min_steps = n >= 4 ? 8 : 1;
+  int h3_steps = 0;
+  if (h3_ok(&a[0])) {
+    H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
+    const int nt = a[0].Cout % 128 == 0 ? 2 : 1;
+    for (int i = 0; i < n; ++i) {
+      const int nti = a[i].Cout % 128 == 0 ? 2 : 1;
+      ho[i].tiles = (a[i].Cout / (64 * nti)) * cdiv(a[i].src.C, 16);
+      ho[i].nseg = (long)a[i].N * a[i].OH * cdiv(a[i].OW, H3_KP);
+    }
+    h3_steps = h3_pick_steps(ho, n, nt);
+    free(ho);
+  }
   for (int i = 0; i < n; ++i) {
     WgK k; int cty, ctz, tiles;
-    int rc = wg_fill(&a[i], k, cty, ctz, tiles, host_blob != nullptr, budget, min_steps);
+    int rc = wg_fill(&a[i], k, cty, ctz, tiles, host_blob != nullptr, budget, min_steps, h3_steps);
     if (rc) return rc;
-    int kind = os_kind(a[i].Cout, a[i].src.C);
+    int kind = kind_of(&a[i]);
     if (i == 0) { kind0 = kind; cty0 = cty; ctz0 = ctz; }
     if (kind != kind0 || cty != cty0 || ctz != ctz0) { addk_set_error("wgrad_batch_prepare: mixed tile configurations"); return ADDK_ERR_INVALID; }
     nblocks += (long)tiles * k.splits;
@@ -535,7 +766,7 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
   long b = 0, rb = 0;
   for (int i = 0; i < n; ++i) {
     int cty, ctz, tiles;
-    wg_fill(&a[i], ops[i], cty, ctz, tiles, true, budget, min_steps);
+    wg_fill(&a[i], ops[i], cty, ctz, tiles, true, budget, min_steps, h3_steps);
     for (int y = 0; y < ops[i].splits; ++y)
       for (int x = 0; x < tiles; ++x) work[b++] = make_int4(i, x, y, 0);
     long ne = (long)a[i].Cout * ops[i].taps * a[i].src.C;

@@ -1,0 +1,64 @@
+// Stand-alone timing of addk_conv_fwd / addk_conv_dgrad / wgrad on the heavy shapes of config 2 (through the C ABI).
+// hipcc -O2 --offload-arch=gfx950 -Iinclude scripts/conv_bench.cpp -Lauto-dynamic-deeplab_amd -laddk -Wl,-rpath,$PWD/auto-dynamic-deeplab_amd -o /tmp/conv_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "addk.h"
+
+static float* dev_rand(size_t n, float scale) {
+  std::vector<float> h(n);
+  unsigned s = 12345u + (unsigned)n;
+  for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = scale * ((s >> 8) * (1.0f / 8388608.0f) - 1.0f); }
+  float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d;
+}
+struct Shape { const char* name; int N, H, W, Cin, Cout, k, dil; };
+
+int main(int argc, char** argv) {
+  Shape shapes[] = {
+    {"decoder 3x3 304->256 @128x256", 2, 128, 256, 304, 256, 3, 1},
+    {"decoder 3x3 256->256 @128x256", 2, 128, 256, 256, 256, 3, 1},
+    {"aspp 3x3 d6 256->256 @64x128", 2, 64, 128, 256, 256, 3, 6},
+    {"stem 3x3 64->64 @512x1024", 2, 512, 1024, 64, 64, 3, 1},
+    {"aspp 1x1 1280->256 @64x128", 2, 64, 128, 1280, 256, 1, 1},
+  };
+  int reps = argc > 1 ? atoi(argv[1]) : 20;
+  hipStream_t st; hipStreamCreate(&st);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (const Shape& s : shapes) {
+    long P = (long)s.N * s.H * s.W;
+    int taps = s.k * s.k, pad = s.dil * (s.k - 1) / 2;
+    float* x = dev_rand(P * s.Cin, 1.f); float* a = dev_rand(s.Cin, 1.f); float* b = dev_rand(s.Cin, 0.5f);
+    float* w = dev_rand((size_t)s.Cout * taps * s.Cin, 0.05f);
+    float* y; hipMalloc(&y, P * s.Cout * 4);
+    float* g; hipMalloc(&g, P * s.Cin * 4);
+    int rows = addk_conv_rows(P, s.Cout);
+    double* slab; hipMalloc(&slab, (size_t)rows * s.Cout * 2 * 8);
+    double* dab; hipMalloc(&dab, (size_t)addk_conv_rows(P, s.Cin) * s.Cin * 2 * 8);
+    addk_conv_args ar; memset(&ar, 0, sizeof ar);
+    ar.src[0].x = x; ar.src[0].a = a; ar.src[0].b = b; ar.src[0].ld = s.Cin; ar.src[0].C = s.Cin; ar.src[0].relu = 1; ar.nsrc = 1;
+    ar.N = s.N; ar.H = s.H; ar.W = s.W; ar.OH = s.H; ar.OW = s.W; ar.KH = ar.KW = s.k; ar.stride = 1; ar.pad = pad; ar.dil = s.dil;
+    ar.Cout = s.Cout; ar.ldw = taps * s.Cin; ar.cin_total = s.Cin; ar.ldy = s.Cout; ar.w = w; ar.y = y; ar.stats = slab; ar.stats_ld = s.Cout;
+    addk_conv_dgrad_args dg; memset(&dg, 0, sizeof dg);
+    dg.dy = y; dg.lddy = s.Cout; dg.Cout = s.Cout; dg.N = s.N; dg.H = s.H; dg.W = s.W; dg.OH = s.H; dg.OW = s.W; dg.KH = dg.KW = s.k;
+    dg.stride = 1; dg.pad = pad; dg.dil = s.dil; dg.w = w; dg.ldw = taps * s.Cin; dg.cin_total = s.Cin; dg.dst = ar.src[0];
+    dg.g = g; dg.ldg = s.Cin; dg.dab = dab;
+    addk_conv_wgrad_args wg; memset(&wg, 0, sizeof wg);
+    wg.dy = y; wg.lddy = s.Cout; wg.Cout = s.Cout; wg.N = s.N; wg.H = s.H; wg.W = s.W; wg.OH = s.H; wg.OW = s.W; wg.KH = wg.KW = s.k;
+    wg.stride = 1; wg.pad = pad; wg.dil = s.dil; wg.src = ar.src[0]; wg.ldw = taps * s.Cin; wg.cin_total = s.Cin;
+    hipMalloc(&wg.dw, (size_t)s.Cout * taps * s.Cin * 4);
+    wg.ws_floats = addk_conv_wgrad_ws(P, s.Cout, s.Cin, taps); hipMalloc(&wg.ws, wg.ws_floats * 4);
+    double gf = 2.0 * P * s.Cout * taps * s.Cin * 1e-9;
+    for (int mode = 0; mode < 3; ++mode) {
+      auto run = [&] { return mode == 0 ? addk_conv_fwd(&ar, st) : mode == 1 ? addk_conv_dgrad(&dg, st) : addk_conv_wgrad(&wg, st); };
+      if (run() != 0) { printf("%s: error %s\n", s.name, addk_last_error()); return 1; }
+      hipStreamSynchronize(st);
+      hipEventRecord(e0, st); for (int r = 0; r < reps; ++r) run(); hipEventRecord(e1, st); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("%-34s %-5s %8.1f us  %6.1f TFLOP/s (%.1f GF)\n", s.name, mode == 0 ? "fwd" : mode == 1 ? "dgrad" : "wgrad", ms * 1e3, gf / ms, gf);
+    }
+    hipFree(x); hipFree(a); hipFree(b); hipFree(w); hipFree(y); hipFree(g); hipFree(slab); hipFree(dab); hipFree(wg.dw); hipFree(wg.ws);
+  }
+  return 0;
+}
