@@ -74,3 +74,6 @@ static inline EwMap ew_map(int C) {
 // pw.hip: register-stationary 1x1 convolution; 0 = launched, 1 = shape not covered (fall back), <0 = error
 int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream);
 int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream);
+// conv3.hip: halo-patch 3x3 stride-1 convolution (needs a->wpack); same return convention
+int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream);
+int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream);

@@ -451,11 +451,19 @@ int conv_precision() {
   return g_prec;
 }
 
-bool pw_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("ADDK_PW"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on != 0;
+int g_fast = -1;
+int fast_paths() {
+  if (g_fast < 0) {
+    int m = ADDK_FAST_PW | ADDK_FAST_CONV3 | ADDK_FAST_WGRAD3;
+    const char* e;
+    if ((e = getenv("ADDK_PW")) && e[0] == '0') m &= ~ADDK_FAST_PW;
+    if ((e = getenv("ADDK_C3")) && e[0] == '0') m &= ~ADDK_FAST_CONV3;
+    if ((e = getenv("ADDK_WGRAD_H3")) && e[0] == '0') m &= ~ADDK_FAST_WGRAD3;
+    g_fast = m;
+  }
+  return g_fast;
 }
+bool pw_enabled() { return (fast_paths() & ADDK_FAST_PW) != 0; }
 
 template <int MODE>
 int launch(ConvK& k, hipStream_t st, int grid_x = 0) {
@@ -495,6 +503,8 @@ extern "C" int addk_set_conv_precision(int mode) {
   return ADDK_OK;
 }
 extern "C" int addk_get_conv_precision(void) { return conv_precision(); }
+extern "C" int addk_set_fast_paths(int mask) { g_fast = mask & (ADDK_FAST_PW | ADDK_FAST_CONV3 | ADDK_FAST_WGRAD3); return ADDK_OK; }
+extern "C" int addk_get_fast_paths(void) { return fast_paths(); }
 
 extern "C" int addk_selftest_mfma(float* out256, void* stream) {
   hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out256);
@@ -531,6 +541,10 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
     int r = addk_pw_try_fwd(a, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), stream);
     if (r <= 0) return r;
   }
+  if (a->wpack) {                                          // wide 3x3 stride-1: halo-patch kernel (conv3.hip)
+    int r = addk_c3_try_fwd(a, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), stream);
+    if (r <= 0) return r;
+  }
   k.nsrc = a->nsrc;
   k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
   k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;
@@ -555,6 +569,10 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
   ADDK_REQUIRE((a->dst.a == nullptr) == (a->dst.b == nullptr), "conv_dgrad: a/b must come together");
   if (conv_precision() == PREC_F32 && pw_enabled()) {
     int r = addk_pw_try_dgrad(a, addk_conv_rows((long)a->N * a->H * a->W, a->dst.C), stream);
+    if (r <= 0) return r;
+  }
+  if (a->wpack) {
+    int r = addk_c3_try_dgrad(a, addk_conv_rows((long)a->N * a->H * a->W, a->dst.C), stream);
     if (r <= 0) return r;
   }
   ConvK k;

@@ -1,0 +1,420 @@
+// Halo-patch form of the wide 3x3, stride-1, 'same'-padded convolutions (decoder, ASPP dilated branches, stem1),
+// forward and data gradient, on the fp32 matrix cores of gfx950 (v_mfma_f32_16x16x4_f32).
+//
+// The generic implicit-GEMM kernel (conv.hip) walks K as (tap, 32-channel chunk) and re-stages the pixel tile for every
+// tap: 9 global loads + 9 BatchNorm/ReLU prologues per input element, two barriers per 128 MFMAs, and the staging phase
+// does not overlap the MFMA phase (measured: 454 us of staging + 714 us of MFMAs ~ the 1072 us of the decoder conv).
+// Here a block owns 128 consecutive pixels of ONE output row and 64/128 output channels, and walks K in 16-channel
+// chunks.  Per chunk it stages the three input rows oh-d, oh, oh+d ([3][128+2d px][16 ch], prologue applied once, zero
+// padding after it) in LDS and runs all nine taps from that patch: one global load + one prologue per input element
+// and 2 barriers per 576 MFMAs per wave.  The weights never touch LDS: a small pack kernel rewrites them per launch
+// into MFMA-fragment order ([column block][chunk*9+tap][16-col tile][lane][4 k-slots]) so that a wave fetches the
+// fragments of one tap with CT coalesced 16-byte loads (L1/L2 hits: every block reads the same stream), one tap ahead
+// of their use.  The data gradient is the same kernel over dy with the packed weights transposed and tap-mirrored.
+//
+// Reference call sites: decoder.py:17-27 (3x3 conv+BN+ReLU x2), aspp_train.py:20-41 (dilated 3x3 branches),
+// ADD.py:220-232 (stem1); autograd of nn.Conv2d for the data gradient.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+constexpr int C3_BP = 128;                 // pixels per tile (one row segment)
+constexpr int C3_BK = 16;                  // channels per chunk
+constexpr int C3_RS = 20;                  // floats per patch pixel in LDS (16 + 4: ds_read_b64 fragment reads hit 64 distinct banks per half-wave)
+constexpr int C3_PWMAX = C3_BP + 2 * 18;   // widest patch row (dilation 18)
+constexpr int C3_MAXCH = 64;               // chunks per launch (K <= 1024 channels)
+constexpr int C3_NS = (3 * C3_PWMAX * 4 + 255) / 256;   // 16-byte patch slots per thread
+
+struct C3K {
+  addk_src src[ADDK_MAX_SRC];
+  int nsrc;
+  int N, H, W, dil;
+  int Cn, ldy;
+  float* y;
+  const float* wp;          // packed weights of this launch
+  long wp_blk;              // floats per column block in wp
+  int nT;                   // chunks * 9
+  const float* bias; const float* bias_n;
+  double* slab; int slab_ld;
+  addk_src dst; int accumulate;
+  int vecY, red32;
+  long P; int ntiles, spr;
+};
+
+struct PackK {
+  const float* w; int ldw, cin_total;
+  int mode;                 // fwd: rows = co, K = input channels; dgrad: rows = input channels, K = co
+  int Cn;                   // GEMM N extent (rows of the packed tiles)
+  int w_choff;              // dgrad: channel offset of the destination source inside a tap
+  int nchunks, bct;
+  int cbase[C3_MAXCH];      // first K index of the chunk (fwd: absolute channel inside a tap; dgrad: co)
+  int cvalid[C3_MAXCH];     // valid K entries in the chunk (<= 16)
+  float* out;
+};
+
+// out[colblk][T = chunk*9 + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
+__global__ void __launch_bounds__(256) c3_pack_kernel(const PackK p) {
+  const int BC = 16 * p.bct;
+  const long per_blk = (long)p.nchunks * 9 * p.bct * 256;
+  const long total = (long)((p.Cn + BC - 1) / BC) * per_blk;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int m = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    long r = idx >> 8;
+    const int i = (int)(r % p.bct); r /= p.bct;
+    const int T = (int)(r % (p.nchunks * 9)); const int blk = (int)(r / (p.nchunks * 9));
+    const int chunk = T / 9, tap = T - chunk * 9;
+    const int li = lane & 15, kq = lane >> 4;
+    const int row = blk * BC + i * 16 + li;
+    const int kk = 8 * (m >> 1) + 2 * kq + (m & 1);
+    float v = 0.f;
+    if (row < p.Cn && kk < p.cvalid[chunk]) {
+      if (p.mode == MODE_FWD) v = p.w[(long)row * p.ldw + (long)tap * p.cin_total + p.cbase[chunk] + kk];
+      else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(8 - tap) * p.cin_total + p.w_choff + row];
+    }
+    p.out[idx] = v;
+  }
+}
+
+template <int BCT, int MODE>
+__global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
+  constexpr int BC = 16 * BCT;
+  constexpr int WC = BCT == 8 ? 2 : 1;      // waves across output channels
+  constexpr int WP = 4 / WC;                // waves across pixels
+  constexpr int PT = 8 / WP;                // 16-pixel tiles per wave
+  constexpr int CT = BCT / WC;              // 16-channel tiles per wave
+  __shared__ __attribute__((aligned(16))) float Ps[3 * C3_PWMAX * C3_RS];
+  __shared__ double red[WP][BC][2];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int wc = wave % WC, wpx = wave / WC;
+  const int n0 = blockIdx.y * BC;
+  const int d = p.dil, PW = C3_BP + 2 * d;
+  double tot0 = 0.0, tot1 = 0.0;
+
+  // fixed patch-slot geometry, packed to one register per slot: slot -> (row r | patch column pj << 2); r == 3: outside the patch
+  const int q = t & 3;
+  int geo[C3_NS];
+#pragma unroll
+  for (int k = 0; k < C3_NS; ++k) {
+    const int pix = (t + 256 * k) >> 2;
+    int r = pix / PW; const int pj = pix - r * PW;
+    if (r > 3) r = 3;
+    geo[k] = r | (pj << 2);
+  }
+  // fragment read bases (bytes are implied by float indexing): pixel (wpx*PT*16 + li) of patch row 0, k pair 2*kq, per kw
+  int xb[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) xb[kw] = (wpx * PT * 16 + li + kw * d) * C3_RS + 2 * kq;
+  const float4* wpl = reinterpret_cast<const float4*>(p.wp + (long)blockIdx.y * p.wp_blk) + (long)wc * CT * 64 + lane;
+  const int nT = p.nT;
+
+  const int tpx = p.ntiles >> 3;
+  const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
+  for (int tlin = blockIdx.x; tlin < p.ntiles; tlin += gridDim.x) {
+    const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
+    const int rowid = tile / p.spr, sx = tile - rowid * p.spr;
+    const int n = rowid / p.H, oh = rowid - n * p.H;
+    const int ow0 = sx * C3_BP;
+    // per-tile validity of the slots (image borders)
+    unsigned vmask = 0;
+    const int pbase = (n * p.H + oh - d) * p.W + ow0 - d;      // pixel index of patch (row 0, column 0)
+#pragma unroll
+    for (int k = 0; k < C3_NS; ++k) {
+      const int r = geo[k] & 3, pj = geo[k] >> 2;
+      const int ih = oh + (r - 1) * d, iw = ow0 - d + pj;
+      const bool ok = r < 3 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      vmask |= (ok ? 1u : 0u) << k;
+    }
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[C3_NS];
+    float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4();
+    bool prelu = false, pch = false;
+    auto load_patch = [&](int s_, int c0_) {      // branch-free: masked slots read the source base and are zeroed at store time
+      const addk_src S = p.src[s_];
+      const int c = c0_ + 4 * q;
+      pch = c < S.C;
+      prelu = S.relu != 0;
+      pa = make_float4(1.f, 1.f, 1.f, 1.f); pb = zero4();
+      if (S.a && pch) { pa = ld4(S.a + c); pb = ld4(S.b + c); }
+      const float* sb = S.x + (pch ? c : 0);
+#pragma unroll
+      for (int k = 0; k < C3_NS; ++k) {
+        const int r = geo[k] & 3, pj = geo[k] >> 2;
+        const int po = ((vmask >> k) & 1u) ? pbase + r * d * p.W + pj : 0;
+        ra[k] = ld4(sb + (long)po * S.ld);
+      }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+      for (int k = 0; k < C3_NS; ++k) {
+        float4 v = ra[k];
+        v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
+        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const bool ok = pch && ((vmask >> k) & 1u);
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        const int r = geo[k] & 3, pj = geo[k] >> 2;
+        if (r < 3) st4(&Ps[(r * C3_PWMAX + pj) * C3_RS + 4 * q], v);
+      }
+    };
+
+    // weight fragments: two register sets, the next tap's fragments are fetched while the current tap's MFMAs issue
+    float4 wr[2][CT];
+    auto load_w = [&](int T, float4* dst) {
+      const int Tc = T < nT ? T : nT - 1;
+      const float4* src = wpl + (long)Tc * (BCT * 64);
+#pragma unroll
+      for (int i = 0; i < CT; ++i) dst[i] = src[i * 64];
+    };
+    // pixel fragments: one buffer per half of the 16-channel chunk (k 0-7 / 8-15), read one half ahead
+    float2 xf[2][PT];
+    auto read_x = [&](int tap, int h, float2* x) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const float* b = &Ps[xb[kw] + kh * C3_PWMAX * C3_RS + 8 * h];
+#pragma unroll
+      for (int j = 0; j < PT; ++j) x[j] = *reinterpret_cast<const float2*>(b + j * 16 * C3_RS);
+    };
+    auto mma = [&](const float4* w, int h, const float2* x) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(h ? w[i].z : w[i].x, x[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(h ? w[i].w : w[i].y, x[j].y, acc[i][j], 0, 0, 0);
+    };
+
+    int s = 0, c0 = 0, T0 = 0;
+    load_w(0, wr[0]);
+    load_patch(0, 0);
+    store_patch();
+    __syncthreads();
+    while (true) {
+      int s2 = s, c2 = c0 + C3_BK;
+      if (c2 >= p.src[s].C) { c2 = 0; ++s2; }
+      const bool more = s2 < p.nsrc;
+      read_x(0, 0, xf[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        load_w(T0 + tap + 1, wr[(tap + 1) & 1]);
+        if (tap == 0 && more) load_patch(s2, c2);
+        read_x(tap, 1, xf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wr[tap & 1], 0, xf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < 9) read_x(tap + 1, 0, xf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wr[tap & 1], 1, xf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      T0 += 9;
+#pragma unroll
+      for (int i = 0; i < CT; ++i) wr[0][i] = wr[1][i];      // nine taps per chunk: the set fetched during tap 8 is next chunk's tap 0
+      __syncthreads();
+      if (!more) break;
+      s = s2; c0 = c2;
+      store_patch();
+      __syncthreads();
+    }
+
+    // ---- epilogue (same contract as conv.hip) ----
+    const bool want_red = p.slab != nullptr;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int col = (wc * CT + i) * 16 + kq * 4;
+      const int c = n0 + col;
+      const int nrem = p.Cn - c;
+      double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        const int lp = (wpx * PT + j) * 16 + li;
+        const long pp = (long)rowid * p.W + ow0 + lp;
+        const bool pv = ow0 + lp < p.W && nrem > 0;
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (MODE == MODE_FWD) {
+          if (pv) {
+            if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.bias_n) {
+              float4 b = ld4g(p.bias_n + (long)n * p.Cn + c, nrem, false);
+              v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            st4g(p.y + pp * p.ldy + c, v, nrem, p.vecY);
+            if (want_red) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                double f = (e < nrem) ? (double)get4(v, e) : 0.0;
+                s1[e] += f; s2v[e] += f * f;
+              }
+            }
+          }
+        } else {
+          if (pv) {
+            float4 x = ld4g(p.dst.x + pp * p.dst.ld + c, nrem, p.vecY);
+            float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+            if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, p.vecY); bv = ld4g(p.dst.b + c, nrem, p.vecY); }
+            float4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), dz = get4(v, e);
+              bool m = (e < nrem) && (!p.dst.relu || fmaf(ae, xe, be) > 0.f);
+              set4(g, e, m ? dz * ae : 0.f);
+              if (want_red && m) { s1[e] += (double)dz * (double)xe; s2v[e] += (double)dz; }
+            }
+            float* gp = p.y + pp * p.ldy + c;
+            if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vecY); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+            st4g(gp, g, nrem, p.vecY);
+          }
+        }
+      }
+      if (want_red) {
+        if (p.red32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = (float)s1[e], b = (float)s2v[e];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            if (li == 0) { red[wpx][col + e][0] = a; red[wpx][col + e][1] = b; }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            double a = s1[e], b = s2v[e];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            if (li == 0) { red[wpx][col + e][0] = a; red[wpx][col + e][1] = b; }
+          }
+        }
+      }
+    }
+    if (want_red) {
+      __syncthreads();
+      if (t < BC) {
+#pragma unroll
+        for (int w = 0; w < WP; ++w) { tot0 += red[w][t][0]; tot1 += red[w][t][1]; }
+      }
+      __syncthreads();
+    }
+  }
+  if (p.slab && t < BC && n0 + t < p.Cn) {
+    double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+    o[0] = tot0; o[1] = tot1;
+  }
+}
+
+bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
+// 128-channel column blocks when that still yields >= 512 blocks (2 per CU), else 64-channel blocks (ASPP's 64x128 maps)
+int c3_bct(int Cn, long P) {
+  if (Cn < 128) return 4;
+  const long tiles = (P + C3_BP - 1) / C3_BP;
+  return tiles * ((Cn + 127) / 128) >= 512 ? 8 : 4;
+}
+long c3_pack_floats(int Cn, int nchunks, long P) {
+  const int bct = c3_bct(Cn, P);
+  return (long)cdiv(Cn, 16 * bct) * nchunks * 9 * bct * 256;
+}
+bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn) {
+  return c3_enabled() && KH == 3 && KW == 3 && stride == 1 && pad == dil && dil >= 1 && dil <= 18 && OH == H && OW == W &&
+         W >= 64 && P >= 8192 && Cn >= 64 && addk_get_conv_precision() == 0;
+}
+
+int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st) {
+  const int bct = c3_bct(k.Cn, k.P);
+  pk.bct = bct; pk.mode = mode; pk.Cn = k.Cn;
+  k.nT = pk.nchunks * 9;
+  k.wp = pk.out;
+  k.wp_blk = (long)pk.nchunks * 9 * bct * 256;
+  k.spr = cdiv(k.W, C3_BP);
+  k.ntiles = k.N * k.H * k.spr;
+  k.red32 = k.P >= 4096;
+  const long total = c3_pack_floats(k.Cn, pk.nchunks, k.P);
+  int pb = cdiv(total, 256 * 4); if (pb > 4096) pb = 4096;
+  hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
+  dim3 grid(rows, cdiv(k.Cn, 16 * bct));
+  if (mode == MODE_FWD) {
+    if (bct == 8) hipLaunchKernelGGL((conv3_kernel<8, MODE_FWD>), grid, dim3(256), 0, st, k);
+    else          hipLaunchKernelGGL((conv3_kernel<4, MODE_FWD>), grid, dim3(256), 0, st, k);
+  } else {
+    if (bct == 8) hipLaunchKernelGGL((conv3_kernel<8, MODE_DGRAD>), grid, dim3(256), 0, st, k);
+    else          hipLaunchKernelGGL((conv3_kernel<4, MODE_DGRAD>), grid, dim3(256), 0, st, k);
+  }
+  return addk_check_launch("conv3");
+}
+
+}  // namespace
+
+// number of floats the packed-weight workspace of this launch needs; 0 = the halo-patch kernel does not apply
+extern "C" int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a) {
+  if (!a || a->nsrc < 1 || a->nsrc > ADDK_MAX_SRC) return 0;
+  if (!c3_geometry_ok(a->KH, a->KW, a->stride, a->pad, a->dil, a->H, a->W, a->OH, a->OW, (long)a->N * a->OH * a->OW, a->Cout)) return 0;
+  int nch = 0;
+  for (int i = 0; i < a->nsrc; ++i) { if (a->src[i].C % 4 || a->src[i].ld % 4) return 0; nch += cdiv(a->src[i].C, C3_BK); }
+  if (nch > C3_MAXCH || a->ldy % 4) return 0;
+  return c3_pack_floats(a->Cout, nch, (long)a->N * a->H * a->W);
+}
+extern "C" int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a) {
+  if (!a) return 0;
+  if (!c3_geometry_ok(a->KH, a->KW, a->stride, a->pad, a->dil, a->H, a->W, a->OH, a->OW, (long)a->N * a->H * a->W, a->dst.C)) return 0;
+  if (a->Cout % 4 || a->lddy % 4 || a->ldg % 4 || a->dst.ld % 4 || a->dst.C % 4) return 0;
+  const int nch = cdiv(a->Cout, C3_BK);
+  if (nch > C3_MAXCH) return 0;
+  return c3_pack_floats(a->dst.C, nch, (long)a->N * a->H * a->W);
+}
+
+// 0 = launched, 1 = not covered (caller falls back to the generic kernel), <0 = error
+int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) {
+  const int64_t need = addk_conv_fwd_pack_floats(a);
+  if (need == 0 || !a->wpack || a->wpack_floats < need) return 1;
+  if (!aligned16(a->y) || !aligned16(a->wpack)) return 1;
+  for (int i = 0; i < a->nsrc; ++i) if (!src_vec_ok(a->src[i])) return 1;
+  C3K k; PackK pk;
+  k.nsrc = a->nsrc;
+  int nch = 0, choff = 0;
+  for (int i = 0; i < a->nsrc; ++i) {
+    k.src[i] = a->src[i];
+    for (int c0 = 0; c0 < a->src[i].C; c0 += C3_BK) {
+      pk.cbase[nch] = a->w_choff + choff + c0;
+      pk.cvalid[nch] = a->src[i].C - c0 < C3_BK ? a->src[i].C - c0 : C3_BK;
+      ++nch;
+    }
+    choff += a->src[i].C;
+  }
+  pk.nchunks = nch; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = 0; pk.out = a->wpack;
+  k.N = a->N; k.H = a->H; k.W = a->W; k.dil = a->dil;
+  k.Cn = a->Cout; k.ldy = a->ldy; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n;
+  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.dst = addk_src{nullptr, nullptr, nullptr, 0, 0, 0, 0}; k.accumulate = 0;
+  k.vecY = 1;
+  k.P = (long)a->N * a->H * a->W;
+  return c3_launch(k, pk, MODE_FWD, rows, (hipStream_t)stream);
+}
+
+int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
+  const int64_t need = addk_conv_dgrad_pack_floats(a);
+  if (need == 0 || !a->wpack || a->wpack_floats < need) return 1;
+  if (!aligned16(a->dy) || !aligned16(a->g) || !aligned16(a->wpack) || !src_vec_ok(a->dst)) return 1;
+  C3K k; PackK pk;
+  k.nsrc = 1;
+  k.src[0] = addk_src{a->dy, nullptr, nullptr, a->lddy, a->Cout, 0, 0};
+  int nch = 0;
+  for (int c0 = 0; c0 < a->Cout; c0 += C3_BK) {
+    pk.cbase[nch] = c0;
+    pk.cvalid[nch] = a->Cout - c0 < C3_BK ? a->Cout - c0 : C3_BK;
+    ++nch;
+  }
+  pk.nchunks = nch; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = a->w_choff; pk.out = a->wpack;
+  k.N = a->N; k.H = a->H; k.W = a->W; k.dil = a->dil;
+  k.Cn = a->dst.C; k.ldy = a->ldg; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr;
+  k.slab = (double*)a->dab; k.slab_ld = a->dst.C;
+  k.dst = a->dst; k.accumulate = a->accumulate;
+  k.vecY = 1;
+  k.P = (long)a->N * a->H * a->W;
+  return c3_launch(k, pk, MODE_DGRAD, rows, (hipStream_t)stream);
+}

@@ -570,9 +570,7 @@ void pick_tiles(int Cout, int C, int* cty, int* ctz) {
 bool use_output_split(int Cout, int C) { return os_kind(Cout, C) != 0; }
 // 5: halo-patch kernel (3x3, stride 1, 'same' padding, wide): tiles are (64*NT co) x (16 c), the nine taps live in the block
 bool h3_ok(const addk_conv_wgrad_args* a) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("ADDK_WGRAD_H3"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == a->dil && a->dil >= 1 && a->dil <= 18 &&
+  return (addk_get_fast_paths() & ADDK_FAST_WGRAD3) && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == a->dil && a->dil >= 1 && a->dil <= 18 &&
          a->OH == a->H && a->OW == a->W && a->Cout % 64 == 0 && a->src.C >= 16 &&
          aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) && (long)a->N * a->H * a->W >= 8192;
 }

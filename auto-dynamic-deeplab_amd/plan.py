@@ -437,9 +437,14 @@ class Graph:
         ar.bias_n = bias_n.ptr if bias_n is not None else None
         ar.stats = stats.ptr if stats is not None else None
         ar.stats_ld = stats_ld
+        wpk = None
+        npk = int(lib.addk_conv_fwd_pack_floats(C.byref(ar)))       # > 0: wide 3x3 stride-1 conv, halo-patch kernel (conv3.hip)
+        if npk > 0:
+            wpk = self.buf(npk)
+            ar.wpack, ar.wpack_floats = wpk.ptr, npk
         self.keep.append(ar)
         self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
-                  rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats])
+                  rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
         self.meta.append(dict(kind='conv_fwd', idx=len(self.fwd) - 1, flops=2.0 * N * OH * OW * Cout * k * k * csum,
                               bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
                               shape=(N, H, W, csum, Cout, k, stride, dil)))
@@ -482,9 +487,14 @@ class Graph:
                         if slab is not None:
                             da.dab = slab.ptr
                             s.bn.slabs.append((slab, rows))
+                        dpk = None
+                        npk = int(lib.addk_conv_dgrad_pack_floats(C.byref(da)))
+                        if npk > 0:
+                            dpk = self.buf(npk)
+                            da.wpack, da.wpack_floats = dpk.ptr, npk
                         self.keep.append(da)
                         self._add(self.bwd, 'conv_dgrad', lib.addk_conv_dgrad, C.byref(da), rd=[dy, weight] + self.lz(s),
-                                  wr=[gs, slab])
+                                  wr=[gs, slab, dpk])
                     choff += s.C
             self._bwd_emitters.append(emit_bwd)
         return out

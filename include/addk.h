@@ -84,12 +84,26 @@ typedef struct addk_conv_args {
                                  Points at this conv's first channel inside the row. */
   int32_t stats_ld;           /* channels per slab row (>= Cout; FactorizedReduce's two convs share one BN) */
   int32_t _pad;
+  float* wpack;               /* optional workspace of >= addk_conv_fwd_pack_floats() floats: lets wide 3x3 stride-1 'same'
+                                 convolutions run on the halo-patch kernel (weights re-packed into MFMA fragment order
+                                 per launch); NULL = generic kernel */
+  int64_t wpack_floats;
 } addk_conv_args;
 int addk_conv_fwd(const addk_conv_args* a, void* stream);
+/* floats of `wpack` this launch can use; 0 = the halo-patch kernel does not cover the shape */
+int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a);
 /* Arithmetic of the dense contractions (fwd and dgrad): 0 = exact fp32 products on v_mfma_f32_16x16x4_f32 (default,
  * the parity path); 1 = split-bf16: x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with
  * fp32 accumulation (~1.5e-5 relative per product).  Process-wide; also ADDK_MATH=bf16x3 in the environment. */
 int addk_set_conv_precision(int mode);
+/* Specialised kernels that may replace the generic ones (all on by default; results agree to fp32 rounding).  The mask is
+ * process-wide and is meant for tests and A/B timing; the environment (ADDK_PW=0, ADDK_C3=0, ADDK_WGRAD_H3=0) sets the
+ * initial value. */
+#define ADDK_FAST_PW      1   /* register-stationary 1x1 convolution (pw.hip) */
+#define ADDK_FAST_CONV3   2   /* halo-patch 3x3 stride-1 forward / data gradient (conv3.hip; needs wpack) */
+#define ADDK_FAST_WGRAD3  4   /* halo-patch 3x3 stride-1 weight gradient (wgrad.hip) */
+int addk_set_fast_paths(int mask);
+int addk_get_fast_paths(void);
 int addk_get_conv_precision(void);
 /* number of partial-statistics rows a launch with these shapes writes (<= 1024) */
 int addk_conv_rows(int64_t P, int32_t Cout);
@@ -106,8 +120,11 @@ typedef struct addk_conv_dgrad_args {
   float* g; int32_t ldg;       /* gradient wrt dst.x (raw), same geometry as dst */
   int32_t accumulate;          /* 0: overwrite g, 1: g += */
   double* dab;                 /* fp64 [rows][C][2] partial (dA,dB) or NULL; rows = addk_conv_rows(N*H*W, C) */
+  float* wpack;                /* optional packed-weight workspace (see addk_conv_args.wpack) */
+  int64_t wpack_floats;
 } addk_conv_dgrad_args;
 int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream);
+int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a);
 
 /* Weight gradient for ONE source: dw[co][tap][w_choff+ci] = sum_p dy[p,co] * z[p@tap,ci],
  * z = relu?(a*x+b).  Deterministic split-P: partial tiles go to `ws`, then are reduced into

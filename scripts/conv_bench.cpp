@@ -49,6 +49,8 @@ int main(int argc, char** argv) {
     wg.stride = 1; wg.pad = pad; wg.dil = s.dil; wg.src = ar.src[0]; wg.ldw = taps * s.Cin; wg.cin_total = s.Cin;
     hipMalloc(&wg.dw, (size_t)s.Cout * taps * s.Cin * 4);
     wg.ws_floats = addk_conv_wgrad_ws(P, s.Cout, s.Cin, taps); hipMalloc(&wg.ws, wg.ws_floats * 4);
+    ar.wpack_floats = addk_conv_fwd_pack_floats(&ar); if (ar.wpack_floats) hipMalloc(&ar.wpack, ar.wpack_floats * 4);
+    dg.wpack_floats = addk_conv_dgrad_pack_floats(&dg); if (dg.wpack_floats) hipMalloc(&dg.wpack, dg.wpack_floats * 4);
     double gf = 2.0 * P * s.Cout * taps * s.Cin * 1e-9;
     for (int mode = 0; mode < 3; ++mode) {
       auto run = [&] { return mode == 0 ? addk_conv_fwd(&ar, st) : mode == 1 ? addk_conv_dgrad(&dg, st) : addk_conv_wgrad(&wg, st); };

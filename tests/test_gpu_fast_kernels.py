@@ -1,0 +1,144 @@
+"""GPU tests of the specialised 3x3 kernels (conv3.hip halo-patch forward / data gradient, wgrad.hip halo-patch weight
+gradient) through the C ABI: each launch is compared with an fp64 PyTorch reference of the same operation
+(relu(a*x+b) -> conv2d -> batch statistics, and its autograd) and with the generic kernels on identical buffers.
+The whole-network parity tests use maps too small to reach these kernels (they need >= 8192 pixels), so they are pinned
+here.  Tolerance: 2e-5 of the reference's max-abs for fp32 products with fp32 accumulation over K <= 2736."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+FAST_ALL = 7
+
+SHAPES = [
+    # name,            N,  H,   W, source channels, Cout, dil
+    ('two_src_d1',     1, 40, 256, (32, 16), 128, 1),
+    ('odd_tail_d2',    2, 33, 129, (24,), 64, 2),
+    ('aspp_like_d6',   1, 70, 128, (48,), 256, 6),
+    ('wide_blocks_d1', 2, 64, 256, (32,), 256, 1),
+    ('max_dil_d18',    1, 64, 128, (16,), 64, 18),
+]
+
+
+@pytest.fixture(scope='module')
+def lib():
+    assert torch.cuda.is_available()
+    import addk
+    from addk import _lib as L
+    yield L
+    L.load().addk_set_fast_paths(FAST_ALL)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def _run(L, fast, shape, data):
+    """One forward + data gradient + weight gradient through the C ABI with the given fast-path mask."""
+    lib = L.load()
+    lib.addk_set_fast_paths(fast)
+    name, N, H, W, Cs, Cout, dil = shape
+    dev = data['w'].device
+    st = torch.cuda.current_stream().cuda_stream
+    ctot = sum(Cs)
+    P = N * H * W
+    keep = []
+    ar = L.ConvArgs()
+    for i, Ci in enumerate(Cs):
+        ar.src[i].x, ar.src[i].a, ar.src[i].b = data['x'][i].data_ptr(), data['a'][i].data_ptr(), data['b'][i].data_ptr()
+        ar.src[i].ld, ar.src[i].C, ar.src[i].relu = Ci, Ci, 1
+    ar.nsrc = len(Cs)
+    ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, H, W
+    ar.KH = ar.KW = 3
+    ar.stride, ar.pad, ar.dil, ar.Cout = 1, dil, dil, Cout
+    ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = 9 * ctot, ctot, 0, Cout
+    y = torch.empty(P, Cout, device=dev)
+    rows = lib.addk_conv_rows(P, Cout)
+    slab = torch.zeros(rows, Cout, 2, device=dev, dtype=torch.float64)
+    ar.w, ar.y, ar.stats, ar.stats_ld = data['w'].data_ptr(), y.data_ptr(), slab.data_ptr(), Cout
+    npk = int(lib.addk_conv_fwd_pack_floats(C.byref(ar)))
+    assert (npk > 0) == bool(fast & 2), 'forward: halo-patch kernel coverage (%d floats, mask %d)' % (npk, fast)
+    if npk:
+        wp = torch.empty(npk, device=dev); keep.append(wp)
+        ar.wpack, ar.wpack_floats = wp.data_ptr(), npk
+    L.check(lib.addk_conv_fwd(C.byref(ar), st), 'conv_fwd')
+    out = {'y': y, 'stats': slab.sum(0)}
+    choff = 0
+    out['g'], out['dab'], out['dw'] = [], [], torch.zeros_like(data['w'])
+    for i, Ci in enumerate(Cs):
+        da = L.ConvDgradArgs()
+        da.dy, da.lddy, da.Cout = data['dy'].data_ptr(), Cout, Cout
+        da.N, da.H, da.W, da.OH, da.OW, da.KH, da.KW, da.stride, da.pad, da.dil = N, H, W, H, W, 3, 3, 1, dil, dil
+        da.w, da.ldw, da.cin_total, da.w_choff = data['w'].data_ptr(), 9 * ctot, ctot, choff
+        da.dst = ar.src[i]
+        g = torch.empty(P, Ci, device=dev)
+        r2 = lib.addk_conv_rows(P, Ci)
+        dab = torch.zeros(r2, Ci, 2, device=dev, dtype=torch.float64)
+        da.g, da.ldg, da.accumulate, da.dab = g.data_ptr(), Ci, 0, dab.data_ptr()
+        npk = int(lib.addk_conv_dgrad_pack_floats(C.byref(da)))
+        if npk:
+            wp = torch.empty(npk, device=dev); keep.append(wp)
+            da.wpack, da.wpack_floats = wp.data_ptr(), npk
+        L.check(lib.addk_conv_dgrad(C.byref(da), st), 'conv_dgrad')
+        out['g'].append(g); out['dab'].append(dab.sum(0))
+        wa = L.ConvWgradArgs()
+        wa.dy, wa.lddy, wa.Cout = data['dy'].data_ptr(), Cout, Cout
+        wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, H, W, 3, 3, 1, dil, dil
+        wa.src = ar.src[i]
+        wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = out['dw'].data_ptr(), 9 * ctot, ctot, choff, 0
+        wa.ws_floats = lib.addk_conv_wgrad_ws(P, Cout, Ci, 9)
+        ws = torch.empty(int(wa.ws_floats), device=dev); keep.append(ws)
+        wa.ws = ws.data_ptr()
+        cfg = (C.c_int32 * 4)()
+        L.check(lib.addk_conv_wgrad_config(C.byref(wa), cfg), 'wgrad_config')
+        if Ci >= 16:
+            assert (cfg[0] == 5) == bool(fast & 4), 'weight gradient: kernel kind %d with mask %d' % (cfg[0], fast)
+        L.check(lib.addk_conv_wgrad(C.byref(wa), st), 'conv_wgrad')
+        choff += Ci
+    torch.cuda.synchronize()
+    return out
+
+
+def _reference(shape, data):
+    name, N, H, W, Cs, Cout, dil = shape
+    xs = [x.double().view(N, H, W, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True) for x in data['x']]
+    as_ = [a.double().requires_grad_(True) for a in data['a']]
+    bs = [b.double().requires_grad_(True) for b in data['b']]
+    z = torch.cat([F.relu(a.view(1, -1, 1, 1) * x + b.view(1, -1, 1, 1)) for x, a, b in zip(xs, as_, bs)], 1)
+    w = data['w'].double().view(Cout, 3, 3, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.conv2d(z, w, padding=dil, dilation=dil)
+    dy = data['dy'].double().view(N, H, W, Cout).permute(0, 3, 1, 2)
+    y.backward(dy)
+    yl = y.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
+    return {'y': yl, 'stats': torch.stack([yl.sum(0), (yl * yl).sum(0)], 1),
+            'g': [x.grad.permute(0, 2, 3, 1).reshape(-1, x.shape[1]) for x in xs],
+            'dab': [torch.stack([a.grad, b.grad], 1) for a, b in zip(as_, bs)],
+            'dw': w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)}
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=[s[0] for s in SHAPES])
+def test_halo_patch_kernels_match_fp64_reference_and_generic(lib, shape):
+    name, N, H, W, Cs, Cout, dil = shape
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    P = N * H * W
+    data = {'x': [rnd(P, c) for c in Cs], 'a': [rnd(c) for c in Cs], 'b': [0.3 * rnd(c) for c in Cs],
+            'w': 0.1 * rnd(Cout, 9 * sum(Cs)), 'dy': rnd(P, Cout)}
+    ref = _reference(shape, data)
+    fast = _run(lib, FAST_ALL, shape, data)
+    slow = _run(lib, 0, shape, data)
+    bad = []
+    for tag, got in (('fast', fast), ('generic', slow)):
+        errs = {'y': _rel(got['y'], ref['y']), 'stats': _rel(got['stats'], ref['stats']), 'dw': _rel(got['dw'], ref['dw'])}
+        for i in range(len(Cs)):
+            errs['g%d' % i] = _rel(got['g'][i], ref['g'][i])
+            errs['dab%d' % i] = _rel(got['dab'][i], ref['dab'][i])
+        bad += ['%s/%s %.2e' % (tag, k, v) for k, v in errs.items() if not v <= TOL]
+    assert not bad, 'beyond %.0e of the fp64 reference: %s' % (TOL, ', '.join(bad))
+    assert _rel(fast['y'], slow['y']) <= 1e-5 and _rel(fast['dw'], slow['dw']) <= 1e-5
