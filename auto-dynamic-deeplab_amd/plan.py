@@ -447,7 +447,7 @@ class Graph:
                   rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
         self.meta.append(dict(kind='conv_fwd', idx=len(self.fwd) - 1, flops=2.0 * N * OH * OW * Cout * k * k * csum,
                               bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
-                              shape=(N, H, W, csum, Cout, k, stride, dil)))
+                              shape=(N, H, W, csum, Cout, k, stride, dil), halo=npk > 0))
 
         if self.want_grad:
             srcs_l = list(srcs)
