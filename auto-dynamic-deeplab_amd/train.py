@@ -78,15 +78,18 @@ class TrainStep:
                    ignore_index, self.wsum.data_ptr(), 1.0 / nex, self.loss.data_ptr(), d.data_ptr(), ws.data_ptr(),
                    rd=[o.y, self.target, self.wsum], wr=[self.loss, d, ws])
             o.dy_ptr, o.dynamic = d.data_ptr(), False
+        has_coll = sync_comm is not None and (self.world > 1 or sync_comm.force)
         if nstreams is None:
-            nstreams = int(os.environ.get('ADDK_STREAMS', '1'))    # >1: independent branches on parallel streams (+5 % eager; opt-in)
+            # two HIP streams: independent branches of the cell DAG overlap (-4 ms of 82 at config 2, eager or captured).
+            # Three or more crash hipStreamEndCapture on ROCm 7.2 (eager they gain nothing further), and the SyncBN
+            # path keeps its collectives on one stream.
+            nstreams = int(os.environ.get('ADDK_STREAMS', '1' if has_coll else '2'))
         g.finalize(nstreams)
         self.nbt = NbtCounter(g.nbt)
         self.nbt.bump(); self.nbt.flat.sub_(self.nbt.inc)      # flatten now (pointers must be fixed before graph capture)
         self.n_active = self.flat_p.numel()
         self.nbytes = g.nbytes
         if use_graph is None:
-            has_coll = sync_comm is not None and (self.world > 1 or sync_comm.force)
             use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (not has_coll or os.environ.get('ADDK_GRAPH_DDP', '0') == '1')
         self.graph = None
         self.use_graph = use_graph
