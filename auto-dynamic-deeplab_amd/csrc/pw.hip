@@ -9,6 +9,8 @@
 //   * the lazy BatchNorm/ReLU prologue is applied to the fragment in registers,
 //   * the epilogue stores 16 B per lane and keeps the BN statistics / (dA,dB) sums in per-lane fp64 registers for the
 //     whole kernel; one butterfly + cross-wave LDS reduction at the very end writes the block's slab row.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -27,63 +29,77 @@ struct PwK {
   int P; int ntiles16; int rows;       // rows: slab rows the caller allocated (>= gridDim.x; the extra rows are zero-filled)
 };
 
-template <int CT, int KG, int MODE>     // CT column tiles of 16, KG groups of 16 reduction channels
-__global__ void __launch_bounds__(256) pw_kernel(const PwK p) {
+// These launches are latency chains (kernel arguments -> weight panel -> one or two pixel tiles -> store -> statistics)
+// run by a few thousand waves: what sets their duration is how many of those chains are resident at once, so the kernel
+// is kept under 128 (KG=3) / 168 (KG=5) registers for 4 / 3 waves per SIMD: no prefetch buffer (occupancy hides the
+// latency) and, for maps of >= 4096 pixels, per-lane statistics in fp32 (a lane sums at most a handful of values; the
+// cross-lane / cross-wave / cross-block sums stay fp64).
+template <int CT, int KG, int MODE, bool RED32>     // CT column tiles of 16, KG groups of 16 reduction channels
+__global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p) {
   __shared__ double red[4][CT * 16][2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.y * (CT * 16);
 
   // ---- weight panel -> registers (A operand: row = output channel li of tile i, k = 16g + 4kq + e) ----
+  // Every load below is unconditional (masked lanes read a safe address and are zeroed afterwards) so that the whole
+  // panel, the prologue coefficients and the first pixel tile are ONE round trip to memory, not a chain of them.
   float4 wf[CT][KG];
 #pragma unroll
   for (int i = 0; i < CT; ++i)
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const int n = n0 + i * 16 + li, k = 16 * g + 4 * kq;
-      float4 v = zero4();
-      if (n < p.Cn) {
-        if (MODE == PW_FWD) {
-          v = ld4g(p.w + (long)n * p.ldw + p.w_off + k, p.K - k, (p.ldw & 3) == 0 && (p.w_off & 3) == 0);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (k + e < p.K) set4(v, e, p.w[(long)(k + e) * p.ldw + p.w_off + n]);
-        }
+      const bool ok = n < p.Cn && k < p.K;          // K % 4 == 0: a quad is valid as a whole
+      float4 v;
+      if (MODE == PW_FWD) {
+        v = ld4(ok ? p.w + (long)n * p.ldw + p.w_off + k : p.w);
+      } else {
+        const float* b = ok ? p.w + (long)k * p.ldw + p.w_off + n : p.w;
+        const long st = ok ? p.ldw : 0;
+        v = make_float4(b[0], b[st], b[2 * st], b[3 * st]);
       }
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
       wf[i][g] = v;
     }
   // lazy prologue coefficients of this lane's k slots
+  const bool relu = p.src.relu != 0;
+  const bool pro = relu || p.src.a != nullptr;
   float4 pa[KG], pb[KG];
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
     const int k = 16 * g + 4 * kq;
     pa[g] = make_float4(1.f, 1.f, 1.f, 1.f); pb[g] = zero4();
-    if (p.src.a && k < p.K) { pa[g] = ld4g(p.src.a + k, p.K - k, true); pb[g] = ld4g(p.src.b + k, p.K - k, true); }
+    if (p.src.a) {                                  // wave-uniform
+      const bool ok = k < p.K;
+      const float4 av = ld4(p.src.a + (ok ? k : 0)), bv = ld4(p.src.b + (ok ? k : 0));
+      pa[g].x = ok ? av.x : 1.f; pa[g].y = ok ? av.y : 1.f; pa[g].z = ok ? av.z : 1.f; pa[g].w = ok ? av.w : 1.f;
+      pb[g].x = ok ? bv.x : 0.f; pb[g].y = ok ? bv.y : 0.f; pb[g].z = ok ? bv.z : 0.f; pb[g].w = ok ? bv.w : 0.f;
+    }
   }
-  const bool relu = p.src.relu != 0;
-  const bool pro = relu || p.src.a != nullptr;
 
-  double s1[CT][4], s2[CT][4];
+  typedef typename std::conditional<RED32, float, double>::type red_t;
+  red_t s1[CT][4], s2[CT][4];
 #pragma unroll
   for (int i = 0; i < CT; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { s1[i][e] = 0.0; s2[i][e] = 0.0; }
+    for (int e = 0; e < 4; ++e) { s1[i][e] = 0; s2[i][e] = 0; }
 
   const int wstride = gridDim.x * 4;
-  float4 xf[KG], xn[KG];
+  float4 xf[KG];
   auto load_tile = [&](int tile, float4 (&x)[KG]) {
     const int pp = tile * 16 + li;
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const int k = 16 * g + 4 * kq;
-      x[g] = (pp < p.P && k < p.K) ? ld4g(p.src.x + (long)pp * p.src.ld + k, p.K - k, true) : zero4();
+      const bool ok = pp < p.P && k < p.K;
+      float4 v = ld4(ok ? p.src.x + (long)pp * p.src.ld + k : p.src.x);
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      x[g] = v;
     }
   };
-  int tile = blockIdx.x * 4 + wave;
-  if (tile < p.ntiles16) load_tile(tile, xf);
-  for (; tile < p.ntiles16; tile += wstride) {
-    const int nxt = tile + wstride;
-    if (nxt < p.ntiles16) load_tile(nxt, xn);
+  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles16; tile += wstride) {
+    load_tile(tile, xf);
     const int pp = tile * 16 + li;
     if (pro) {
 #pragma unroll
@@ -91,9 +107,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwK p) {
         float4 v = xf[g];
         v.x = fmaf(pa[g].x, v.x, pb[g].x); v.y = fmaf(pa[g].y, v.y, pb[g].y); v.z = fmaf(pa[g].z, v.z, pb[g].z); v.w = fmaf(pa[g].w, v.w, pb[g].w);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        const int nrem = p.K - (16 * g + 4 * kq);
-        if (pp >= p.P || nrem <= 0) v = zero4();
-        else if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
+        const bool ok = pp < p.P && 16 * g + 4 * kq < p.K;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
         xf[g] = v;
       }
     }
@@ -121,7 +136,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwK p) {
           st4g(p.y + (long)pp * p.ldy + c, v, nrem, true);
           if (p.slab) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const double f = e < nrem ? (double)get4(v, e) : 0.0; s1[i][e] += f; s2[i][e] += f * f; }
+            for (int e = 0; e < 4; ++e) { const red_t f = e < nrem ? (red_t)get4(v, e) : (red_t)0; s1[i][e] += f; s2[i][e] += f * f; }
           }
         } else {
           float4 x = ld4g(p.dst.x + (long)pp * p.dst.ld + c, nrem, true);
@@ -133,7 +148,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwK p) {
             const float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), dz = get4(v, e);
             const bool m = (e < nrem) && (!p.dst.relu || fmaf(ae, xe, be) > 0.f);
             set4(g4, e, m ? dz * ae : 0.f);
-            if (p.slab && m) { s1[i][e] += (double)dz * (double)xe; s2[i][e] += (double)dz; }
+            if (p.slab && m) { s1[i][e] += (red_t)dz * (red_t)xe; s2[i][e] += (red_t)dz; }
           }
           float* gp = p.y + (long)pp * p.ldy + c;
           if (p.accumulate) { float4 o = ld4g(gp, nrem, true); g4.x += o.x; g4.y += o.y; g4.z += o.z; g4.w += o.w; }
@@ -141,8 +156,6 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwK p) {
         }
       }
     }
-#pragma unroll
-    for (int g = 0; g < KG; ++g) xf[g] = xn[g];
   }
 
   if (p.slab) {     // once per kernel: butterfly over the 16 pixel lanes, then the four waves through LDS (fixed order)
@@ -150,10 +163,10 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwK p) {
     for (int i = 0; i < CT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        double a = s1[i][e], b = s2[i][e];
+        red_t a = s1[i][e], b = s2[i][e];
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-        if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = a; red[wave][i * 16 + kq * 4 + e][1] = b; }
+        if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = (double)a; red[wave][i * 16 + kq * 4 + e][1] = (double)b; }
       }
     __syncthreads();
     if (t < CT * 16 && n0 + t < p.Cn) {
@@ -172,7 +185,7 @@ template <int MODE>
 int pw_launch(PwK& k, int rows, hipStream_t st) {
   const int kg = cdiv(k.K, 16);
   // up to 3 column tiles per block (K <= 80: <= 60 weight VGPRs)
-  int ct = 3;
+  int ct = kg == 5 ? (getenv("ADDK_PW_CT5") ? atoi(getenv("ADDK_PW_CT5")) : 2) : 3;      // K = 80: two column tiles keep the kernel spill-free at 3 waves / SIMD
   if (cdiv(k.Cn, 16) < ct) ct = cdiv(k.Cn, 16);
   if (ct < 1) ct = 1;
   k.rows = rows;
@@ -180,8 +193,12 @@ int pw_launch(PwK& k, int rows, hipStream_t st) {
   if (gx > cdiv(k.ntiles16, 4)) gx = cdiv(k.ntiles16, 4);
   if (gx < 1) gx = 1;
   dim3 grid(gx, cdiv(k.Cn, 16 * ct));
+  const bool red32 = k.P >= 4096;
 #define ADDK_PW(CT_, KG_) \
-  if (ct == CT_ && kg == KG_) { hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE>), grid, dim3(256), 0, st, k); return addk_check_launch("pw_conv"); }
+  if (ct == CT_ && kg == KG_) { \
+    if (red32) hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, k); \
+    else hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, false>), grid, dim3(256), 0, st, k); \
+    return addk_check_launch("pw_conv"); }
   ADDK_PW(1, 3) ADDK_PW(2, 3) ADDK_PW(3, 3)
   ADDK_PW(1, 5) ADDK_PW(2, 5) ADDK_PW(3, 5)
 #undef ADDK_PW
@@ -196,7 +213,7 @@ int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream) {
   const addk_src& s = a->src[0];
   const int kg = cdiv(s.C, 16);
   if (!(kg == 3 || kg == 5) || !src_vec_ok(s) || !aligned16(a->y) || a->ldy % 4 || a->Cout % 4 || a->H != a->OH || a->W != a->OW) return 1;
-  if (!aligned16(a->w)) return 1;
+  if (!aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return 1;
   PwK k{};
   k.src = s; k.K = s.C; k.Cn = a->Cout; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
   k.y = a->y; k.ldy = a->ldy; k.bias = a->bias;

@@ -10,6 +10,8 @@ Activations are *lazy*: `Act = (raw, bn, relu)` means relu?(a*raw+b) with (a,b) 
 the producing BatchNorm; consumers apply it while staging their tiles, so BatchNorm/ReLU
 never cost a pass over HBM.
 """
+import collections
+import os
 import ctypes as C
 
 import torch
@@ -334,6 +336,12 @@ class Graph:
                     blob = torch.frombuffer(host, dtype=torch.uint8).clone()
                 self.keep += [arr, meta, blob]
                 self.nbytes += int(size)
+                if os.environ.get('ADDK_DEBUG_WGRAD') == '1':      # algorithmic work of this batch (tuning aid)
+                    fl = sum(2.0 * w.N * w.OH * w.OW * w.Cout * w.KH * w.KW * w.src.C for w, _, _ in items)
+                    by = sum(4.0 * (w.N * w.OH * w.OW * w.Cout + w.N * w.H * w.W * w.src.C) for w, _, _ in items)
+                    shapes = collections.Counter((w.OH, w.OW, w.Cout, w.src.C, w.KH, w.stride) for w, _, _ in items)
+                    print('wgrad batch kind/cty/ctz=%s n=%d blocks=%d  %.1f GF  %.1f MB min traffic  %s' % (
+                        key, n, meta[5], fl / 1e9, by / 1e6, dict(shapes)), flush=True)
                 self._add(self.bwd, 'conv_wgrad_batch', lib.addk_conv_wgrad_batch_run, blob.data_ptr(), meta,
                           rd=[r for _, rd, _ in items for r in rd], wr=[g for _, _, g in items])
 

@@ -22,11 +22,18 @@ int main(int argc, char** argv) {
     {"aspp 3x3 d6 256->256 @64x128", 2, 64, 128, 256, 256, 3, 6},
     {"stem 3x3 64->64 @512x1024", 2, 512, 1024, 64, 64, 3, 1},
     {"aspp 1x1 1280->256 @64x128", 2, 64, 128, 1280, 256, 1, 1},
+    {"cell 1x1 40->40 @125x253", 2, 125, 253, 40, 40, 1, 1},
+    {"cell 1x1 80->80 @63x127", 2, 63, 127, 80, 80, 1, 1},
+    {"cell 1x1 160->160 @32x64", 2, 32, 64, 160, 160, 1, 1},
+    {"cell 1x1 200->40 @125x253", 2, 125, 253, 200, 40, 1, 1},
+    {"cell 5x5 40->40 @125x253", 2, 125, 253, 40, 40, 5, 1},
   };
+  const char* only = getenv("SHAPES");
   int reps = argc > 1 ? atoi(argv[1]) : 20;
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (const Shape& s : shapes) {
+    if (only && !strstr(s.name, only)) continue;
     long P = (long)s.N * s.H * s.W;
     int taps = s.k * s.k, pad = s.dil * (s.k - 1) / 2;
     float* x = dev_rand(P * s.Cin, 1.f); float* a = dev_rand(s.Cin, 1.f); float* b = dev_rand(s.Cin, 0.5f);
@@ -58,7 +65,8 @@ int main(int argc, char** argv) {
       hipStreamSynchronize(st);
       hipEventRecord(e0, st); for (int r = 0; r < reps; ++r) run(); hipEventRecord(e1, st); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-      printf("%-34s %-5s %8.1f us  %6.1f TFLOP/s (%.1f GF)\n", s.name, mode == 0 ? "fwd" : mode == 1 ? "dgrad" : "wgrad", ms * 1e3, gf / ms, gf);
+      double mb = 4.0 * P * (s.Cin + s.Cout) * 1e-6;
+      printf("%-34s %-5s %8.1f us  %6.1f TFLOP/s (%.1f GF)  %6.0f GB/s of min traffic\n", s.name, mode == 0 ? "fwd" : mode == 1 ? "dgrad" : "wgrad", ms * 1e3, gf / ms, gf, mb / ms);
     }
     hipFree(x); hipFree(a); hipFree(b); hipFree(w); hipFree(y); hipFree(g); hipFree(slab); hipFree(dab); hipFree(wg.dw); hipFree(wg.ws);
   }
