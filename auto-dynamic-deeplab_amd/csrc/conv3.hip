@@ -23,9 +23,10 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 constexpr int C3_BP = 128;                 // pixels per tile (one row segment)
 constexpr int C3_BK = 16;                  // channels per chunk
 constexpr int C3_RS = 20;                  // floats per patch pixel in LDS (16 + 4: ds_read_b64 fragment reads hit 64 distinct banks per half-wave)
-constexpr int C3_PWMAX = C3_BP + 2 * 18;   // widest patch row (dilation 18)
 constexpr int C3_MAXCH = 64;               // chunks per launch (K <= 1024 channels)
-constexpr int C3_NS = (3 * C3_PWMAX * 4 + 255) / 256;   // 16-byte patch slots per thread
+// widest patch row: 3x3 up to dilation 18 (ASPP), 5x5 up to dilation 2 (the cells' dil_conv_5x5)
+constexpr int c3_pwmax(int ks) { return ks == 3 ? C3_BP + 2 * 18 : C3_BP + 4 * 2; }
+constexpr int c3_maxdil(int ks) { return ks == 3 ? 18 : 2; }
 
 struct C3K {
   addk_src src[ADDK_MAX_SRC];
@@ -35,7 +36,7 @@ struct C3K {
   float* y;
   const float* wp;          // packed weights of this launch
   long wp_blk;              // floats per column block in wp
-  int nT;                   // chunks * 9
+  int nT;                   // chunks * taps
   const float* bias; const float* bias_n;
   double* slab; int slab_ld;
   addk_src dst; int accumulate;
@@ -48,65 +49,69 @@ struct PackK {
   int mode;                 // fwd: rows = co, K = input channels; dgrad: rows = input channels, K = co
   int Cn;                   // GEMM N extent (rows of the packed tiles)
   int w_choff;              // dgrad: channel offset of the destination source inside a tap
-  int nchunks, bct;
+  int nchunks, bct, taps;
   int cbase[C3_MAXCH];      // first K index of the chunk (fwd: absolute channel inside a tap; dgrad: co)
   int cvalid[C3_MAXCH];     // valid K entries in the chunk (<= 16)
   float* out;
 };
 
-// out[colblk][T = chunk*9 + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
+// out[colblk][T = chunk*taps + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
 __global__ void __launch_bounds__(256) c3_pack_kernel(const PackK p) {
   const int BC = 16 * p.bct;
-  const long per_blk = (long)p.nchunks * 9 * p.bct * 256;
+  const int nT = p.nchunks * p.taps;
+  const long per_blk = (long)nT * p.bct * 256;
   const long total = (long)((p.Cn + BC - 1) / BC) * per_blk;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int m = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     long r = idx >> 8;
     const int i = (int)(r % p.bct); r /= p.bct;
-    const int T = (int)(r % (p.nchunks * 9)); const int blk = (int)(r / (p.nchunks * 9));
-    const int chunk = T / 9, tap = T - chunk * 9;
+    const int T = (int)(r % nT); const int blk = (int)(r / nT);
+    const int chunk = T / p.taps, tap = T - chunk * p.taps;
     const int li = lane & 15, kq = lane >> 4;
     const int row = blk * BC + i * 16 + li;
     const int kk = 8 * (m >> 1) + 2 * kq + (m & 1);
     float v = 0.f;
     if (row < p.Cn && kk < p.cvalid[chunk]) {
       if (p.mode == MODE_FWD) v = p.w[(long)row * p.ldw + (long)tap * p.cin_total + p.cbase[chunk] + kk];
-      else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(8 - tap) * p.cin_total + p.w_choff + row];
+      else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
     }
     p.out[idx] = v;
   }
 }
 
-template <int BCT, int MODE>
+template <int BCT, int KS, int MODE>
 __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
   constexpr int BC = 16 * BCT;
+  constexpr int TAPS = KS * KS, HK = KS / 2;
+  constexpr int C3_PWMAX = c3_pwmax(KS);
+  constexpr int C3_NS = (KS * C3_PWMAX * 4 + 255) / 256;   // 16-byte patch slots per thread
   constexpr int WC = BCT == 8 ? 2 : 1;      // waves across output channels
   constexpr int WP = 4 / WC;                // waves across pixels
   constexpr int PT = 8 / WP;                // 16-pixel tiles per wave
   constexpr int CT = BCT / WC;              // 16-channel tiles per wave
-  __shared__ __attribute__((aligned(16))) float Ps[3 * C3_PWMAX * C3_RS];
+  __shared__ __attribute__((aligned(16))) float Ps[KS * C3_PWMAX * C3_RS];
   __shared__ double red[WP][BC][2];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
   const int wc = wave % WC, wpx = wave / WC;
   const int n0 = blockIdx.y * BC;
-  const int d = p.dil, PW = C3_BP + 2 * d;
+  const int d = p.dil, PW = C3_BP + (KS - 1) * d;
   double tot0 = 0.0, tot1 = 0.0;
 
-  // fixed patch-slot geometry, packed to one register per slot: slot -> (row r | patch column pj << 2); r == 3: outside the patch
+  // fixed patch-slot geometry, packed to one register per slot: slot -> (row r | patch column pj << 3); r == KS: outside the patch
   const int q = t & 3;
   int geo[C3_NS];
 #pragma unroll
   for (int k = 0; k < C3_NS; ++k) {
     const int pix = (t + 256 * k) >> 2;
     int r = pix / PW; const int pj = pix - r * PW;
-    if (r > 3) r = 3;
-    geo[k] = r | (pj << 2);
+    if (r > KS) r = KS;
+    geo[k] = r | (pj << 3);
   }
   // fragment read bases (bytes are implied by float indexing): pixel (wpx*PT*16 + li) of patch row 0, k pair 2*kq, per kw
-  int xb[3];
+  int xb[KS];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) xb[kw] = (wpx * PT * 16 + li + kw * d) * C3_RS + 2 * kq;
+  for (int kw = 0; kw < KS; ++kw) xb[kw] = (wpx * PT * 16 + li + kw * d) * C3_RS + 2 * kq;
   const float4* wpl = reinterpret_cast<const float4*>(p.wp + (long)blockIdx.y * p.wp_blk) + (long)wc * CT * 64 + lane;
   const int nT = p.nT;
 
@@ -119,12 +124,12 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
     const int ow0 = sx * C3_BP;
     // per-tile validity of the slots (image borders)
     unsigned vmask = 0;
-    const int pbase = (n * p.H + oh - d) * p.W + ow0 - d;      // pixel index of patch (row 0, column 0)
+    const int pbase = (n * p.H + oh - HK * d) * p.W + ow0 - HK * d;      // pixel index of patch (row 0, column 0)
 #pragma unroll
     for (int k = 0; k < C3_NS; ++k) {
-      const int r = geo[k] & 3, pj = geo[k] >> 2;
-      const int ih = oh + (r - 1) * d, iw = ow0 - d + pj;
-      const bool ok = r < 3 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const int r = geo[k] & 7, pj = geo[k] >> 3;
+      const int ih = oh + (r - HK) * d, iw = ow0 - HK * d + pj;
+      const bool ok = r < KS && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       vmask |= (ok ? 1u : 0u) << k;
     }
 
@@ -147,7 +152,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
       const float* sb = S.x + (pch ? c : 0);
 #pragma unroll
       for (int k = 0; k < C3_NS; ++k) {
-        const int r = geo[k] & 3, pj = geo[k] >> 2;
+        const int r = geo[k] & 7, pj = geo[k] >> 3;
         const int po = ((vmask >> k) & 1u) ? pbase + r * d * p.W + pj : 0;
         ra[k] = ld4(sb + (long)po * S.ld);
       }
@@ -160,8 +165,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
         if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         const bool ok = pch && ((vmask >> k) & 1u);
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-        const int r = geo[k] & 3, pj = geo[k] >> 2;
-        if (r < 3) st4(&Ps[(r * C3_PWMAX + pj) * C3_RS + 4 * q], v);
+        const int r = geo[k] & 7, pj = geo[k] >> 3;
+        if (r < KS) st4(&Ps[(r * C3_PWMAX + pj) * C3_RS + 4 * q], v);
       }
     };
 
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
     // pixel fragments: one buffer per half of the 16-channel chunk (k 0-7 / 8-15), read one half ahead
     float2 xf[2][PT];
     auto read_x = [&](int tap, int h, float2* x) {
-      const int kh = tap / 3, kw = tap - kh * 3;
+      const int kh = tap / KS, kw = tap - kh * KS;
       const float* b = &Ps[xb[kw] + kh * C3_PWMAX * C3_RS + 8 * h];
 #pragma unroll
       for (int j = 0; j < PT; ++j) x[j] = *reinterpret_cast<const float2*>(b + j * 16 * C3_RS);
@@ -203,21 +208,21 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
       const bool more = s2 < p.nsrc;
       read_x(0, 0, xf[0]);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      for (int tap = 0; tap < TAPS; ++tap) {
         load_w(T0 + tap + 1, wr[(tap + 1) & 1]);
         if (tap == 0 && more) load_patch(s2, c2);
         read_x(tap, 1, xf[1]);
         __builtin_amdgcn_sched_barrier(0);
         mma(wr[tap & 1], 0, xf[0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (tap + 1 < 9) read_x(tap + 1, 0, xf[0]);
+        if (tap + 1 < TAPS) read_x(tap + 1, 0, xf[0]);
         __builtin_amdgcn_sched_barrier(0);
         mma(wr[tap & 1], 1, xf[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      T0 += 9;
+      T0 += TAPS;
 #pragma unroll
-      for (int i = 0; i < CT; ++i) wr[0][i] = wr[1][i];      // nine taps per chunk: the set fetched during tap 8 is next chunk's tap 0
+      for (int i = 0; i < CT; ++i) wr[0][i] = wr[1][i];      // odd tap count: the set fetched during the last tap is next chunk's tap 0
       __syncthreads();
       if (!more) break;
       s = s2; c0 = c2;
@@ -310,41 +315,51 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
 }
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
-// 128-channel column blocks when that still yields >= 512 blocks (2 per CU), else 64-channel blocks (ASPP's 64x128 maps)
+// Column block (16-channel tiles per block).  128-channel blocks (2x2 waves) for the wide heads when that still
+// yields >= 512 blocks; otherwise the narrowest of 3/4/5 tiles that pads the channel count least (cells: 40 -> 3 tiles,
+// 80 and 160 -> 5 tiles; stem / small ASPP maps: 4 tiles).
 int c3_bct(int Cn, long P) {
-  if (Cn < 128) return 4;
   const long tiles = (P + C3_BP - 1) / C3_BP;
-  return tiles * ((Cn + 127) / 128) >= 512 ? 8 : 4;
+  if (Cn >= 128 && Cn % 128 == 0 && tiles * (Cn / 128) >= 512) return 8;
+  int best = 4; long bc = -1;
+  const int cands[3] = {5, 4, 3};
+  for (int i = 0; i < 3; ++i) {
+    const long cols = (long)cdiv(Cn, 16 * cands[i]) * 16 * cands[i];
+    if (bc < 0 || cols < bc) { bc = cols; best = cands[i]; }
+  }
+  return best;
 }
-long c3_pack_floats(int Cn, int nchunks, long P) {
+long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
   const int bct = c3_bct(Cn, P);
-  return (long)cdiv(Cn, 16 * bct) * nchunks * 9 * bct * 256;
+  return (long)cdiv(Cn, 16 * bct) * nchunks * taps * bct * 256;
 }
 bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn) {
-  return c3_enabled() && KH == 3 && KW == 3 && stride == 1 && pad == dil && dil >= 1 && dil <= 18 && OH == H && OW == W &&
-         W >= 64 && P >= 8192 && Cn >= 64 && addk_get_conv_precision() == 0;
+  if (!c3_enabled() || KH != KW || !(KH == 3 || KH == 5) || stride != 1 || dil < 1 || dil > c3_maxdil(KH)) return false;
+  return pad == dil * (KH / 2) && OH == H && OW == W && W >= 100 && P >= 8192 && Cn >= 32 && addk_get_conv_precision() == 0;
 }
 
 int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st) {
   const int bct = c3_bct(k.Cn, k.P);
   pk.bct = bct; pk.mode = mode; pk.Cn = k.Cn;
-  k.nT = pk.nchunks * 9;
+  k.nT = pk.nchunks * pk.taps;
   k.wp = pk.out;
-  k.wp_blk = (long)pk.nchunks * 9 * bct * 256;
+  k.wp_blk = (long)pk.nchunks * pk.taps * bct * 256;
   k.spr = cdiv(k.W, C3_BP);
   k.ntiles = k.N * k.H * k.spr;
   k.red32 = k.P >= 4096;
-  const long total = c3_pack_floats(k.Cn, pk.nchunks, k.P);
+  const long total = c3_pack_floats(k.Cn, pk.nchunks, k.P, pk.taps);
   int pb = cdiv(total, 256 * 4); if (pb > 4096) pb = 4096;
   hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
   dim3 grid(rows, cdiv(k.Cn, 16 * bct));
-  if (mode == MODE_FWD) {
-    if (bct == 8) hipLaunchKernelGGL((conv3_kernel<8, MODE_FWD>), grid, dim3(256), 0, st, k);
-    else          hipLaunchKernelGGL((conv3_kernel<4, MODE_FWD>), grid, dim3(256), 0, st, k);
-  } else {
-    if (bct == 8) hipLaunchKernelGGL((conv3_kernel<8, MODE_DGRAD>), grid, dim3(256), 0, st, k);
-    else          hipLaunchKernelGGL((conv3_kernel<4, MODE_DGRAD>), grid, dim3(256), 0, st, k);
-  }
+  bool done = false;
+#define ADDK_C3(B_, K_) \
+  if (!done && bct == B_ && pk.taps == K_ * K_) { \
+    if (mode == MODE_FWD) hipLaunchKernelGGL((conv3_kernel<B_, K_, MODE_FWD>), grid, dim3(256), 0, st, k); \
+    else hipLaunchKernelGGL((conv3_kernel<B_, K_, MODE_DGRAD>), grid, dim3(256), 0, st, k); \
+    done = true; }
+  ADDK_C3(3, 3) ADDK_C3(4, 3) ADDK_C3(5, 3) ADDK_C3(8, 3) ADDK_C3(3, 5) ADDK_C3(4, 5) ADDK_C3(5, 5)
+#undef ADDK_C3
+  if (!done) { addk_set_error("conv3: no instantiation for %d column tiles, %d taps", bct, pk.taps); return ADDK_ERR_UNSUPPORTED; }
   return addk_check_launch("conv3");
 }
 
@@ -357,7 +372,7 @@ extern "C" int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a) {
   int nch = 0;
   for (int i = 0; i < a->nsrc; ++i) { if (a->src[i].C % 4 || a->src[i].ld % 4) return 0; nch += cdiv(a->src[i].C, C3_BK); }
   if (nch > C3_MAXCH || a->ldy % 4) return 0;
-  return c3_pack_floats(a->Cout, nch, (long)a->N * a->H * a->W);
+  return c3_pack_floats(a->Cout, nch, (long)a->N * a->H * a->W, a->KH * a->KW);
 }
 extern "C" int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a) {
   if (!a) return 0;
@@ -365,7 +380,7 @@ extern "C" int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a) {
   if (a->Cout % 4 || a->lddy % 4 || a->ldg % 4 || a->dst.ld % 4 || a->dst.C % 4) return 0;
   const int nch = cdiv(a->Cout, C3_BK);
   if (nch > C3_MAXCH) return 0;
-  return c3_pack_floats(a->dst.C, nch, (long)a->N * a->H * a->W);
+  return c3_pack_floats(a->dst.C, nch, (long)a->N * a->H * a->W, a->KH * a->KW);
 }
 
 // 0 = launched, 1 = not covered (caller falls back to the generic kernel), <0 = error
@@ -386,7 +401,7 @@ int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) {
     }
     choff += a->src[i].C;
   }
-  pk.nchunks = nch; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = 0; pk.out = a->wpack;
+  pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = 0; pk.out = a->wpack;
   k.N = a->N; k.H = a->H; k.W = a->W; k.dil = a->dil;
   k.Cn = a->Cout; k.ldy = a->ldy; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n;
   k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
@@ -409,7 +424,7 @@ int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
     pk.cvalid[nch] = a->Cout - c0 < C3_BK ? a->Cout - c0 : C3_BK;
     ++nch;
   }
-  pk.nchunks = nch; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = a->w_choff; pk.out = a->wpack;
+  pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = a->w_choff; pk.out = a->wpack;
   k.N = a->N; k.H = a->H; k.W = a->W; k.dil = a->dil;
   k.Cn = a->dst.C; k.ldy = a->ldg; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr;
   k.slab = (double*)a->dab; k.slab_ld = a->dst.C;

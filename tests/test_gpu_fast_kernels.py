@@ -2,7 +2,8 @@
 gradient) through the C ABI: each launch is compared with an fp64 PyTorch reference of the same operation
 (relu(a*x+b) -> conv2d -> batch statistics, and its autograd) and with the generic kernels on identical buffers.
 The whole-network parity tests use maps too small to reach these kernels (they need >= 8192 pixels), so they are pinned
-here.  Tolerance: 2e-5 of the reference's max-abs for fp32 products with fp32 accumulation over K <= 2736."""
+here.  Tolerance: 2e-5 of the reference's max-abs for fp32 products with fp32 accumulation over K <= 2736.  Shapes cover the wide heads (3x3, dilation 1-18, 64/128-channel column blocks) and
+the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5, 40/80/160 channels, odd map sizes)."""
 import ctypes as C
 
 import numpy as np
@@ -16,12 +17,16 @@ TOL = 2e-5
 FAST_ALL = 7
 
 SHAPES = [
-    # name,            N,  H,   W, source channels, Cout, dil
-    ('two_src_d1',     1, 40, 256, (32, 16), 128, 1),
-    ('odd_tail_d2',    2, 33, 129, (24,), 64, 2),
-    ('aspp_like_d6',   1, 70, 128, (48,), 256, 6),
-    ('wide_blocks_d1', 2, 64, 256, (32,), 256, 1),
-    ('max_dil_d18',    1, 64, 128, (16,), 64, 18),
+    # name,            N,  H,   W, source channels, Cout, dil, k
+    ('two_src_d1',     1, 40, 256, (32, 16), 128, 1, 3),
+    ('odd_tail_d2',    2, 33, 129, (24,), 64, 2, 3),
+    ('aspp_like_d6',   1, 70, 128, (48,), 256, 6, 3),
+    ('wide_blocks_d1', 2, 64, 256, (32,), 256, 1, 3),
+    ('max_dil_d18',    1, 64, 128, (16,), 64, 18, 3),
+    ('cell_dil5_40',   1, 70, 125, (40,), 40, 2, 5),       # dil_conv_5x5 at level 1 (3 column tiles, K tail 40 = 16+16+8)
+    ('cell_dil5_80',   2, 63, 127, (80,), 80, 2, 5),       # level 2 (5 column tiles)
+    ('cell_dil3_40',   1, 70, 125, (40,), 40, 2, 3),       # dil_conv_3x3
+    ('cell_dil3_160',  2, 40, 104, (32,), 160, 2, 3),      # two 5-tile column blocks
 ]
 
 
@@ -42,7 +47,8 @@ def _run(L, fast, shape, data):
     """One forward + data gradient + weight gradient through the C ABI with the given fast-path mask."""
     lib = L.load()
     lib.addk_set_fast_paths(fast)
-    name, N, H, W, Cs, Cout, dil = shape
+    name, N, H, W, Cs, Cout, dil, ks = shape
+    taps, pad = ks * ks, dil * (ks // 2)
     dev = data['w'].device
     st = torch.cuda.current_stream().cuda_stream
     ctot = sum(Cs)
@@ -54,9 +60,9 @@ def _run(L, fast, shape, data):
         ar.src[i].ld, ar.src[i].C, ar.src[i].relu = Ci, Ci, 1
     ar.nsrc = len(Cs)
     ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, H, W
-    ar.KH = ar.KW = 3
-    ar.stride, ar.pad, ar.dil, ar.Cout = 1, dil, dil, Cout
-    ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = 9 * ctot, ctot, 0, Cout
+    ar.KH = ar.KW = ks
+    ar.stride, ar.pad, ar.dil, ar.Cout = 1, pad, dil, Cout
+    ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = taps * ctot, ctot, 0, Cout
     y = torch.empty(P, Cout, device=dev)
     rows = lib.addk_conv_rows(P, Cout)
     slab = torch.zeros(rows, Cout, 2, device=dev, dtype=torch.float64)
@@ -73,8 +79,8 @@ def _run(L, fast, shape, data):
     for i, Ci in enumerate(Cs):
         da = L.ConvDgradArgs()
         da.dy, da.lddy, da.Cout = data['dy'].data_ptr(), Cout, Cout
-        da.N, da.H, da.W, da.OH, da.OW, da.KH, da.KW, da.stride, da.pad, da.dil = N, H, W, H, W, 3, 3, 1, dil, dil
-        da.w, da.ldw, da.cin_total, da.w_choff = data['w'].data_ptr(), 9 * ctot, ctot, choff
+        da.N, da.H, da.W, da.OH, da.OW, da.KH, da.KW, da.stride, da.pad, da.dil = N, H, W, H, W, ks, ks, 1, pad, dil
+        da.w, da.ldw, da.cin_total, da.w_choff = data['w'].data_ptr(), taps * ctot, ctot, choff
         da.dst = ar.src[i]
         g = torch.empty(P, Ci, device=dev)
         r2 = lib.addk_conv_rows(P, Ci)
@@ -88,15 +94,15 @@ def _run(L, fast, shape, data):
         out['g'].append(g); out['dab'].append(dab.sum(0))
         wa = L.ConvWgradArgs()
         wa.dy, wa.lddy, wa.Cout = data['dy'].data_ptr(), Cout, Cout
-        wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, H, W, 3, 3, 1, dil, dil
+        wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, H, W, ks, ks, 1, pad, dil
         wa.src = ar.src[i]
-        wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = out['dw'].data_ptr(), 9 * ctot, ctot, choff, 0
-        wa.ws_floats = lib.addk_conv_wgrad_ws(P, Cout, Ci, 9)
+        wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = out['dw'].data_ptr(), taps * ctot, ctot, choff, 0
+        wa.ws_floats = lib.addk_conv_wgrad_ws(P, Cout, Ci, taps)
         ws = torch.empty(int(wa.ws_floats), device=dev); keep.append(ws)
         wa.ws = ws.data_ptr()
         cfg = (C.c_int32 * 4)()
         L.check(lib.addk_conv_wgrad_config(C.byref(wa), cfg), 'wgrad_config')
-        if Ci >= 16:
+        if Ci >= 16 and ks == 3 and Cout % 64 == 0:
             assert (cfg[0] == 5) == bool(fast & 4), 'weight gradient: kernel kind %d with mask %d' % (cfg[0], fast)
         L.check(lib.addk_conv_wgrad(C.byref(wa), st), 'conv_wgrad')
         choff += Ci
@@ -105,13 +111,13 @@ def _run(L, fast, shape, data):
 
 
 def _reference(shape, data):
-    name, N, H, W, Cs, Cout, dil = shape
+    name, N, H, W, Cs, Cout, dil, ks = shape
     xs = [x.double().view(N, H, W, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True) for x in data['x']]
     as_ = [a.double().requires_grad_(True) for a in data['a']]
     bs = [b.double().requires_grad_(True) for b in data['b']]
     z = torch.cat([F.relu(a.view(1, -1, 1, 1) * x + b.view(1, -1, 1, 1)) for x, a, b in zip(xs, as_, bs)], 1)
-    w = data['w'].double().view(Cout, 3, 3, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-    y = F.conv2d(z, w, padding=dil, dilation=dil)
+    w = data['w'].double().view(Cout, ks, ks, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.conv2d(z, w, padding=dil * (ks // 2), dilation=dil)
     dy = data['dy'].double().view(N, H, W, Cout).permute(0, 3, 1, 2)
     y.backward(dy)
     yl = y.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
@@ -123,13 +129,13 @@ def _reference(shape, data):
 
 @pytest.mark.parametrize('shape', SHAPES, ids=[s[0] for s in SHAPES])
 def test_halo_patch_kernels_match_fp64_reference_and_generic(lib, shape):
-    name, N, H, W, Cs, Cout, dil = shape
+    name, N, H, W, Cs, Cout, dil, ks = shape
     dev = torch.device('cuda:0')
     gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
     rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
     P = N * H * W
     data = {'x': [rnd(P, c) for c in Cs], 'a': [rnd(c) for c in Cs], 'b': [0.3 * rnd(c) for c in Cs],
-            'w': 0.1 * rnd(Cout, 9 * sum(Cs)), 'dy': rnd(P, Cout)}
+            'w': 0.1 * rnd(Cout, ks * ks * sum(Cs)), 'dy': rnd(P, Cout)}
     ref = _reference(shape, data)
     fast = _run(lib, FAST_ALL, shape, data)
     slow = _run(lib, 0, shape, data)
