@@ -59,6 +59,83 @@ __global__ void __launch_bounds__(256) dw_fwd_kernel(const DwK p) {
   }
 }
 
+// LDS-tiled forward for the vector-aligned case.  The kernel above issues its k*k loads one dependent round trip at a
+// time (25 for a 5x5) and is latency-bound at ~10 % of HBM speed.  Here a block owns a TH x 16 output tile of one
+// channel group (<= 10 channel quads): it stages the haloed input patch in LDS once — all loads of a thread are
+// independent and issued back to back, BatchNorm/ReLU applied on the way in, zero padding after it — and every tap
+// then reads LDS.
+struct DwT {
+  DwK k;
+  int nqb, ngrp;          // channel quads per block, channel groups
+  int TH, PH, PW;         // output rows per tile, patch rows / columns
+  int tiles_x, tiles_y;
+};
+constexpr int DW_TW = 16;
+
+template <int KS>
+__global__ void __launch_bounds__(256) dw_fwd_tile_kernel(const DwT t) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const DwK& p = t.k;
+  const int C4b = t.nqb * 4;
+  float* wl = sm;                              // [KS*KS][C4b]
+  float* patch = sm + KS * KS * C4b;           // [PH][PW][C4b]
+  const int grp = blockIdx.y, cg0 = grp * C4b;
+  const int C = p.src.C;
+  int b = blockIdx.x;
+  const int tx = b % t.tiles_x; b /= t.tiles_x;
+  const int ty = b % t.tiles_y; const int n = b / t.tiles_y;
+  const int oh0 = ty * t.TH, ow0 = tx * DW_TW;
+  const int ih0 = oh0 * p.stride - p.pad, iw0 = ow0 * p.stride - p.pad;
+  for (int i = threadIdx.x; i < KS * KS * C4b; i += 256) {
+    const int tp = i / C4b, c = cg0 + i - tp * C4b;
+    wl[i] = c < C ? p.w[(long)c * (KS * KS) + tp] : 0.f;
+  }
+  const int npl = 256 / t.nqb;
+  const int q = threadIdx.x % t.nqb, pl = threadIdx.x / t.nqb;
+  const int c = cg0 + 4 * q;
+  const bool cact = pl < npl && c < C;
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  if (p.src.a && cact) { av = ld4(p.src.a + c); bv = ld4(p.src.b + c); }
+  const bool relu = p.src.relu != 0;
+  if (pl < npl) {
+    const int npix = t.PH * t.PW;
+    const float* xb = p.src.x + (cact ? c : 0);
+#pragma unroll 4
+    for (int pix = pl; pix < npix; pix += npl) {
+      const int pr = pix / t.PW, pc = pix - pr * t.PW;
+      const int ih = ih0 + pr, iw = iw0 + pc;
+      const bool ok = cact && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      float4 v = ld4(xb + (ok ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
+      v.x = fmaf(av.x, v.x, bv.x); v.y = fmaf(av.y, v.y, bv.y); v.z = fmaf(av.z, v.z, bv.z); v.w = fmaf(av.w, v.w, bv.w);
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      st4(&patch[pix * C4b + 4 * q], v);
+    }
+  }
+  __syncthreads();
+  if (!cact) return;
+  float4 wr[KS * KS];
+#pragma unroll
+  for (int tp = 0; tp < KS * KS; ++tp) wr[tp] = ld4(&wl[tp * C4b + 4 * q]);
+  const int nout = t.TH * DW_TW;
+  for (int o = pl; o < nout; o += npl) {
+    const int orow = o / DW_TW, ocol = o - orow * DW_TW;
+    const int oh = oh0 + orow, ow = ow0 + ocol;
+    if (oh >= p.OH || ow >= p.OW) continue;
+    const float* pb = &patch[((orow * p.stride) * t.PW + ocol * p.stride) * C4b + 4 * q];
+    float4 acc = zero4();
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) {
+        const float4 v = ld4(pb + ((kh * p.dil) * t.PW + kw * p.dil) * C4b);
+        const float4 w = wr[kh * KS + kw];
+        acc.x = fmaf(w.x, v.x, acc.x); acc.y = fmaf(w.y, v.y, acc.y); acc.z = fmaf(w.z, v.z, acc.z); acc.w = fmaf(w.w, v.w, acc.w);
+      }
+    st4(p.y + ((long)(n * p.OH + oh) * p.OW + ow) * p.ldy + c, acc);
+  }
+}
+
 // Backward, organised by INPUT pixel: for input pixel p and tap t the output pixel o(p,t) that read p
 // through t contributes  w[t]*dy[o]  to dz[p]  and  dy[o]*z[p]  to dW[t]  — one pass yields both.
 template <int NT>
@@ -154,6 +231,129 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
   }
 }
 
+// LDS-tiled backward (stride 1): a block walks TH x 16 INPUT-pixel tiles of one channel group.  Per tile it stages the
+// dy patch those pixels touch ([TH+(k-1)d][16+(k-1)d][channels], zero outside the output map) with independent loads, then
+// every tap reads LDS; the weight-gradient and (dA,dB) sums stay in registers across all tiles of the block and are
+// reduced once, in the same fixed order as the kernel above.  Workspace rows beyond gridDim.x are zero-filled.
+template <int KS>
+__global__ void __launch_bounds__(256) dw_bwd_tile_kernel(const DwT t, int ntiles, int rows) {
+  constexpr int NT = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const DwK& p = t.k;
+  const int C4b = t.nqb * 4, C = p.src.C;
+  float* wl = sm;                              // [NT][C4b]
+  float* patch = sm + NT * C4b;                // [PH][PW][C4b]; reused as the reduction panel at the end
+  const int grp = blockIdx.y, cg0 = grp * C4b;
+  for (int i = threadIdx.x; i < NT * C4b; i += 256) {
+    const int tp = i / C4b, c = cg0 + i - tp * C4b;
+    wl[i] = c < C ? p.w[(long)c * NT + tp] : 0.f;
+  }
+  const int npl = 256 / t.nqb;
+  const int q = threadIdx.x % t.nqb, pl = threadIdx.x / t.nqb;
+  const int c = cg0 + 4 * q;
+  const bool cact = pl < npl && c < C;
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  if (p.src.a && cact) { av = ld4(p.src.a + c); bv = ld4(p.src.b + c); }
+  const bool relu = p.src.relu != 0;
+  float4 dwacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) dwacc[i] = zero4();
+  double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
+  const int halo = (KS - 1) * p.dil;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % t.tiles_x; b /= t.tiles_x;
+    const int ty = b % t.tiles_y; const int n = b / t.tiles_y;
+    const int ih0 = ty * t.TH, iw0 = tx * DW_TW;
+    const int oh0 = ih0 + p.pad - halo, ow0 = iw0 + p.pad - halo;     // output position of patch (0, 0)
+    __syncthreads();                                                 // previous tile's readers are done (and wl is ready)
+    if (pl < npl) {
+      const int npix = t.PH * t.PW;
+      const float* yb = p.dy + (cact ? c : 0);
+#pragma unroll 4
+      for (int pix = pl; pix < npix; pix += npl) {
+        const int pr = pix / t.PW, pc = pix - pr * t.PW;
+        const int oh = oh0 + pr, ow = ow0 + pc;
+        const bool ok = cact && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+        float4 v = ld4(yb + (ok ? ((long)(n * p.OH + oh) * p.OW + ow) * p.lddy : 0));
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        st4(&patch[pix * C4b + 4 * q], v);
+      }
+    }
+    __syncthreads();
+    if (cact) {
+      const int nin = t.TH * DW_TW;
+      for (int o = pl; o < nin; o += npl) {
+        const int r = o / DW_TW, cc = o - r * DW_TW;
+        const int ih = ih0 + r, iw = iw0 + cc;
+        if (ih >= p.H || iw >= p.W) continue;
+        const long pp = (long)(n * p.H + ih) * p.W + iw;
+        const float4 x = ld4(p.src.x + pp * p.src.ld + c);
+        const float4 zp = make_float4(fmaf(av.x, x.x, bv.x), fmaf(av.y, x.y, bv.y), fmaf(av.z, x.z, bv.z), fmaf(av.w, x.w, bv.w));
+        const bool m0 = !relu || zp.x > 0.f, m1 = !relu || zp.y > 0.f, m2 = !relu || zp.z > 0.f, m3 = !relu || zp.w > 0.f;
+        const float4 z = make_float4(m0 ? zp.x : 0.f, m1 ? zp.y : 0.f, m2 ? zp.z : 0.f, m3 ? zp.w : 0.f);
+        const float* pb = &patch[(r * t.PW + cc) * C4b + 4 * q];
+        float4 dz = zero4();
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const int tp = kh * KS + kw;
+            const float4 d = ld4(pb + (((KS - 1 - kh) * p.dil) * t.PW + (KS - 1 - kw) * p.dil) * C4b);
+            const float4 w = ld4(&wl[tp * C4b + 4 * q]);
+            dz.x = fmaf(w.x, d.x, dz.x); dz.y = fmaf(w.y, d.y, dz.y); dz.z = fmaf(w.z, d.z, dz.z); dz.w = fmaf(w.w, d.w, dz.w);
+            dwacc[tp].x = fmaf(d.x, z.x, dwacc[tp].x); dwacc[tp].y = fmaf(d.y, z.y, dwacc[tp].y);
+            dwacc[tp].z = fmaf(d.z, z.z, dwacc[tp].z); dwacc[tp].w = fmaf(d.w, z.w, dwacc[tp].w);
+          }
+        const float4 gm = make_float4(m0 ? dz.x : 0.f, m1 ? dz.y : 0.f, m2 ? dz.z : 0.f, m3 ? dz.w : 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sA[e] += (double)get4(gm, e) * (double)get4(x, e); sB[e] += (double)get4(gm, e); }
+        if (p.g) {
+          float4 gv = make_float4(gm.x * av.x, gm.y * av.y, gm.z * av.z, gm.w * av.w);
+          float* gp = p.g + pp * p.ldg + c;
+          if (p.accumulate) { const float4 o4 = ld4(gp); gv.x += o4.x; gv.y += o4.y; gv.z += o4.z; gv.w += o4.w; }
+          st4(gp, gv);
+        }
+      }
+    }
+  }
+  // fixed-order block reduction over the pixel lanes (same scheme as dw_bwd_kernel), channels of this group only
+  float* redt = patch;
+  const int cgn = (C - cg0 < C4b) ? C - cg0 : C4b;            // valid channels of this group
+  constexpr int TG = NT == 9 ? 3 : 5;
+#pragma unroll
+  for (int t0 = 0; t0 < NT; t0 += TG) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < TG; ++u)
+      if (pl < npl) *reinterpret_cast<float4*>(&redt[(u * npl + pl) * C4b + 4 * q]) = cact ? dwacc[t0 + u] : zero4();
+    __syncthreads();
+    for (int i = threadIdx.x; i < TG * cgn; i += 256) {
+      const int u = i / cgn, ch = i - u * cgn;
+      float sacc = 0.f;
+      for (int r = 0; r < npl; ++r) sacc += redt[(u * npl + r) * C4b + ch];
+      p.ws[((long)blockIdx.x * C + cg0 + ch) * NT + t0 + u] = sacc;
+      for (int rr = blockIdx.x + gridDim.x; rr < rows; rr += gridDim.x) p.ws[((long)rr * C + cg0 + ch) * NT + t0 + u] = 0.f;
+    }
+  }
+  if (p.dab) {
+    __syncthreads();
+    double* redd = reinterpret_cast<double*>(redt);      // [npl][C4b][2] doubles
+    if (pl < npl) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { redd[((pl * C4b) + 4 * q + e) * 2] = cact ? sA[e] : 0.0; redd[((pl * C4b) + 4 * q + e) * 2 + 1] = cact ? sB[e] : 0.0; }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < cgn; ch += 256) {
+      double a = 0.0, b2 = 0.0;
+      for (int r = 0; r < npl; ++r) { a += redd[(r * C4b + ch) * 2]; b2 += redd[(r * C4b + ch) * 2 + 1]; }
+      p.dab[((long)blockIdx.x * C + cg0 + ch) * 2] = a;
+      p.dab[((long)blockIdx.x * C + cg0 + ch) * 2 + 1] = b2;
+      for (int rr = blockIdx.x + gridDim.x; rr < rows; rr += gridDim.x) { p.dab[((long)rr * C + cg0 + ch) * 2] = 0.0; p.dab[((long)rr * C + cg0 + ch) * 2 + 1] = 0.0; }
+    }
+  }
+}
+
 // one 64-lane wave per weight element: lanes stride over the partial rows, then a fixed-order butterfly
 __global__ void __launch_bounds__(256) dw_wreduce_kernel(const float* ws, int rows, int n, float* dw, int accumulate) {
   const int lane = threadIdx.x & 63;
@@ -195,6 +395,27 @@ extern "C" int addk_dw_fwd(const addk_dw_args* a, void* stream) {
   k.w = a->w; k.y = a->y; k.ldy = a->ldy;
   k.P = (long)a->N * a->OH * a->OW;
   k.vec = src_vec_ok(a->src) && aligned16(a->y) && a->ldy % 4 == 0;
+  if (k.vec && a->KH == a->KW && (a->KH == 3 || a->KH == 5) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) && k.P >= 2048) {
+    DwT t; t.k = k;
+    t.nqb = k.nq <= 10 ? k.nq : (k.nq % 10 == 0 ? 10 : 8);
+    t.ngrp = cdiv(k.nq, t.nqb);
+    const int span = (a->KH - 1) * a->dil + 1;
+    t.PW = (DW_TW - 1) * a->stride + span;
+    const long row_bytes = (long)t.PW * t.nqb * 16;
+    int ph = (int)((48 * 1024) / row_bytes);                       // patch rows that fit the LDS budget
+    int th = (ph - span) / a->stride + 1;
+    if (th > 16) th = 16;
+    if (th > a->OH) th = a->OH;
+    if (th >= 2) {
+      t.TH = th; t.PH = (th - 1) * a->stride + span;
+      t.tiles_x = cdiv(a->OW, DW_TW); t.tiles_y = cdiv(a->OH, th);
+      const size_t shb = ((size_t)a->KH * a->KW * t.nqb * 4 + (size_t)t.PH * t.PW * t.nqb * 4) * sizeof(float);
+      dim3 grid((unsigned)(a->N * t.tiles_y * t.tiles_x), (unsigned)t.ngrp);
+      if (a->KH == 3) hipLaunchKernelGGL(dw_fwd_tile_kernel<3>, grid, dim3(256), shb, (hipStream_t)stream, t);
+      else            hipLaunchKernelGGL(dw_fwd_tile_kernel<5>, grid, dim3(256), shb, (hipStream_t)stream, t);
+      return addk_check_launch("dw_fwd_tile");
+    }
+  }
   long blocks = cdiv(k.P, k.npl); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
   size_t sh = (size_t)a->KH * a->KW * k.nq * 4 * sizeof(float);
   hipLaunchKernelGGL(dw_fwd_kernel, dim3((unsigned)blocks), dim3(256), sh, (hipStream_t)stream, k);
@@ -215,7 +436,34 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
   const int rows = dw_rows(k.P, a->src.C);
   size_t sh = (size_t)(taps * C4 + k.npl * C4 * 5) * sizeof(float);     // tap weights + [TG<=5][npl][C4] reduction panel (>= the fp64 (dA,dB) panel)
   hipStream_t st = (hipStream_t)stream;
-  if (taps == 9) hipLaunchKernelGGL(dw_bwd_kernel<9>, dim3(rows), dim3(256), sh, st, k);
+  bool tiled = false;
+  if (k.vec && a->stride == 1 && a->KH == a->KW && (a->KH == 3 || a->KH == 5) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) && k.P >= 2048) {
+    DwT t; t.k = k;
+    t.nqb = k.nq <= 10 ? k.nq : (k.nq % 10 == 0 ? 10 : 8);
+    t.ngrp = cdiv(k.nq, t.nqb);
+    const int halo = (a->KH - 1) * a->dil;
+    t.PW = DW_TW + halo;
+    const long row_bytes = (long)t.PW * t.nqb * 16;
+    int th = (int)((40 * 1024) / row_bytes) - halo;
+    if (th > 16) th = 16;
+    if (th > a->H) th = a->H;
+    const int npl = 256 / t.nqb;
+    const size_t panel = (size_t)5 * npl * t.nqb * 4 * sizeof(float);          // [TG<=5][npl][C4b] floats >= [npl][C4b][2] doubles
+    if (th >= 2) {
+      t.TH = th; t.PH = th + halo;
+      t.tiles_x = cdiv(a->W, DW_TW); t.tiles_y = cdiv(a->H, th);
+      const int ntiles = a->N * t.tiles_y * t.tiles_x;
+      size_t pbytes = (size_t)t.PH * t.PW * t.nqb * 16;
+      if (pbytes < panel) pbytes = panel;
+      const size_t shb = (size_t)taps * t.nqb * 16 + pbytes;
+      dim3 grid((unsigned)(ntiles < rows ? ntiles : rows), (unsigned)t.ngrp);
+      if (taps == 9) hipLaunchKernelGGL(dw_bwd_tile_kernel<3>, grid, dim3(256), shb, st, t, ntiles, rows);
+      else           hipLaunchKernelGGL(dw_bwd_tile_kernel<5>, grid, dim3(256), shb, st, t, ntiles, rows);
+      tiled = true;
+    }
+  }
+  if (tiled) {}
+  else if (taps == 9) hipLaunchKernelGGL(dw_bwd_kernel<9>, dim3(rows), dim3(256), sh, st, k);
   else if (taps == 25) hipLaunchKernelGGL(dw_bwd_kernel<25>, dim3(rows), dim3(256), sh, st, k);
   else { addk_set_error("dw_bwd: only 3x3 and 5x5 depthwise kernels are built"); return ADDK_ERR_UNSUPPORTED; }
   rc = addk_check_launch("dw_bwd");

@@ -15,6 +15,36 @@ static float* dev_rand(size_t n, float scale) {
 }
 struct Shape { const char* name; int N, H, W, Cin, Cout, k, dil; };
 
+static void dw_bench(hipStream_t st, hipEvent_t e0, hipEvent_t e1, int reps) {
+  struct D { const char* name; int N, H, W, C, k, s; } ds[] = {
+    {"dw 5x5 C40 @125x253", 2, 125, 253, 40, 5, 1}, {"dw 3x3 C40 @125x253", 2, 125, 253, 40, 3, 1},
+    {"dw 5x5 C80 @63x127", 2, 63, 127, 80, 5, 1}, {"dw 3x3 C80 @63x127", 2, 63, 127, 80, 3, 1},
+    {"dw 5x5 C160 @32x64", 2, 32, 64, 160, 5, 1}, {"dw 5x5 C40 s2 @125x253", 2, 125, 253, 40, 5, 2}};
+  for (auto& d : ds) {
+    long P = (long)d.N * d.H * d.W; int pad = d.k / 2;
+    int OH = (d.H + 2 * pad - d.k) / d.s + 1, OW = (d.W + 2 * pad - d.k) / d.s + 1; long PO = (long)d.N * OH * OW;
+    float* x = dev_rand(P * d.C, 1.f); float* a = dev_rand(d.C, 1.f); float* b = dev_rand(d.C, .5f); float* w = dev_rand(d.C * d.k * d.k, .3f);
+    float* y; hipMalloc(&y, PO * d.C * 4); float* g; hipMalloc(&g, P * d.C * 4); float* dw; hipMalloc(&dw, d.C * d.k * d.k * 4);
+    int rows = addk_dw_rows(P, d.C); double* dab; hipMalloc(&dab, (size_t)rows * d.C * 16); float* ws; hipMalloc(&ws, (size_t)rows * d.C * d.k * d.k * 4);
+    addk_dw_args ar; memset(&ar, 0, sizeof ar);
+    ar.src.x = x; ar.src.a = a; ar.src.b = b; ar.src.ld = d.C; ar.src.C = d.C; ar.src.relu = 1;
+    ar.N = d.N; ar.H = d.H; ar.W = d.W; ar.OH = OH; ar.OW = OW; ar.KH = ar.KW = d.k; ar.stride = d.s; ar.pad = pad; ar.dil = 1; ar.w = w; ar.y = y; ar.ldy = d.C;
+    addk_dw_bwd_args ba; memset(&ba, 0, sizeof ba);
+    ba.dy = y; ba.lddy = d.C; ba.N = d.N; ba.H = d.H; ba.W = d.W; ba.OH = OH; ba.OW = OW; ba.KH = ba.KW = d.k; ba.stride = d.s; ba.pad = pad; ba.dil = 1;
+    ba.src = ar.src; ba.w = w; ba.g = g; ba.ldg = d.C; ba.dab = dab; ba.dw = dw; ba.ws = ws;
+    for (int mode = 0; mode < 2; ++mode) {
+      auto run = [&] { return mode == 0 ? addk_dw_fwd(&ar, st) : addk_dw_bwd(&ba, st); };
+      if (run() != 0) { printf("%s: error %s\n", d.name, addk_last_error()); return; }
+      hipStreamSynchronize(st);
+      hipEventRecord(e0, st); for (int r = 0; r < reps; ++r) run(); hipEventRecord(e1, st); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      double mb = 4.0 * d.C * (mode == 0 ? P + PO : 2 * P + PO) * 1e-6;
+      printf("%-34s %-5s %8.1f us  %6.0f GB/s of min traffic (%.1f MB)\n", d.name, mode ? "bwd" : "fwd", ms * 1e3, mb / ms, mb);
+    }
+    hipFree(x); hipFree(a); hipFree(b); hipFree(w); hipFree(y); hipFree(g); hipFree(dw); hipFree(dab); hipFree(ws);
+  }
+}
+
 int main(int argc, char** argv) {
   Shape shapes[] = {
     {"decoder 3x3 304->256 @128x256", 2, 128, 256, 304, 256, 3, 1},
@@ -32,6 +62,7 @@ int main(int argc, char** argv) {
   int reps = argc > 1 ? atoi(argv[1]) : 20;
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  if (only && strstr(only, "dw")) { dw_bench(st, e0, e1, reps); return 0; }
   for (const Shape& s : shapes) {
     if (only && !strstr(s.name, only)) continue;
     long P = (long)s.N * s.H * s.W;

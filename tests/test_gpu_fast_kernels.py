@@ -14,7 +14,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-5
-FAST_ALL = 7
+FAST_ALL = 15
 
 SHAPES = [
     # name,            N,  H,   W, source channels, Cout, dil, k
@@ -148,3 +148,72 @@ def test_halo_patch_kernels_match_fp64_reference_and_generic(lib, shape):
         bad += ['%s/%s %.2e' % (tag, k, v) for k, v in errs.items() if not v <= TOL]
     assert not bad, 'beyond %.0e of the fp64 reference: %s' % (TOL, ', '.join(bad))
     assert _rel(fast['y'], slow['y']) <= 1e-5 and _rel(fast['dw'], slow['dw']) <= 1e-5
+
+
+DW_SHAPES = [
+    # name,          N,  H,   W,   C, k, stride, dil
+    ('sep5_l2',      2, 63, 127,  80, 5, 1, 1),
+    ('sep3_l1',      1, 125, 253, 40, 3, 1, 1),
+    ('sep5_stride2', 2, 64, 128,  80, 5, 2, 1),
+    ('sep3_dil2',    1, 70,  90,  24, 3, 1, 2),
+    ('sep5_l3',      2, 32,  64, 160, 5, 1, 1),
+    ('sep3_odd_c',   1, 50,  70,  36, 3, 2, 1),
+]
+
+
+def _dw_run(L, fast, shape, data, grads=False):
+    lib = L.load()
+    lib.addk_set_fast_paths(fast)
+    name, N, H, W, Cc, k, s, d = shape
+    pad = d * (k // 2)
+    OH, OW = (H + 2 * pad - d * (k - 1) - 1) // s + 1, (W + 2 * pad - d * (k - 1) - 1) // s + 1
+    dev = data['x'].device
+    st = torch.cuda.current_stream().cuda_stream
+    ar = L.DwArgs()
+    ar.src.x, ar.src.a, ar.src.b = data['x'].data_ptr(), data['a'].data_ptr(), data['b'].data_ptr()
+    ar.src.ld, ar.src.C, ar.src.relu = Cc, Cc, 1
+    ar.N, ar.H, ar.W, ar.OH, ar.OW, ar.KH, ar.KW, ar.stride, ar.pad, ar.dil = N, H, W, OH, OW, k, k, s, pad, d
+    y = torch.empty(N * OH * OW, Cc, device=dev)
+    ar.w, ar.y, ar.ldy = data['w'].data_ptr(), y.data_ptr(), Cc
+    L.check(lib.addk_dw_fwd(C.byref(ar), st), 'dw_fwd')
+    out = {'y': y}
+    if grads:
+        ba = L.DwBwdArgs()
+        ba.dy, ba.lddy = data['dy'].data_ptr(), Cc
+        ba.N, ba.H, ba.W, ba.OH, ba.OW, ba.KH, ba.KW, ba.stride, ba.pad, ba.dil = N, H, W, OH, OW, k, k, s, pad, d
+        ba.src = ar.src
+        ba.w = data['w'].data_ptr()
+        rows = lib.addk_dw_rows(N * H * W, Cc)
+        g = torch.empty(N * H * W, Cc, device=dev)
+        dab = torch.zeros(rows, Cc, 2, device=dev, dtype=torch.float64)
+        dw = torch.zeros(Cc, k * k, device=dev)
+        ws = torch.empty(rows * Cc * k * k, device=dev)
+        ba.g, ba.ldg, ba.accumulate, ba.dab, ba.dw, ba.dw_accumulate, ba.ws = g.data_ptr(), Cc, 0, dab.data_ptr(), dw.data_ptr(), 0, ws.data_ptr()
+        L.check(lib.addk_dw_bwd(C.byref(ba), st), 'dw_bwd')
+        out.update(g=g, dab=dab.sum(0), dw=dw)
+    torch.cuda.synchronize()
+    return out, (OH, OW)
+
+
+@pytest.mark.parametrize('shape', DW_SHAPES, ids=[s[0] for s in DW_SHAPES])
+def test_depthwise_tiled_kernels_match_fp64_reference_and_generic(lib, shape):
+    name, N, H, W, Cc, k, s, d = shape
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
+    rnd = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
+    pad = d * (k // 2)
+    OH, OW = (H + 2 * pad - d * (k - 1) - 1) // s + 1, (W + 2 * pad - d * (k - 1) - 1) // s + 1
+    data = {'x': rnd(N * H * W, Cc), 'a': rnd(Cc), 'b': 0.3 * rnd(Cc), 'w': 0.3 * rnd(Cc, k * k), 'dy': rnd(N * OH * OW, Cc)}
+    x = data['x'].double().view(N, H, W, Cc).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    a, b = data['a'].double().requires_grad_(True), data['b'].double().requires_grad_(True)
+    w = data['w'].double().view(Cc, 1, k, k).clone().requires_grad_(True)
+    yr = F.conv2d(F.relu(a.view(1, -1, 1, 1) * x + b.view(1, -1, 1, 1)), w, stride=s, padding=pad, dilation=d, groups=Cc)
+    yr.backward(data['dy'].double().view(N, OH, OW, Cc).permute(0, 3, 1, 2))
+    ref = {'y': yr.detach().permute(0, 2, 3, 1).reshape(-1, Cc), 'g': x.grad.permute(0, 2, 3, 1).reshape(-1, Cc),
+           'dab': torch.stack([a.grad, b.grad], 1), 'dw': w.grad.view(Cc, k * k)}
+    fast, _ = _dw_run(lib, 15, shape, data, grads=True)
+    slow, _ = _dw_run(lib, 0, shape, data, grads=True)
+    bad = []
+    for tag, got in (('fast', fast), ('generic', slow)):
+        bad += ['%s/%s %.2e' % (tag, kk, _rel(got[kk], ref[kk])) for kk in ('y', 'g', 'dab', 'dw') if not _rel(got[kk], ref[kk]) <= TOL]
+    assert not bad, 'beyond %.0e of the fp64 reference: %s' % (TOL, ', '.join(bad))
