@@ -99,6 +99,66 @@ __global__ void __launch_bounds__(256) resize_fwd_nchw_kernel(const RsK p) {
 }
 
 
+// Backward of the final logits up-sampling (NCHW gradient in, NHWC gradient out; decoder.py:28), LDS-tiled: a block owns
+// an 8x8 tile of low-resolution pixels and four channel planes, stages the block of the high-resolution gradient those
+// pixels can receive from (<= RB_PM x RB_PM per plane, contiguous row segments, independent loads) and gathers from LDS.
+// The thread-per-pixel kernel above walks its ~64 taps x 19 channels as dependent global loads (1.16 ms per exit at
+// 1024x2048; this one is bandwidth-bound).  Same taps, same weights, same summation order per pixel.
+constexpr int RB_T = 8, RB_PM = 48, RB_MAXT = 14;
+
+__global__ void __launch_bounds__(256) resize_bwd_nchw_tile_kernel(const RsK p, int tiles_x, int tiles_y) {
+  __shared__ float patch[4][RB_PM][RB_PM + 1];
+  const int C = p.src.C;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; const int n = b / tiles_y;
+  const int c0 = blockIdx.y * 4;
+  const int ih0 = ty * RB_T, iw0 = tx * RB_T;
+  const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
+  int rlo, rhi, clo, chi, tmp;
+  out_range(ih0, sh, p.OH, rlo, tmp);
+  out_range(min(ih0 + RB_T - 1, p.H - 1), sh, p.OH, tmp, rhi);
+  out_range(iw0, sw, p.OW, clo, tmp);
+  out_range(min(iw0 + RB_T - 1, p.W - 1), sw, p.OW, tmp, chi);
+  const int PH = rhi - rlo + 1, PW = chi - clo + 1;          // host guarantees <= RB_PM
+  const long ohw = (long)p.OH * p.OW;
+  const int per = PH * PW;
+#pragma unroll 5
+  for (int i = threadIdx.x; i < 4 * per; i += 256) {
+    const int ch = i / per, rem = i - ch * per;
+    const int r = rem / PW, cc = rem - r * PW;
+    const bool ok = c0 + ch < C;
+    const float v = p.dy[ok ? ((long)n * C + c0 + ch) * ohw + (long)(rlo + r) * p.OW + clo + cc : 0];
+    patch[ch][r][cc] = ok ? v : 0.f;
+  }
+  __syncthreads();
+  const int ch = threadIdx.x & 3, pix = threadIdx.x >> 2;
+  const int ih = ih0 + (pix >> 3), iw = iw0 + (pix & 7);
+  const int c = c0 + ch;
+  if (ih >= p.H || iw >= p.W || c >= C) return;
+  int hlo, hhi, wlo, whi;
+  out_range(ih, sh, p.OH, hlo, hhi);
+  out_range(iw, sw, p.OW, wlo, whi);
+  float ww[RB_MAXT];
+#pragma unroll
+  for (int k = 0; k < RB_MAXT; ++k) ww[k] = (wlo + k <= whi) ? tap_weight(wlo + k, iw, sw, p.W) : 0.f;
+  float sacc = 0.f;
+  for (int oh = hlo; oh <= hhi; ++oh) {
+    const float wh = tap_weight(oh, ih, sh, p.H);
+    const float* row = &patch[ch][oh - rlo][wlo - clo];
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < RB_MAXT; ++k) if (wlo + k <= whi) r = fmaf(ww[k], row[k], r);
+    sacc = fmaf(wh, r, sacc);
+  }
+  const float gs = p.dy_scale ? *p.dy_scale : 1.f;
+  const float a = p.src.a ? p.src.a[c] : 1.f;
+  const long pp = (long)(n * p.H + ih) * p.W + iw;
+  float* gp = p.g + pp * p.ldg + c;
+  const float gv = sacc * gs * a;
+  *gp = p.accumulate ? *gp + gv : gv;
+}
+
 template <bool NCHW>
 __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
   extern __shared__ double redt[];       // [C4][2]
@@ -279,6 +339,16 @@ extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
   if (a->nchw_in) {
     ADDK_REQUIRE(!a->src.relu && !a->dab, "resize_bwd: NCHW gradient input has no prologue support");
     k.nq = 1; k.npl = 256;
+    // receptive block of an 8x8 tile: (8 + 2) / scale + 4 output rows / columns (out_range's margins), at most RB_PM
+    const float invh = (float)a->OH / (float)a->H, invw = (float)a->OW / (float)a->W;
+    const bool fits = (RB_T + 2) * invh + 5.f <= (float)RB_PM && (RB_T + 2) * invw + 5.f <= (float)RB_PM &&
+                      2.f * invh + 5.f <= (float)RB_MAXT && 2.f * invw + 5.f <= (float)RB_MAXT;
+    if (fits && (addk_get_fast_paths() & ADDK_FAST_DWTILE)) {
+      const int txs = cdiv(a->W, RB_T), tys = cdiv(a->H, RB_T);
+      dim3 grid((unsigned)(a->N * tys * txs), (unsigned)cdiv(a->src.C, 4));
+      hipLaunchKernelGGL(resize_bwd_nchw_tile_kernel, grid, dim3(256), 0, st, k, txs, tys);
+      return addk_check_launch("resize_bwd_nchw_tile");
+    }
     long b = cdiv(k.P, 256); if (b > 8192) b = 8192;
     hipLaunchKernelGGL(resize_bwd_kernel<true>, dim3((unsigned)b), dim3(256), 0, st, k);
   } else {

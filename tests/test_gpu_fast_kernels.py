@@ -217,3 +217,35 @@ def test_depthwise_tiled_kernels_match_fp64_reference_and_generic(lib, shape):
     for tag, got in (('fast', fast), ('generic', slow)):
         bad += ['%s/%s %.2e' % (tag, kk, _rel(got[kk], ref[kk])) for kk in ('y', 'g', 'dab', 'dw') if not _rel(got[kk], ref[kk]) <= TOL]
     assert not bad, 'beyond %.0e of the fp64 reference: %s' % (TOL, ', '.join(bad))
+
+
+@pytest.mark.parametrize('N,H,W,OH,OW,Cc', [(2, 64, 128, 256, 512, 19), (1, 33, 65, 129, 257, 19), (1, 40, 50, 80, 100, 6)])
+def test_logits_upsample_backward_tiled_matches_autograd(lib, N, H, W, OH, OW, Cc):
+    """NCHW gradient of the up-sampled logits -> NHWC gradient of the low-resolution logits (decoder.py:28)."""
+    L = lib
+    l = L.load()
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(N * 1000 + H)
+    dy = torch.randn(N, Cc, OH, OW, generator=gen).to(dev)
+    a = torch.randn(Cc, generator=gen).to(dev)
+    x = torch.zeros(N, Cc, H, W, device=dev, dtype=torch.float64, requires_grad=True)
+    y = F.interpolate(x * a.double().view(1, -1, 1, 1), size=(OH, OW), mode='bilinear', align_corners=False)
+    y.backward(dy.double() * 0.5)
+    ref = x.grad.permute(0, 2, 3, 1).reshape(-1, Cc)
+    scale = torch.full((1,), 0.5, device=dev)
+    bz = torch.zeros(Cc, device=dev)
+    outs = []
+    for fast in (15, 0):
+        l.addk_set_fast_paths(fast)
+        ld = (Cc + 3) // 4 * 4
+        g = torch.zeros(N * H * W, ld, device=dev)
+        ar = L.ResizeBwdArgs()
+        ar.dy, ar.lddy, ar.nchw_in, ar.dy_scale = dy.data_ptr(), 0, 1, scale.data_ptr()
+        ar.src.x, ar.src.a, ar.src.b, ar.src.ld, ar.src.C, ar.src.relu = g.data_ptr(), a.data_ptr(), bz.data_ptr(), ld, Cc, 0
+        ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
+        ar.g, ar.ldg, ar.accumulate = g.data_ptr(), ld, 0
+        L.check(l.addk_resize_bwd(C.byref(ar), torch.cuda.current_stream().cuda_stream), 'resize_bwd')
+        torch.cuda.synchronize()
+        outs.append(g[:, :Cc].clone())
+        assert _rel(outs[-1], ref) <= TOL, 'mask %d: %.2e' % (fast, _rel(outs[-1], ref))
+    assert torch.equal(outs[0], outs[1]) or _rel(outs[0], outs[1]) <= 1e-6
