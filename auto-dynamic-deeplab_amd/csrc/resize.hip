@@ -99,20 +99,24 @@ __global__ void __launch_bounds__(256) resize_fwd_nchw_kernel(const RsK p) {
 }
 
 
-// Backward of the final logits up-sampling (NCHW gradient in, NHWC gradient out; decoder.py:28), LDS-tiled: a block owns
-// an 8x8 tile of low-resolution pixels and four channel planes, stages the block of the high-resolution gradient those
-// pixels can receive from (<= RB_PM x RB_PM per plane, contiguous row segments, independent loads) and gathers from LDS.
-// The thread-per-pixel kernel above walks its ~64 taps x 19 channels as dependent global loads (1.16 ms per exit at
-// 1024x2048; this one is bandwidth-bound).  Same taps, same weights, same summation order per pixel.
-constexpr int RB_T = 8, RB_PM = 48, RB_MAXT = 14;
+// Backward of the final logits up-sampling (NCHW gradient in, NHWC gradient out; decoder.py:28), LDS-tiled and SEPARABLE:
+// a block owns an 8x8 tile of low-resolution pixels of one channel plane, stages the block of the high-resolution
+// gradient those pixels receive from (<= RB_PM x RB_PM, contiguous row segments, independent loads), reduces it along W
+// with the column weights (t1[row][j]) and then along H with the row weights: 2*T taps per pixel instead of T*T
+// (T = 21 at the x8 up-sampling of config 2).  The thread-per-pixel kernel below walks its T*T x 19 taps as dependent
+// global loads (1.17 ms per exit at 1024x2048).
+constexpr int RB_T = 8, RB_PM = 88, RB_MAXT = 22;
 
 __global__ void __launch_bounds__(256) resize_bwd_nchw_tile_kernel(const RsK p, int tiles_x, int tiles_y) {
-  __shared__ float patch[4][RB_PM][RB_PM + 1];
+  __shared__ float patch[RB_PM][RB_PM + 1];
+  __shared__ float t1[RB_PM][RB_T];
+  __shared__ float wtw[RB_T][RB_MAXT], wth[RB_T][RB_MAXT];
+  __shared__ int lo_w[RB_T], lo_h[RB_T], n_w[RB_T], n_h[RB_T];
   const int C = p.src.C;
   int b = blockIdx.x;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y; const int n = b / tiles_y;
-  const int c0 = blockIdx.y * 4;
+  const int c = blockIdx.y;
   const int ih0 = ty * RB_T, iw0 = tx * RB_T;
   const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
   int rlo, rhi, clo, chi, tmp;
@@ -121,42 +125,59 @@ __global__ void __launch_bounds__(256) resize_bwd_nchw_tile_kernel(const RsK p, 
   out_range(iw0, sw, p.OW, clo, tmp);
   out_range(min(iw0 + RB_T - 1, p.W - 1), sw, p.OW, tmp, chi);
   const int PH = rhi - rlo + 1, PW = chi - clo + 1;          // host guarantees <= RB_PM
-  const long ohw = (long)p.OH * p.OW;
+  const float* plane = p.dy + ((long)n * C + c) * ((long)p.OH * p.OW) + (long)rlo * p.OW + clo;
   const int per = PH * PW;
-#pragma unroll 5
-  for (int i = threadIdx.x; i < 4 * per; i += 256) {
-    const int ch = i / per, rem = i - ch * per;
-    const int r = rem / PW, cc = rem - r * PW;
-    const bool ok = c0 + ch < C;
-    const float v = p.dy[ok ? ((long)n * C + c0 + ch) * ohw + (long)(rlo + r) * p.OW + clo + cc : 0];
-    patch[ch][r][cc] = ok ? v : 0.f;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < per; i += 256) {
+    const int r = i / PW, cc = i - r * PW;
+    patch[r][cc] = plane[(long)r * p.OW + cc];
+  }
+  // per-axis weight tables of the tile's 8 columns / 8 rows
+  if (threadIdx.x < 2 * RB_T) {
+    const bool isw = threadIdx.x < RB_T;
+    const int j = threadIdx.x & (RB_T - 1);
+    const int i = (isw ? iw0 : ih0) + j;
+    const int lim = isw ? p.W : p.H;
+    int lo = 0, hi = -1;
+    if (i < lim) out_range(i, isw ? sw : sh, isw ? p.OW : p.OH, lo, hi);
+    if (isw) { lo_w[j] = lo; n_w[j] = hi - lo + 1; } else { lo_h[j] = lo; n_h[j] = hi - lo + 1; }
   }
   __syncthreads();
-  const int ch = threadIdx.x & 3, pix = threadIdx.x >> 2;
-  const int ih = ih0 + (pix >> 3), iw = iw0 + (pix & 7);
-  const int c = c0 + ch;
-  if (ih >= p.H || iw >= p.W || c >= C) return;
-  int hlo, hhi, wlo, whi;
-  out_range(ih, sh, p.OH, hlo, hhi);
-  out_range(iw, sw, p.OW, wlo, whi);
-  float ww[RB_MAXT];
-#pragma unroll
-  for (int k = 0; k < RB_MAXT; ++k) ww[k] = (wlo + k <= whi) ? tap_weight(wlo + k, iw, sw, p.W) : 0.f;
-  float sacc = 0.f;
-  for (int oh = hlo; oh <= hhi; ++oh) {
-    const float wh = tap_weight(oh, ih, sh, p.H);
-    const float* row = &patch[ch][oh - rlo][wlo - clo];
-    float r = 0.f;
-#pragma unroll
-    for (int k = 0; k < RB_MAXT; ++k) if (wlo + k <= whi) r = fmaf(ww[k], row[k], r);
-    sacc = fmaf(wh, r, sacc);
+  for (int i = threadIdx.x; i < 2 * RB_T * RB_MAXT; i += 256) {
+    const bool isw = i < RB_T * RB_MAXT;
+    const int r = isw ? i : i - RB_T * RB_MAXT;
+    const int j = r / RB_MAXT, k = r - j * RB_MAXT;
+    if (isw) wtw[j][k] = k < n_w[j] ? tap_weight(lo_w[j] + k, iw0 + j, sw, p.W) : 0.f;
+    else     wth[j][k] = k < n_h[j] ? tap_weight(lo_h[j] + k, ih0 + j, sh, p.H) : 0.f;
   }
-  const float gs = p.dy_scale ? *p.dy_scale : 1.f;
-  const float a = p.src.a ? p.src.a[c] : 1.f;
-  const long pp = (long)(n * p.H + ih) * p.W + iw;
-  float* gp = p.g + pp * p.ldg + c;
-  const float gv = sacc * gs * a;
-  *gp = p.accumulate ? *gp + gv : gv;
+  __syncthreads();
+  // pass 1: along W
+  for (int i = threadIdx.x; i < PH * RB_T; i += 256) {
+    const int r = i / RB_T, j = i - r * RB_T;
+    const float* row = &patch[r][lo_w[j] - clo];
+    float acc = 0.f;
+    const int nw = n_w[j];
+#pragma unroll
+    for (int k = 0; k < RB_MAXT; ++k) if (k < nw) acc = fmaf(wtw[j][k], row[k], acc);
+    t1[r][j] = acc;
+  }
+  __syncthreads();
+  // pass 2: along H, one thread per pixel of the tile
+  if (threadIdx.x < RB_T * RB_T) {
+    const int i = threadIdx.x / RB_T, j = threadIdx.x - i * RB_T;
+    const int ih = ih0 + i, iw = iw0 + j;
+    if (ih < p.H && iw < p.W) {
+      const int nh = n_h[i], r0 = lo_h[i] - rlo;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < RB_MAXT; ++k) if (k < nh) acc = fmaf(wth[i][k], t1[r0 + k][j], acc);
+      const float gs = p.dy_scale ? *p.dy_scale : 1.f;
+      const float a = p.src.a ? p.src.a[c] : 1.f;
+      float* gp = p.g + ((long)(n * p.H + ih) * p.W + iw) * p.ldg + c;
+      const float gv = acc * gs * a;
+      *gp = p.accumulate ? *gp + gv : gv;
+    }
+  }
 }
 
 template <bool NCHW>
@@ -342,10 +363,10 @@ extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
     // receptive block of an 8x8 tile: (8 + 2) / scale + 4 output rows / columns (out_range's margins), at most RB_PM
     const float invh = (float)a->OH / (float)a->H, invw = (float)a->OW / (float)a->W;
     const bool fits = (RB_T + 2) * invh + 5.f <= (float)RB_PM && (RB_T + 2) * invw + 5.f <= (float)RB_PM &&
-                      2.f * invh + 5.f <= (float)RB_MAXT && 2.f * invw + 5.f <= (float)RB_MAXT;
+                      2.f * invh + 5.f <= (float)RB_MAXT && 2.f * invw + 5.f <= (float)RB_MAXT && invh >= 1.f && invw >= 1.f;
     if (fits && (addk_get_fast_paths() & ADDK_FAST_DWTILE)) {
       const int txs = cdiv(a->W, RB_T), tys = cdiv(a->H, RB_T);
-      dim3 grid((unsigned)(a->N * tys * txs), (unsigned)cdiv(a->src.C, 4));
+      dim3 grid((unsigned)(a->N * tys * txs), (unsigned)a->src.C);
       hipLaunchKernelGGL(resize_bwd_nchw_tile_kernel, grid, dim3(256), 0, st, k, txs, tys);
       return addk_check_launch("resize_bwd_nchw_tile");
     }
