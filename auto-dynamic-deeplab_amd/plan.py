@@ -141,7 +141,10 @@ def schedule(cmds, nstreams):
     recorded waits preserve every RAW/WAW/WAR relation of the sequential list."""
     writers, readers = {}, {}            # buffer id -> [(region, idx)]
     tail = [-1] * nstreams               # index of the last command on each stream
-    synced = [[-1] * nstreams for _ in range(nstreams)]   # synced[s][t]: latest index of stream t that s already waits for
+    # vector clocks: clock[i][t] = latest command of stream t known to have completed before command i starts.  A wait
+    # that a previous wait already implies TRANSITIVELY (A -> B -> C and A -> C) is dropped: besides being useless,
+    # such redundant edges crash hipStreamEndCapture on ROCm 7.2 once three or more streams are captured.
+    clock = []
     for i, c in enumerate(cmds):
         deps = set()
         for k in c.rd:
@@ -157,12 +160,23 @@ def schedule(cmds, nstreams):
             st = ls if tail[ls] == last else min(range(nstreams), key=lambda t: tail[t])
         else:
             st = min(range(nstreams), key=lambda t: tail[t])
+        # hipStreamEndCapture (ROCm 7.2) crashes when two SIDE streams wait on each other (measured with
+        # scripts/capture_probe.py: 'mutual12' dumps core, 'ordered' does not).  Side stream s therefore only ever waits
+        # on side streams t > s (and on the main stream 0, which may wait on anybody); a command that would need the
+        # other direction runs on the main stream instead.
+        if st != 0:
+            vc0 = clock[tail[st]] if tail[st] >= 0 else [-1] * nstreams
+            if any(0 < cmds[j].stream < st and vc0[cmds[j].stream] < j for j in deps):
+                st = 0
+        vc = list(clock[tail[st]]) if tail[st] >= 0 else [-1] * nstreams
         waits = []
         for j in sorted(deps, reverse=True):
             t = cmds[j].stream
-            if t != st and synced[st][t] < j:
+            if t != st and vc[t] < j:
                 waits.append(j)
-                synced[st][t] = j
+                vc = [max(a, b) for a, b in zip(vc, clock[j])]
+        vc[st] = i
+        clock.append(vc)
         c.stream, c.waits = st, tuple(waits)
         tail[st] = i
         for k in c.wr:

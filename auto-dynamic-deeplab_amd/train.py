@@ -80,9 +80,9 @@ class TrainStep:
             o.dy_ptr, o.dynamic = d.data_ptr(), False
         has_coll = sync_comm is not None and (self.world > 1 or sync_comm.force)
         if nstreams is None:
-            # two HIP streams: independent branches of the cell DAG overlap (-4 ms of 82 at config 2, eager or captured).
-            # Three or more crash hipStreamEndCapture on ROCm 7.2 (eager they gain nothing further), and the SyncBN
-            # path keeps its collectives on one stream.
+            # two HIP streams: independent branches of the cell DAG overlap (-4 ms of 82 at config 2, eager or captured);
+            # 3, 4 and 6 streams measure the same or slightly worse (68.5 / 68.7 / 69.8 / 69.7 ms).  The SyncBN path
+            # keeps its collectives on one stream.
             nstreams = int(os.environ.get('ADDK_STREAMS', '1' if has_coll else '2'))
         g.finalize(nstreams)
         self.nbt = NbtCounter(g.nbt)
