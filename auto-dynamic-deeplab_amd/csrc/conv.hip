@@ -454,12 +454,13 @@ int conv_precision() {
 int g_fast = -1;
 int fast_paths() {
   if (g_fast < 0) {
-    int m = ADDK_FAST_PW | ADDK_FAST_CONV3 | ADDK_FAST_WGRAD3 | ADDK_FAST_DWTILE;
+    int m = ADDK_FAST_PW | ADDK_FAST_CONV3 | ADDK_FAST_WGRAD3 | ADDK_FAST_DWTILE | ADDK_FAST_WGRAD_RS;
     const char* e;
     if ((e = getenv("ADDK_PW")) && e[0] == '0') m &= ~ADDK_FAST_PW;
     if ((e = getenv("ADDK_C3")) && e[0] == '0') m &= ~ADDK_FAST_CONV3;
     if ((e = getenv("ADDK_WGRAD_H3")) && e[0] == '0') m &= ~ADDK_FAST_WGRAD3;
     if ((e = getenv("ADDK_DWTILE")) && e[0] == '0') m &= ~ADDK_FAST_DWTILE;
+    if ((e = getenv("ADDK_WGRAD_RS")) && e[0] == '0') m &= ~ADDK_FAST_WGRAD_RS;
     g_fast = m;
   }
   return g_fast;
@@ -504,7 +505,7 @@ extern "C" int addk_set_conv_precision(int mode) {
   return ADDK_OK;
 }
 extern "C" int addk_get_conv_precision(void) { return conv_precision(); }
-extern "C" int addk_set_fast_paths(int mask) { g_fast = mask & (ADDK_FAST_PW | ADDK_FAST_CONV3 | ADDK_FAST_WGRAD3 | ADDK_FAST_DWTILE); return ADDK_OK; }
+extern "C" int addk_set_fast_paths(int mask) { g_fast = mask & (ADDK_FAST_PW | ADDK_FAST_CONV3 | ADDK_FAST_WGRAD3 | ADDK_FAST_DWTILE | ADDK_FAST_WGRAD_RS); return ADDK_OK; }
 extern "C" int addk_get_fast_paths(void) { return fast_paths(); }
 
 extern "C" int addk_selftest_mfma(float* out256, void* stream) {

@@ -97,12 +97,13 @@ int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a);
  * fp32 accumulation (~1.5e-5 relative per product).  Process-wide; also ADDK_MATH=bf16x3 in the environment. */
 int addk_set_conv_precision(int mode);
 /* Specialised kernels that may replace the generic ones (all on by default; results agree to fp32 rounding).  The mask is
- * process-wide and is meant for tests and A/B timing; the environment (ADDK_PW=0, ADDK_C3=0, ADDK_WGRAD_H3=0, ADDK_DWTILE=0) sets the
+ * process-wide and is meant for tests and A/B timing; the environment (ADDK_PW=0, ADDK_C3=0, ADDK_WGRAD_H3=0, ADDK_DWTILE=0, ADDK_WGRAD_RS=0) sets the
  * initial value. */
 #define ADDK_FAST_PW      1   /* register-stationary 1x1 convolution (pw.hip) */
 #define ADDK_FAST_CONV3   2   /* halo-patch 3x3 stride-1 forward / data gradient (conv3.hip; needs wpack) */
 #define ADDK_FAST_WGRAD3  4   /* halo-patch 3x3 stride-1 weight gradient (wgrad.hip) */
-#define ADDK_FAST_DWTILE  8   /* LDS-tiled depthwise forward / backward (dw.hip) */
+#define ADDK_FAST_DWTILE  8   /* LDS-tiled depthwise forward / backward, tiled logits-upsample backward */
+#define ADDK_FAST_WGRAD_RS 16  /* register-streaming weight gradient of the narrow cell convs (wgrad.hip) */
 int addk_set_fast_paths(int mask);
 int addk_get_fast_paths(void);
 int addk_get_conv_precision(void);

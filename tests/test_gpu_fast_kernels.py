@@ -14,7 +14,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-5
-FAST_ALL = 15
+FAST_ALL = 31
 
 SHAPES = [
     # name,            N,  H,   W, source channels, Cout, dil, k
@@ -211,7 +211,7 @@ def test_depthwise_tiled_kernels_match_fp64_reference_and_generic(lib, shape):
     yr.backward(data['dy'].double().view(N, OH, OW, Cc).permute(0, 3, 1, 2))
     ref = {'y': yr.detach().permute(0, 2, 3, 1).reshape(-1, Cc), 'g': x.grad.permute(0, 2, 3, 1).reshape(-1, Cc),
            'dab': torch.stack([a.grad, b.grad], 1), 'dw': w.grad.view(Cc, k * k)}
-    fast, _ = _dw_run(lib, 15, shape, data, grads=True)
+    fast, _ = _dw_run(lib, FAST_ALL, shape, data, grads=True)
     slow, _ = _dw_run(lib, 0, shape, data, grads=True)
     bad = []
     for tag, got in (('fast', fast), ('generic', slow)):
@@ -235,7 +235,7 @@ def test_logits_upsample_backward_tiled_matches_autograd(lib, N, H, W, OH, OW, C
     scale = torch.full((1,), 0.5, device=dev)
     bz = torch.zeros(Cc, device=dev)
     outs = []
-    for fast in (15, 0):
+    for fast in (FAST_ALL, 0):
         l.addk_set_fast_paths(fast)
         ld = (Cc + 3) // 4 * 4
         g = torch.zeros(N * H * W, ld, device=dev)
@@ -249,3 +249,42 @@ def test_logits_upsample_backward_tiled_matches_autograd(lib, N, H, W, OH, OW, C
         outs.append(g[:, :Cc].clone())
         assert _rel(outs[-1], ref) <= TOL, 'mask %d: %.2e' % (fast, _rel(outs[-1], ref))
     assert torch.equal(outs[0], outs[1]) or _rel(outs[0], outs[1]) <= 1e-6
+
+
+@pytest.mark.parametrize('name,N,H,W,Ci,Cout,k,s,d', [
+    ('pw40', 2, 63, 127, 40, 40, 1, 1, 1), ('pw80', 1, 64, 128, 80, 80, 1, 1, 1), ('glue200', 1, 50, 90, 200, 40, 1, 1, 1),
+    ('reduce_s2', 2, 128, 96, 80, 40, 1, 2, 1), ('dense3_s2', 2, 97, 129, 48, 96, 3, 2, 1), ('pw160', 2, 32, 64, 160, 160, 1, 1, 1)])
+def test_register_streaming_wgrad_matches_fp64_reference(lib, name, N, H, W, Ci, Cout, k, s, d):
+    """Weight gradients of the narrow cell convolutions (1x1, strided, multi-tile) on wgrad_rs_kernel vs autograd in fp64."""
+    L = lib
+    l = L.load()
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
+    rnd = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
+    pad = d * (k // 2)
+    OH, OW = (H + 2 * pad - d * (k - 1) - 1) // s + 1, (W + 2 * pad - d * (k - 1) - 1) // s + 1
+    x, a, b, dy = rnd(N * H * W, Ci), rnd(Ci), 0.3 * rnd(Ci), rnd(N * OH * OW, Cout)
+    xr = x.double().view(N, H, W, Ci).permute(0, 3, 1, 2)
+    z = F.relu(a.double().view(1, -1, 1, 1) * xr + b.double().view(1, -1, 1, 1))
+    w = torch.zeros(Cout, Ci, k, k, device=dev, dtype=torch.float64, requires_grad=True)
+    F.conv2d(z, w, stride=s, padding=pad, dilation=d).backward(dy.double().view(N, OH, OW, Cout).permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
+    outs = {}
+    for fast in (31, 0):
+        l.addk_set_fast_paths(fast)
+        wa = L.ConvWgradArgs()
+        wa.dy, wa.lddy, wa.Cout = dy.data_ptr(), Cout, Cout
+        wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, OH, OW, k, k, s, pad, d
+        wa.src.x, wa.src.a, wa.src.b, wa.src.ld, wa.src.C, wa.src.relu = x.data_ptr(), a.data_ptr(), b.data_ptr(), Ci, Ci, 1
+        dw = torch.zeros(Cout, k * k * Ci, device=dev)
+        wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = dw.data_ptr(), k * k * Ci, Ci, 0, 0
+        wa.ws_floats = l.addk_conv_wgrad_ws(N * OH * OW, Cout, Ci, k * k)
+        ws = torch.empty(int(wa.ws_floats), device=dev)
+        wa.ws = ws.data_ptr()
+        cfg = (C.c_int32 * 4)()
+        L.check(l.addk_conv_wgrad_config(C.byref(wa), cfg), 'wgrad_config')
+        assert (cfg[0] == 6) == (fast == 31), 'kernel kind %d with mask %d' % (cfg[0], fast)
+        L.check(l.addk_conv_wgrad(C.byref(wa), torch.cuda.current_stream().cuda_stream), 'conv_wgrad')
+        torch.cuda.synchronize()
+        outs[fast] = dw
+        assert _rel(dw, ref) <= TOL, 'mask %d: %.2e' % (fast, _rel(dw, ref))
