@@ -469,17 +469,35 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
 
 // Register-streaming weight gradient for the narrow cell convolutions (Cout, C <= 160; 1x1, dilated k x k, strided):
 // no LDS staging and no barrier in the main loop.  A wave walks its own pixel range four pixels per MFMA k-step; lane
-// (li, kq) loads ONE float4 of dy (channels co0+4li..+3 of pixel kq) and ONE float4 of the activation (channels c0+4li..+3
-// of the tap-shifted pixel) straight from global memory and uses the four components as the operands of 4x4 MFMAs:
-// component e of dy is the A fragment of the tile holding output channels {co0+4r+e}, component f of z the B fragment of
-// the tile holding input channels {c0+4l+f}.  One 16-byte load feeds 16 MFMAs, every load is unconditional (masked
-// lanes read a safe address and are zeroed), and eight k-steps are in flight per wave.  A 64x64 tile is at most 62 %
-// occupied by a 40-channel conv, but these launches were bound by their barrier/latency chains, not by MFMA issue
-// (23 TF/s on the LDS-staged kernels).
-constexpr int RS_T = 64;             // output tile edge (channels); a tile holds <= 64 co x <= 64 c of one tap
+// (li, kq) loads its slice of dy (pixel kq) and of the activation (tap-shifted pixel kq) straight from global memory and
+// uses the COMPONENTS of those vector loads as MFMA operands.  Two lane layouts per operand:
+//   LAY 4: one float4 at channel 4*li        -> 4 operand tiles, tile e holds channels {4r+e}           (<= 64 channels)
+//   LAY 3: one float2 at channel 2*li + one float at channel 32+li -> 3 tiles {2r}, {2r+1}, {32+r}      (<= 48 channels)
+// so a 40-channel conv issues 3x3 MFMAs per k-step (83 % useful rows) instead of 4x4 (62 %).  Every load is unconditional
+// (masked lanes read a safe address and are zeroed) and RS_U k-steps are in flight per wave.  The LDS-staged kernels
+// above ran these launches at 23 TF/s, bound by their barrier/latency chains.
+constexpr int RS_T = 64;             // LDS tile edge for the cross-wave combine (channels)
 constexpr int RS_U = 4;              // k-steps per unrolled batch
 
-template <bool BATCH>
+template <int LAY> struct RsFrag { float v[LAY]; };
+
+template <int LAY>
+__device__ __forceinline__ RsFrag<LAY> rs_load(const float* base, int li, bool ok4, bool ok2, bool ok1) {
+  RsFrag<LAY> f;
+  if (LAY == 4) {
+    const float4 x = ld4(base + (ok4 ? 4 * li : 0));
+    f.v[0] = ok4 ? x.x : 0.f; f.v[1] = ok4 ? x.y : 0.f; f.v[2] = ok4 ? x.z : 0.f; f.v[3 % LAY] = ok4 ? x.w : 0.f;
+  } else {
+    const float2 x = *reinterpret_cast<const float2*>(base + (ok2 ? 2 * li : 0));
+    const float y = base[ok1 ? 32 + li : 0];
+    f.v[0] = ok2 ? x.x : 0.f; f.v[1] = ok2 ? x.y : 0.f; f.v[2] = ok1 ? y : 0.f;
+  }
+  return f;
+}
+// channel (relative to the tile origin) held by component e, row/column index R of the MFMA tile
+template <int LAY> __device__ __forceinline__ int rs_chan(int e, int R) { return LAY == 4 ? 4 * R + e : (e < 2 ? 2 * R + e : 32 + R); }
+
+template <int LA, int LB, bool BATCH>
 __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
   int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
   if (BATCH) {
@@ -493,42 +511,42 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
   const int zt = bx % p.nzt; bx /= p.nzt;
   const int tap = bx % p.taps; const int yt = bx / p.taps;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int tsy = p.vecY, tsz = p.vecZ;        // tile strides in channels (multiples of 4, <= 64), set by the host for this kind
+  const int tsy = p.vecY, tsz = p.vecZ;        // tile strides in channels (multiples of 4), set by the host for this kind
   const int co0 = yt * tsy, c0 = zt * tsz;
   const int ncy = min(tsy, p.Cout - co0), ncz = min(tsz, p.src.C - c0);
-  const bool yok = 4 * li < ncy, zok = 4 * li < ncz;
+  const bool y4 = 4 * li < ncy, y2 = 2 * li < min(ncy, 32), y1 = 32 + li < ncy;
+  const bool z4 = 4 * li < ncz, z2 = 2 * li < min(ncz, 32), z1 = 32 + li < ncz;
   const int C = p.src.C;
-  // pixel range of this wave
   const int pbeg = blk_y * p.chunkP;
   int pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
   const int span = (pend - pbeg + 3) / 4;                  // k-steps of the block
   const int per_wave = (span + 3) / 4;
   const int s_beg = wave * per_wave, s_end = min(span, s_beg + per_wave);
-  float4 za = make_float4(1.f, 1.f, 1.f, 1.f), zb = zero4();
-  if (p.src.a && zok) { za = ld4(p.src.a + c0 + 4 * li); zb = ld4(p.src.b + c0 + 4 * li); }
+  RsFrag<LB> za, zb;
+#pragma unroll
+  for (int f = 0; f < LB; ++f) { za.v[f] = 1.f; zb.v[f] = 0.f; }
+  if (p.src.a) { za = rs_load<LB>(p.src.a + c0, li, z4, z2, z1); zb = rs_load<LB>(p.src.b + c0, li, z4, z2, z1); }
   const bool zrelu = p.src.relu != 0;
   const int ohw = p.OH * p.OW;
-  const float* ybase = p.dy + (yok ? co0 + 4 * li : 0);
-  const float* zbase = p.src.x + (zok ? c0 + 4 * li : 0);
+  const float* ybase = p.dy + co0;
+  const float* zbase = p.src.x + c0;
   const bool same = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;      // 1x1: the activation pixel is the dy pixel
 
-  f32x4 acc[4][4];
+  f32x4 acc[LA][LB];
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < LA; ++e)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < LB; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int s0 = s_beg; s0 < s_end; s0 += RS_U) {
-    float4 dy4[RS_U], z4[RS_U];
+    RsFrag<LA> dy4[RS_U]; RsFrag<LB> z4v[RS_U];
     bool zv[RS_U];
 #pragma unroll
     for (int u = 0; u < RS_U; ++u) {
       const int pp = pbeg + 4 * (s0 + u) + kq;
       const bool pv_ = (s0 + u) < s_end && pp < pend;
-      const bool oky = pv_ && yok;
-      dy4[u] = ld4(ybase + (oky ? (long)pp * p.lddy : 0));
-      if (!oky) dy4[u] = zero4();
-      long zoff = 0; bool okz = pv_ && zok;
+      dy4[u] = rs_load<LA>(ybase + (pv_ ? (long)pp * p.lddy : 0), li, pv_ && y4, pv_ && y2, pv_ && y1);
+      long zoff = 0; bool okz = pv_;
       if (same) zoff = (long)pp * p.src.ld;
       else if (okz) {
         const int n = pp / ohw, rem = pp - n * ohw, oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -536,34 +554,37 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
         okz = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         zoff = ((long)(n * p.H + ih) * p.W + iw) * p.src.ld;
       }
-      z4[u] = ld4(zbase + (okz ? zoff : 0));
+      z4v[u] = rs_load<LB>(zbase + (okz ? zoff : 0), li, okz && z4, okz && z2, okz && z1);
       zv[u] = okz;
     }
 #pragma unroll
     for (int u = 0; u < RS_U; ++u) {
-      float4 v = z4[u];
-      v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
-      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      RsFrag<LB> v = z4v[u];
       const bool ok = zv[u];
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      const float4 d = dy4[u];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int f = 0; f < LB; ++f) {
+        float x = fmaf(za.v[f], v.v[f], zb.v[f]);
+        if (zrelu) x = fmaxf(x, 0.f);
+        const bool okf = ok && (LB == 4 ? z4 : (f < 2 ? z2 : z1));
+        v.v[f] = okf ? x : 0.f;
+      }
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-          acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(d, e), get4(v, f), acc[e][f], 0, 0, 0);
+      for (int e = 0; e < LA; ++e)
+#pragma unroll
+        for (int f = 0; f < LB; ++f)
+          acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy4[u].v[e], v.v[f], acc[e][f], 0, 0, 0);
     }
   }
-  // combine the four waves in a fixed order; acc[e][f][r] = dW[co0 + 4*(4*kq + r) + e][c0 + 4*li + f]
+  // combine the four waves in a fixed order; acc[e][f][r] = dW[co0 + chanA(e, 4*kq + r)][c0 + chanB(f, li)]
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < LA; ++e)
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < LB; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float* d = &tile[4 * (4 * kq + r) + e][4 * li + f];
+            float* d = &tile[rs_chan<LA>(e, 4 * kq + r)][rs_chan<LB>(f, li)];
             *d = (w == 0) ? acc[e][f][r] : *d + acc[e][f][r];
           }
     }
@@ -688,7 +709,15 @@ bool rs_ok(const addk_conv_wgrad_args* a) {
   return (addk_get_fast_paths() & ADDK_FAST_WGRAD_RS) && a->Cout <= 160 && a->Cout >= 16 && a->src.C >= 16 && a->KH * a->KW <= 25 &&
          aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0 && src_vec_ok(a->src) && (long)a->N * a->OH * a->OW >= 4096;
 }
-inline int rs_tile(int Cn) { const int nt = cdiv(Cn, RS_T); return cdiv(cdiv(Cn, nt), 4) * 4; }
+// tile stride of an operand: 40-channel tiles (3-component layout) when the channel count is a multiple of 40 or fits 48,
+// else up to 64 channels (4-component layout)
+inline int rs_tile(int Cn) {
+  if (Cn <= 48) return Cn;
+  if (Cn % 40 == 0) return 40;
+  if (Cn % 48 == 0) return 48;
+  const int nt = cdiv(Cn, RS_T); return cdiv(cdiv(Cn, nt), 4) * 4;
+}
+inline int rs_lay(int tile) { return tile <= 48 ? 3 : 4; }
 int kind_of(const addk_conv_wgrad_args* a) { return h3_ok(a) ? 5 : rs_ok(a) ? 6 : os_kind(a->Cout, a->src.C); }
 // Halo-patch scheduling.  A block runs `steps` row segments; blocks are dispatched in grid order as CU slots free up
 // (2 resident blocks per CU at NT=2, 3 at NT=1), so what matters is that the LAST round of blocks is nearly full:
@@ -777,8 +806,8 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   k.vecZ = src_vec_ok(a->src);
   if (!h3_ok(a) && rs_ok(a)) {      // register-streaming kernel: <= 64-channel tiles, 2048-pixel chunks (128 k-steps per wave), vecY/vecZ carry the tile strides
     const int cap = pick_splits(k.P, tiles);
-    cty = 0; ctz = 0;
     k.vecY = rs_tile(a->Cout); k.vecZ = rs_tile(a->src.C);
+    cty = rs_lay(k.vecY); ctz = rs_lay(k.vecZ);
     k.nyt = cdiv(a->Cout, k.vecY); k.nzt = cdiv(a->src.C, k.vecZ);
     tiles = k.nyt * k.taps * k.nzt;
     int sp = cdiv(k.P, 2048);
@@ -800,11 +829,13 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_OS(1, 4, 2) ADDK_OS(2, 3, 3) ADDK_OS(3, 2, 2) ADDK_OS(4, 4, 4)
 #undef ADDK_OS
-  if (kind == 6) {
-    if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<true>), grid, dim3(256), 0, st, k, ops, work);
-    else hipLaunchKernelGGL((wgrad_rs_kernel<false>), grid, dim3(256), 0, st, k, ops, work);
-    done = true;
-  }
+#define ADDK_RS(A_, B_) \
+  if (kind == 6 && cty == A_ && ctz == B_) { \
+    if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true>), grid, dim3(256), 0, st, k, ops, work); \
+    else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false>), grid, dim3(256), 0, st, k, ops, work); \
+    done = true; }
+  ADDK_RS(3, 3) ADDK_RS(3, 4) ADDK_RS(4, 3) ADDK_RS(4, 4)
+#undef ADDK_RS
 #define ADDK_H3(NT_) \
   if (kind == 5 && cty == 4 * NT_) { \
     if (ops) hipLaunchKernelGGL((wgrad_h3_kernel<NT_, true>), grid, dim3(256), 0, st, k, ops, work); \
