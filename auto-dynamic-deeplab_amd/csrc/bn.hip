@@ -7,29 +7,37 @@
 
 namespace {
 
-// block = 32 channels x 32 row groups; result (sum0, sum1) per channel for threads with rg == 0
+// block = BN_CH channels x BN_RG row groups (1024 threads); result (sum0, sum1) per channel for threads with rg == 0.
+// 16 x 64: a 40-channel slab of ~1000 rows is three blocks of two 8-deep batches of independent 16-byte loads per thread
+// (the 32 x 32 split it replaces walked 31 rows per thread in 8 dependent batches — these kernels are pure latency).
+constexpr int BN_CH = 16, BN_RG = 64;
 __device__ __forceinline__ void slab_sum(const double* slab, int rows, int C, int c, int rg, double& s0, double& s1,
-                                         double (*sh)[32][2]) {
+                                         double (*sh)[BN_CH][2]) {
   double a = 0.0, b = 0.0;
   if (c < C) {
-    // independent 16-B loads: unroll so several are in flight per thread
     int r = rg;
-    for (; r + 96 < rows; r += 128) {
-      const double2 v0 = *reinterpret_cast<const double2*>(slab + ((long)r * C + c) * 2);
-      const double2 v1 = *reinterpret_cast<const double2*>(slab + ((long)(r + 32) * C + c) * 2);
-      const double2 v2 = *reinterpret_cast<const double2*>(slab + ((long)(r + 64) * C + c) * 2);
-      const double2 v3 = *reinterpret_cast<const double2*>(slab + ((long)(r + 96) * C + c) * 2);
-      a += (v0.x + v1.x) + (v2.x + v3.x); b += (v0.y + v1.y) + (v2.y + v3.y);
+    for (; r + 7 * BN_RG < rows; r += 8 * BN_RG) {
+      double2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2*>(slab + ((long)(r + k * BN_RG) * C + c) * 2);
+      a += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+      b += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
     }
-    for (; r < rows; r += 32) {
-      const double2 v = *reinterpret_cast<const double2*>(slab + ((long)r * C + c) * 2);
-      a += v.x; b += v.y;
+    double2 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int rr = r + k * BN_RG;
+      const bool ok = rr < rows;
+      const double2 t = *reinterpret_cast<const double2*>(slab + ((long)(ok ? rr : 0) * C + c) * 2);
+      w[k].x = ok ? t.x : 0.0; w[k].y = ok ? t.y : 0.0;
     }
+    a += ((w[0].x + w[1].x) + (w[2].x + w[3].x)) + ((w[4].x + w[5].x) + (w[6].x + w[7].x));
+    b += ((w[0].y + w[1].y) + (w[2].y + w[3].y)) + ((w[4].y + w[5].y) + (w[6].y + w[7].y));
   }
-  const int cl = threadIdx.x & 31;
+  const int cl = threadIdx.x % BN_CH;
   sh[rg][cl][0] = a; sh[rg][cl][1] = b;
   __syncthreads();
-  for (int s = 16; s > 0; s >>= 1) {
+  for (int s = BN_RG / 2; s > 0; s >>= 1) {
     if (rg < s) { sh[rg][cl][0] += sh[rg + s][cl][0]; sh[rg][cl][1] += sh[rg + s][cl][1]; }
     __syncthreads();
   }
@@ -38,9 +46,9 @@ __device__ __forceinline__ void slab_sum(const double* slab, int rows, int C, in
 }
 
 __global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finalize_args p) {
-  __shared__ double sh[32][32][2];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double sh[BN_RG][BN_CH][2];
+  const int cl = threadIdx.x % BN_CH, rg = threadIdx.x / BN_CH;
+  const int c = blockIdx.x * BN_CH + cl;
   double s0, s1;
   slab_sum((const double*)p.partial, p.rows, p.C, c, rg, s0, s1, sh);
   if (rg == 0 && c < p.C) {
@@ -63,9 +71,9 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finaliz
 }
 
 __global__ void __launch_bounds__(1024) slab_reduce_kernel(const double* slab, int rows, int C, double* out) {
-  __shared__ double sh[32][32][2];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double sh[BN_RG][BN_CH][2];
+  const int cl = threadIdx.x % BN_CH, rg = threadIdx.x / BN_CH;
+  const int c = blockIdx.x * BN_CH + cl;
   double s0, s1;
   slab_sum(slab, rows, C, c, rg, s0, s1, sh);
   if (rg == 0 && c < C) { out[2 * c] = s0; out[2 * c + 1] = s1; }
@@ -93,9 +101,9 @@ __global__ void bn_eval_affine_batch_kernel(const BnEvalEntry* __restrict__ tab)
 }
 
 __global__ void __launch_bounds__(1024) bn_bwd_kernel(const addk_bn_bwd_args p) {
-  __shared__ double sh[32][32][2];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double sh[BN_RG][BN_CH][2];
+  const int cl = threadIdx.x % BN_CH, rg = threadIdx.x / BN_CH;
+  const int c = blockIdx.x * BN_CH + cl;
   double dA = 0.0, dB = 0.0;
   for (int k = 0; k < p.nslab; ++k) {
     double s0, s1;
@@ -125,13 +133,13 @@ __global__ void bn_coeffs_kernel(const float* dmv, int C, double count, float* c
 extern "C" int addk_bn_finalize(const addk_bn_finalize_args* a, void* stream) {
   ADDK_REQUIRE(a && a->partial && a->a && a->b && a->C > 0 && a->rows > 0 && a->count > 0, "bn_finalize: bad args");
   ADDK_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "bn_finalize: running stats come together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 32)), dim3(1024), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, BN_CH)), dim3(1024), 0, (hipStream_t)stream, *a);
   return addk_check_launch("bn_finalize");
 }
 
 extern "C" int addk_slab_reduce(const double* partial, int32_t rows, int32_t C, double* out, void* stream) {
   ADDK_REQUIRE(partial && out && rows > 0 && C > 0, "slab_reduce: bad args");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, partial, rows, C, out);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(C, BN_CH)), dim3(1024), 0, (hipStream_t)stream, partial, rows, C, out);
   return addk_check_launch("slab_reduce");
 }
 
@@ -147,7 +155,7 @@ extern "C" int addk_bn_bwd(const addk_bn_bwd_args* a, void* stream) {
   ADDK_REQUIRE(a->mean && a->invstd && a->a, "bn_bwd: saved statistics missing");
   ADDK_REQUIRE((a->c1 == nullptr) == (a->c2 == nullptr) && (a->c1 || a->dmv), "bn_bwd: need c1/c2 or dmv");
   for (int i = 0; i < a->nslab; ++i) ADDK_REQUIRE(a->slab[i] && a->rows[i] > 0, "bn_bwd: bad slab %d", i);
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(a->C, 32)), dim3(1024), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(a->C, BN_CH)), dim3(1024), 0, (hipStream_t)stream, *a);
   return addk_check_launch("bn_bwd");
 }
 
