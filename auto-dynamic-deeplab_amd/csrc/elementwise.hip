@@ -111,6 +111,31 @@ __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
   }
 }
 
+// vector-aligned form: every load is a plain 16-byte load issued up front (coefficients and data are one round trip)
+__global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* g, int ldg, const float* x, int ldx, const float* alpha,
+                                                               const float* c1, const float* c2, long P, float* out, int ldo,
+                                                               int nq, int npl) {
+  const int q = threadIdx.x % nq, pl = threadIdx.x / nq;
+  if (pl >= npl) return;
+  const int c = 4 * q;
+  const long pp0 = (long)blockIdx.x * npl + pl;
+  if (pp0 >= P) return;
+  float4 gv = ld4(g + pp0 * ldg + c);
+  float4 xv = c2 ? ld4(x + pp0 * ldx + c) : zero4();
+  const float4 al = alpha ? ld4(alpha + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 k1 = c1 ? ld4(c1 + c) : zero4();
+  const float4 k2 = c2 ? ld4(c2 + c) : zero4();
+  for (long pp = pp0;;) {
+    const long nx = pp + (long)gridDim.x * npl;
+    float4 gn = zero4(), xn = zero4();
+    if (nx < P) { gn = ld4(g + nx * ldg + c); if (c2) xn = ld4(x + nx * ldx + c); }
+    st4(out + pp * ldo + c, make_float4(fmaf(al.x, gv.x, fmaf(k2.x, xv.x, k1.x)), fmaf(al.y, gv.y, fmaf(k2.y, xv.y, k1.y)),
+                                        fmaf(al.z, gv.z, fmaf(k2.z, xv.z, k1.z)), fmaf(al.w, gv.w, fmaf(k2.w, xv.w, k1.w))));
+    if (nx >= P) break;
+    pp = nx; gv = gn; xv = xn;
+  }
+}
+
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* g, int ldg, const float* x, int ldx, const float* alpha,
                                                            const float* c1, const float* c2, long P, int C, float* out, int ldo,
                                                            int nq, int npl, int vec) {
@@ -206,6 +231,11 @@ extern "C" int addk_bn_bwd_apply(const float* g, int32_t ldg, const float* x, in
   int vec = aligned16(g) && aligned16(out) && ldg % 4 == 0 && ldo % 4 == 0 && C % 4 == 0 && (!x || (aligned16(x) && ldx % 4 == 0)) &&
             (!alpha || aligned16(alpha)) && (!c1 || (aligned16(c1) && aligned16(c2)));
   EwMap m = ew_map(C);
+  if (vec && C == m.nq * 4) {
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(ew_blocks(P, m.npl)), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, alpha, c1, c2,
+                       (long)P, out, ldo, m.nq, m.npl);
+    return addk_check_launch("bn_bwd_apply");
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, m.npl)), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, alpha, c1, c2,
                      (long)P, C, out, ldo, m.nq, m.npl, vec);
   return addk_check_launch("bn_bwd_apply");
