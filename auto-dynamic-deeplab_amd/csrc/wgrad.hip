@@ -928,6 +928,17 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
   for (int i = 0; i < n; ++i) {
     int cty, ctz, tiles;
     wg_fill(&a[i], ops[i], cty, ctz, tiles, true, budget, min_steps, h3_steps);
+    if (kind0 == 6) {
+      // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so within a group of 8 pixel chunks the tiles
+      // (taps x channel blocks) of one chunk are placed 8 apart: they share an XCD and its L2 serves the 9/25 re-reads
+      // of that chunk's dy / activation rows.
+      const int sp = ops[i].splits;
+      for (int g0 = 0; g0 < sp; g0 += 8) {
+        const int gn = sp - g0 < 8 ? sp - g0 : 8;
+        for (int x = 0; x < tiles; ++x)
+          for (int yy = 0; yy < gn; ++yy) work[b++] = make_int4(i, x, g0 + yy, 0);
+      }
+    } else
     for (int y = 0; y < ops[i].splits; ++y)
       for (int x = 0; x < tiles; ++x) work[b++] = make_int4(i, x, y, 0);
     long ne = (long)a[i].Cout * ops[i].taps * a[i].src.C;
