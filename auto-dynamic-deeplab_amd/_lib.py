@@ -46,7 +46,11 @@ class DwArgs(C.Structure):
 class DwBwdArgs(C.Structure):
     _fields_ = [('dy', vp), ('lddy', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32), ('KH', i32),
                 ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('src', Src), ('w', vp), ('g', vp), ('ldg', i32),
-                ('accumulate', i32), ('dab', vp), ('dw', vp), ('dw_accumulate', i32), ('ws', vp)]
+                ('accumulate', i32), ('dab', vp), ('dw', vp), ('dw_accumulate', i32), ('ws', vp), ('defer_wreduce', i32), ('_pad', i32)]
+
+
+class DwWreduceItem(C.Structure):
+    _fields_ = [('ws', vp), ('dw', vp), ('rows', i32), ('n', i32), ('accumulate', i32), ('_pad', i32)]
 
 
 class BnFinalizeArgs(C.Structure):
@@ -107,6 +111,7 @@ _SIGS = {
     'addk_dw_fwd': (i32, [C.POINTER(DwArgs), vp]),
     'addk_dw_bwd': (i32, [C.POINTER(DwBwdArgs), vp]),
     'addk_dw_rows': (i32, [i64, i32]),
+    'addk_dw_wreduce_batch': (i32, [vp, i32, vp]),
     'addk_bn_finalize': (i32, [C.POINTER(BnFinalizeArgs), vp]),
     'addk_slab_reduce': (i32, [vp, i32, i32, vp, vp]),
     'addk_bn_eval_affine': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),

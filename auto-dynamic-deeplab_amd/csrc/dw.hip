@@ -365,6 +365,18 @@ __global__ void __launch_bounds__(256) dw_wreduce_kernel(const float* ws, int ro
   if (lane == 0) dw[i] = accumulate ? dw[i] + s : s;
 }
 
+// batched form: block b = (item, 4 weight elements); the items' tables live in device memory
+__global__ void __launch_bounds__(256) dw_wreduce_batch_kernel(const addk_dw_wreduce_item* __restrict__ items, int max_blocks_per_item) {
+  const addk_dw_wreduce_item it = items[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < it.n; i += max_blocks_per_item * 4) {
+    float s = 0.f;
+    for (int r = lane; r < it.rows; r += 64) s += it.ws[(long)r * it.n + i];
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) it.dw[i] = it.accumulate ? it.dw[i] + s : s;
+  }
+}
+
 int dw_rows(long P, int C) {
   EwMap m = ew_map(C);
   long r = P / ((long)m.npl * 2);      // >= 4 resident blocks per CU on the level-1 maps
@@ -468,7 +480,15 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
   else { addk_set_error("dw_bwd: only 3x3 and 5x5 depthwise kernels are built"); return ADDK_ERR_UNSUPPORTED; }
   rc = addk_check_launch("dw_bwd");
   if (rc) return rc;
+  if (a->defer_wreduce) return ADDK_OK;
   int n = a->src.C * taps;
   hipLaunchKernelGGL(dw_wreduce_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, a->ws, rows, n, a->dw, a->dw_accumulate);
   return addk_check_launch("dw_wreduce");
+}
+
+extern "C" int addk_dw_wreduce_batch(const addk_dw_wreduce_item* dev_items, int32_t n_items, void* stream) {
+  ADDK_REQUIRE(dev_items && n_items > 0, "dw_wreduce_batch: bad args");
+  const int per = 256;          // blocks per item: 1024 weight elements per pass (C*taps <= 160*25 = 4000 -> 4 passes)
+  hipLaunchKernelGGL(dw_wreduce_batch_kernel, dim3(per, n_items), dim3(256), 0, (hipStream_t)stream, dev_items, per);
+  return addk_check_launch("dw_wreduce_batch");
 }

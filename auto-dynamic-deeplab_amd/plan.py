@@ -211,6 +211,7 @@ class Graph:
         self.nstreams = 1             # set by finalize(nstreams=k)
         self.tag = ''                 # segment label stamped on emitted commands (stem / cell / low / aspp / decoder)
         self._evalbn, self._evalbn_cmd = [], None
+        self._dwreds = []             # deferred depthwise weight-gradient reductions (item, workspace, grad tensor)
         self.meta = []                # per-launch algorithmic work of the dense convs (bench / roofline)
 
     # ---------------- memory ----------------
@@ -297,6 +298,7 @@ class Graph:
             tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
             self.keep += [arr, tab]
             self._evalbn_cmd.args[0], self._evalbn_cmd.args[1] = tab.data_ptr(), n
+        self._emit_batched_dw_reductions()
         self._emit_batched_wgrads()
         for lst in (self.fwd, self.bwd):
             for i, c in enumerate(lst):
@@ -306,6 +308,25 @@ class Graph:
             for c in lst:
                 if c.event:
                     c.event = torch.cuda.Event()
+
+    def _emit_batched_dw_reductions(self):
+        """One launch reduces the weight-gradient partials of every depthwise conv of the backward pass; two items that
+        write the same weight (a module used twice) go to consecutive launches, in emission order."""
+        waves = []
+        for it, ws, grad in self._dwreds:
+            if not waves or it.dw in waves[-1][1]:
+                waves.append(([], set()))
+            waves[-1][0].append((it, ws, grad))
+            waves[-1][1].add(it.dw)
+        for items, _ in waves:
+            n = len(items)
+            arr = (L.DwWreduceItem * n)(*[it for it, _, _ in items])
+            host = bytes(arr)
+            tab = torch.frombuffer(bytearray(host), dtype=torch.uint8)
+            tab = tab.to(self.device) if self.device.type == 'cuda' else tab.clone()
+            self.keep += [arr, tab]
+            self._add(self.bwd, 'dw_wreduce_batch', self.lib.addk_dw_wreduce_batch, tab.data_ptr(), n,
+                      rd=[ws for _, ws, _ in items], wr=[g for _, _, g in items])
 
     def _emit_batched_wgrads(self):
         """All weight gradients of the backward pass are deferred to its end and launched in a few batches: one launch
@@ -697,9 +718,13 @@ class Graph:
                 ba.dw, ba.dw_accumulate = gp, acc
                 ws = self.buf(rows * Cc * k * k)
                 ba.ws = ws.ptr
+                ba.defer_wreduce = 1          # the [rows][C][k*k] partials are reduced at the end of the backward pass, all convs in one launch
+                it = L.DwWreduceItem()
+                it.ws, it.dw, it.rows, it.n, it.accumulate = ws.ptr, gp, rows, Cc * k * k, acc
+                self._dwreds.append((it, ws, self.pgrad[conv_mod.weight]))
                 self.keep.append(ba)
                 self._add(self.bwd, 'dw_bwd', lib.addk_dw_bwd, C.byref(ba), rd=[dy, conv_mod.weight] + self.lz(src),
-                          wr=[gs, slab, self.pgrad[conv_mod.weight], ws])
+                          wr=[gs, slab, ws])
             self._bwd_emitters.append(emit_bwd)
         return act
 

@@ -172,8 +172,14 @@ typedef struct addk_dw_bwd_args {
   double* dab;                  /* fp64 [rows][C][2] or NULL; rows = addk_dw_rows() */
   float* dw; int32_t dw_accumulate;            /* [C][KH*KW] */
   float* ws;                    /* [rows][C][KH*KW] partial weight gradients */
+  int32_t defer_wreduce;        /* 1: leave the partials in ws; the caller reduces them later with addk_dw_wreduce_batch */
+  int32_t _pad;
 } addk_dw_bwd_args;
 int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream);
+/* Deferred reduction of the depthwise weight-gradient partials of MANY convolutions in one launch (they are mutually
+ * independent and only needed by the optimizer): table entry i reduces ws_i [rows_i][n_i] into dw_i [n_i]. */
+typedef struct addk_dw_wreduce_item { const float* ws; float* dw; int32_t rows, n, accumulate, _pad; } addk_dw_wreduce_item;
+int addk_dw_wreduce_batch(const addk_dw_wreduce_item* dev_items, int32_t n_items, void* stream);
 int addk_dw_rows(int64_t P, int32_t C);
 
 /* ---------------------------------------------------------------------------------------
