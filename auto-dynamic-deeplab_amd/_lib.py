@@ -22,14 +22,14 @@ class ConvArgs(C.Structure):
     _fields_ = [('src', Src * MAX_SRC), ('nsrc', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('Cout', i32), ('ldw', i32),
                 ('cin_total', i32), ('w_choff', i32), ('ldy', i32), ('w', vp), ('y', vp), ('bias', vp), ('bias_n', vp),
-                ('stats', vp), ('stats_ld', i32), ('_pad', i32), ('wpack', vp), ('wpack_floats', i64)]
+                ('stats', vp), ('stats_ld', i32), ('_pad', i32), ('wpack', vp), ('wpack_floats', i64), ('wpack_ready', i32), ('_pad2', i32)]
 
 
 class ConvDgradArgs(C.Structure):
     _fields_ = [('dy', vp), ('lddy', i32), ('Cout', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('w', vp), ('ldw', i32),
                 ('cin_total', i32), ('w_choff', i32), ('dst', Src), ('g', vp), ('ldg', i32), ('accumulate', i32),
-                ('dab', vp), ('wpack', vp), ('wpack_floats', i64)]
+                ('dab', vp), ('wpack', vp), ('wpack_floats', i64), ('wpack_ready', i32), ('_pad2', i32)]
 
 
 class ConvWgradArgs(C.Structure):
@@ -103,6 +103,10 @@ _SIGS = {
     'addk_get_fast_paths': (i32, []),
     'addk_conv_fwd_pack_floats': (i64, [C.POINTER(ConvArgs)]),
     'addk_conv_dgrad_pack_floats': (i64, [C.POINTER(ConvDgradArgs)]),
+    'addk_conv_pack_desc_bytes': (i64, []),
+    'addk_conv_fwd_pack_desc': (i32, [C.POINTER(ConvArgs), vp]),
+    'addk_conv_dgrad_pack_desc': (i32, [C.POINTER(ConvDgradArgs), vp]),
+    'addk_conv_pack_batch': (i32, [vp, i32, vp]),
     'addk_conv_wgrad': (i32, [C.POINTER(ConvWgradArgs), vp]),
     'addk_conv_wgrad_ws': (i64, [i64, i32, i32, i32]),
     'addk_conv_wgrad_config': (i32, [C.POINTER(ConvWgradArgs), C.POINTER(i32)]),

@@ -56,12 +56,18 @@ struct PackK {
 };
 
 // out[colblk][T = chunk*taps + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
-__global__ void __launch_bounds__(256) c3_pack_kernel(const PackK p) {
+__device__ __forceinline__ void c3_pack_body(const PackK& p, long first, long stride);
+__global__ void __launch_bounds__(256) c3_pack_kernel(const PackK p) { c3_pack_body(p, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256); }
+// all packs of a plan in one launch at the start of the step (the weights only change in the optimizer): block (x, y) works on descriptor y
+__global__ void __launch_bounds__(256) c3_pack_batch_kernel(const PackK* __restrict__ descs) {
+  c3_pack_body(descs[blockIdx.y], (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+}
+__device__ __forceinline__ void c3_pack_body(const PackK& p, long first, long stride) {
   const int BC = 16 * p.bct;
   const int nT = p.nchunks * p.taps;
   const long per_blk = (long)nT * p.bct * 256;
   const long total = (long)((p.Cn + BC - 1) / BC) * per_blk;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+  for (long idx = first; idx < total; idx += stride) {
     const int m = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     long r = idx >> 8;
     const int i = (int)(r % p.bct); r /= p.bct;
@@ -338,7 +344,7 @@ bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, 
   return pad == dil * (KH / 2) && OH == H && OW == W && W >= 100 && P >= 8192 && Cn >= 32 && addk_get_conv_precision() == 0;
 }
 
-int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st) {
+int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out = nullptr) {
   const int bct = c3_bct(k.Cn, k.P);
   pk.bct = bct; pk.mode = mode; pk.Cn = k.Cn;
   k.nT = pk.nchunks * pk.taps;
@@ -349,7 +355,8 @@ int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st) {
   k.red32 = k.P >= 4096;
   const long total = c3_pack_floats(k.Cn, pk.nchunks, k.P, pk.taps);
   int pb = cdiv(total, 256 * 4); if (pb > 4096) pb = 4096;
-  hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
+  if (desc_out) { *desc_out = pk; return ADDK_OK; }              // descriptor query only (addk_conv_*_pack_desc)
+  if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
   dim3 grid(rows, cdiv(k.Cn, 16 * bct));
   bool done = false;
 #define ADDK_C3(B_, K_) \
@@ -384,7 +391,7 @@ extern "C" int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a) {
 }
 
 // 0 = launched, 1 = not covered (caller falls back to the generic kernel), <0 = error
-int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) {
+static int c3_fwd(const addk_conv_args* a, int rows, void* stream, PackK* desc_out) {
   const int64_t need = addk_conv_fwd_pack_floats(a);
   if (need == 0 || !a->wpack || a->wpack_floats < need) return 1;
   if (!aligned16(a->y) || !aligned16(a->wpack)) return 1;
@@ -408,10 +415,10 @@ int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) {
   k.dst = addk_src{nullptr, nullptr, nullptr, 0, 0, 0, 0}; k.accumulate = 0;
   k.vecY = 1;
   k.P = (long)a->N * a->H * a->W;
-  return c3_launch(k, pk, MODE_FWD, rows, (hipStream_t)stream);
+  return c3_launch(k, pk, MODE_FWD, rows, (hipStream_t)stream, a->wpack_ready != 0, desc_out);
 }
 
-int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
+static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK* desc_out) {
   const int64_t need = addk_conv_dgrad_pack_floats(a);
   if (need == 0 || !a->wpack || a->wpack_floats < need) return 1;
   if (!aligned16(a->dy) || !aligned16(a->g) || !aligned16(a->wpack) || !src_vec_ok(a->dst)) return 1;
@@ -431,5 +438,29 @@ int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
   k.dst = a->dst; k.accumulate = a->accumulate;
   k.vecY = 1;
   k.P = (long)a->N * a->H * a->W;
-  return c3_launch(k, pk, MODE_DGRAD, rows, (hipStream_t)stream);
+  return c3_launch(k, pk, MODE_DGRAD, rows, (hipStream_t)stream, a->wpack_ready != 0, desc_out);
+}
+
+int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) { return c3_fwd(a, rows, stream, nullptr); }
+int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) { return c3_dgrad(a, rows, stream, nullptr); }
+
+// Hoisting the weight packs out of the step's critical path: a plan collects one descriptor per halo-patch launch,
+// uploads the table and runs ONE addk_conv_pack_batch at the start of the step; the launches then carry wpack_ready = 1.
+extern "C" int64_t addk_conv_pack_desc_bytes(void) { return (int64_t)sizeof(PackK); }
+extern "C" int addk_conv_fwd_pack_desc(const addk_conv_args* a, void* host_desc) {
+  ADDK_REQUIRE(a && host_desc, "conv_fwd_pack_desc: null pointer");
+  const int r = c3_fwd(a, 1, nullptr, reinterpret_cast<PackK*>(host_desc));
+  if (r == 1) { addk_set_error("conv_fwd_pack_desc: the halo-patch kernel does not cover this launch"); return ADDK_ERR_UNSUPPORTED; }
+  return r;
+}
+extern "C" int addk_conv_dgrad_pack_desc(const addk_conv_dgrad_args* a, void* host_desc) {
+  ADDK_REQUIRE(a && host_desc, "conv_dgrad_pack_desc: null pointer");
+  const int r = c3_dgrad(a, 1, nullptr, reinterpret_cast<PackK*>(host_desc));
+  if (r == 1) { addk_set_error("conv_dgrad_pack_desc: the halo-patch kernel does not cover this launch"); return ADDK_ERR_UNSUPPORTED; }
+  return r;
+}
+extern "C" int addk_conv_pack_batch(const void* dev_descs, int32_t n, void* stream) {
+  ADDK_REQUIRE(dev_descs && n > 0, "conv_pack_batch: bad args");
+  hipLaunchKernelGGL(c3_pack_batch_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackK*>(dev_descs));
+  return addk_check_launch("conv_pack_batch");
 }

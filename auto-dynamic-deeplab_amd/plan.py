@@ -212,6 +212,7 @@ class Graph:
         self.tag = ''                 # segment label stamped on emitted commands (stem / cell / low / aspp / decoder)
         self._evalbn, self._evalbn_cmd = [], None
         self._dwreds = []             # deferred depthwise weight-gradient reductions (item, workspace, grad tensor)
+        self._packs, self._pack_cmd = [], None   # hoisted weight packs of the halo-patch conv launches (descriptor bytes)
         self.meta = []                # per-launch algorithmic work of the dense convs (bench / roofline)
 
     # ---------------- memory ----------------
@@ -300,6 +301,12 @@ class Graph:
             self._evalbn_cmd.args[0], self._evalbn_cmd.args[1] = tab.data_ptr(), n
         self._emit_batched_dw_reductions()
         self._emit_batched_wgrads()
+        if self._packs:
+            host = bytearray(b''.join(self._packs))
+            tab = torch.frombuffer(host, dtype=torch.uint8)
+            tab = tab.to(self.device) if self.device.type == 'cuda' else tab.clone()
+            self.keep.append(tab)
+            self._pack_cmd.args[0], self._pack_cmd.args[1] = tab.data_ptr(), len(self._packs)
         for lst in (self.fwd, self.bwd):
             for i, c in enumerate(lst):
                 if not isinstance(c, Cmd):           # commands appended as plain triples (e.g. collectives): pinned to the main stream
@@ -308,6 +315,21 @@ class Graph:
             for c in lst:
                 if c.event:
                     c.event = torch.cuda.Event()
+
+    def _hoist_pack(self, desc_fn, args, weight, wpk, create):
+        """Move the weight pack of a halo-patch conv launch out of the launch: all packs of the plan (forward and data
+        gradient: the weights only change in the optimizer) run as ONE launch placed before the first such conv."""
+        if self._pack_cmd is None:
+            if not create:
+                return
+            self._pack_cmd = self._add(self.fwd, 'conv_pack_batch', self.lib.addk_conv_pack_batch, None, 0)
+        nb = int(self.lib.addk_conv_pack_desc_bytes())
+        buf = (C.c_uint8 * nb)()
+        L.check(desc_fn(C.byref(args), buf), 'conv_pack_desc')
+        self._packs.append(bytes(buf))
+        args.wpack_ready = 1
+        self._pack_cmd.rd.append(_region(weight))
+        self._pack_cmd.wr.append(_region(wpk))
 
     def _emit_batched_dw_reductions(self):
         """One launch reduces the weight-gradient partials of every depthwise conv of the backward pass; two items that
@@ -485,6 +507,7 @@ class Graph:
         if npk > 0:
             wpk = self.buf(npk)
             ar.wpack, ar.wpack_floats = wpk.ptr, npk
+            self._hoist_pack(lib.addk_conv_fwd_pack_desc, ar, weight, wpk, create=True)
         self.keep.append(ar)
         self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
                   rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
@@ -535,6 +558,7 @@ class Graph:
                         if npk > 0:
                             dpk = self.buf(npk)
                             da.wpack, da.wpack_floats = dpk.ptr, npk
+                            self._hoist_pack(lib.addk_conv_dgrad_pack_desc, da, weight, dpk, create=False)
                         self.keep.append(da)
                         self._add(self.bwd, 'conv_dgrad', lib.addk_conv_dgrad, C.byref(da), rd=[dy, weight] + self.lz(s),
                                   wr=[gs, slab, dpk])

@@ -88,6 +88,9 @@ typedef struct addk_conv_args {
                                  convolutions run on the halo-patch kernel (weights re-packed into MFMA fragment order
                                  per launch); NULL = generic kernel */
   int64_t wpack_floats;
+  int32_t wpack_ready;        /* 1: wpack already holds this launch's packed weights (addk_conv_pack_batch ran since the
+                                 last weight update); 0: the launch packs them itself */
+  int32_t _pad2;
 } addk_conv_args;
 int addk_conv_fwd(const addk_conv_args* a, void* stream);
 /* floats of `wpack` this launch can use; 0 = the halo-patch kernel does not cover the shape */
@@ -124,9 +127,18 @@ typedef struct addk_conv_dgrad_args {
   double* dab;                 /* fp64 [rows][C][2] partial (dA,dB) or NULL; rows = addk_conv_rows(N*H*W, C) */
   float* wpack;                /* optional packed-weight workspace (see addk_conv_args.wpack) */
   int64_t wpack_floats;
+  int32_t wpack_ready;         /* see addk_conv_args.wpack_ready */
+  int32_t _pad2;
 } addk_conv_dgrad_args;
 int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream);
 int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a);
+/* Weight packs hoisted out of the step: fill one opaque descriptor (addk_conv_pack_desc_bytes() bytes, host memory) per
+ * launch that has a wpack workspace, upload the array and run addk_conv_pack_batch once per step before the first
+ * launch; those launches then set wpack_ready = 1. */
+int64_t addk_conv_pack_desc_bytes(void);
+int addk_conv_fwd_pack_desc(const addk_conv_args* a, void* host_desc);
+int addk_conv_dgrad_pack_desc(const addk_conv_dgrad_args* a, void* host_desc);
+int addk_conv_pack_batch(const void* dev_descs, int32_t n, void* stream);
 
 /* Weight gradient for ONE source: dw[co][tap][w_choff+ci] = sum_p dy[p,co] * z[p@tap,ci],
  * z = relu?(a*x+b).  Deterministic split-P: partial tiles go to `ws`, then are reduced into
