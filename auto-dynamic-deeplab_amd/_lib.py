@@ -69,6 +69,11 @@ class BnBwdArgs(C.Structure):
                 ('accumulate', i32), ('c1', vp), ('c2', vp), ('dmv', vp)]
 
 
+class BnApplyItem(C.Structure):
+    _fields_ = [('g', vp), ('x', vp), ('c1', vp), ('c2', vp), ('out', vp), ('P', i64), ('ldg', i32), ('ldx', i32), ('ldo', i32),
+                ('C', i32)]
+
+
 class AffineSumArgs(C.Structure):
     _fields_ = [('term', Src * MAX_TERMS), ('nterm', i32), ('P', i64), ('C', i32), ('out', vp), ('ldo', i32),
                 ('relu_out', i32), ('accumulate', i32)]
@@ -116,6 +121,9 @@ _SIGS = {
     'addk_dw_bwd': (i32, [C.POINTER(DwBwdArgs), vp]),
     'addk_dw_rows': (i32, [i64, i32]),
     'addk_dw_wreduce_batch': (i32, [vp, i32, vp]),
+    'addk_bn_finalize_batch': (i32, [vp, i32, i32, vp]),
+    'addk_bn_bwd_batch': (i32, [vp, i32, i32, vp]),
+    'addk_bn_bwd_apply_batch': (i32, [vp, i32, i64, vp]),
     'addk_bn_finalize': (i32, [C.POINTER(BnFinalizeArgs), vp]),
     'addk_slab_reduce': (i32, [vp, i32, i32, vp, vp]),
     'addk_bn_eval_affine': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),

@@ -45,8 +45,7 @@ __device__ __forceinline__ void slab_sum(const double* slab, int rows, int C, in
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finalize_args p) {
-  __shared__ double sh[BN_RG][BN_CH][2];
+__device__ __forceinline__ void bn_finalize_body(const addk_bn_finalize_args& p, double (*sh)[BN_CH][2]) {
   const int cl = threadIdx.x % BN_CH, rg = threadIdx.x / BN_CH;
   const int c = blockIdx.x * BN_CH + cl;
   double s0, s1;
@@ -68,6 +67,17 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finaliz
       p.running_var[c] = (float)((1.0 - p.momentum) * p.running_var[c] + p.momentum * unb);
     }
   }
+}
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const addk_bn_finalize_args p) {
+  __shared__ double sh[BN_RG][BN_CH][2];
+  bn_finalize_body(p, sh);
+}
+// several independent BatchNorms in one launch: block (x, y) = channel block x of table entry y
+__global__ void __launch_bounds__(1024) bn_finalize_batch_kernel(const addk_bn_finalize_args* __restrict__ tab) {
+  __shared__ double sh[BN_RG][BN_CH][2];
+  const addk_bn_finalize_args p = tab[blockIdx.y];
+  if (blockIdx.x * BN_CH >= p.C) return;
+  bn_finalize_body(p, sh);
 }
 
 __global__ void __launch_bounds__(1024) slab_reduce_kernel(const double* slab, int rows, int C, double* out) {
@@ -100,8 +110,7 @@ __global__ void bn_eval_affine_batch_kernel(const BnEvalEntry* __restrict__ tab)
   }
 }
 
-__global__ void __launch_bounds__(1024) bn_bwd_kernel(const addk_bn_bwd_args p) {
-  __shared__ double sh[BN_RG][BN_CH][2];
+__device__ __forceinline__ void bn_bwd_body(const addk_bn_bwd_args& p, double (*sh)[BN_CH][2]) {
   const int cl = threadIdx.x % BN_CH, rg = threadIdx.x / BN_CH;
   const int c = blockIdx.x * BN_CH + cl;
   double dA = 0.0, dB = 0.0;
@@ -121,6 +130,16 @@ __global__ void __launch_bounds__(1024) bn_bwd_kernel(const addk_bn_bwd_args p) 
     if (p.dmv) { p.dmv[2 * c] = (float)dmean_tot; p.dmv[2 * c + 1] = (float)dvar; }
     if (p.c1) { p.c1[c] = (float)(dmean_tot / p.count); p.c2[c] = (float)(2.0 * dvar / p.count); }
   }
+}
+__global__ void __launch_bounds__(1024) bn_bwd_kernel(const addk_bn_bwd_args p) {
+  __shared__ double sh[BN_RG][BN_CH][2];
+  bn_bwd_body(p, sh);
+}
+__global__ void __launch_bounds__(1024) bn_bwd_batch_kernel(const addk_bn_bwd_args* __restrict__ tab) {
+  __shared__ double sh[BN_RG][BN_CH][2];
+  const addk_bn_bwd_args& p = tab[blockIdx.y];
+  if (blockIdx.x * BN_CH >= p.C) return;
+  bn_bwd_body(p, sh);
 }
 
 __global__ void bn_coeffs_kernel(const float* dmv, int C, double count, float* c1, float* c2) {
@@ -169,4 +188,15 @@ extern "C" int addk_bn_eval_affine_batch(const void* dev_table, int32_t n, void*
   ADDK_REQUIRE(dev_table && n > 0, "bn_eval_affine_batch: bad args");
   hipLaunchKernelGGL(bn_eval_affine_batch_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const BnEvalEntry*>(dev_table));
   return addk_check_launch("bn_eval_affine_batch");
+}
+
+extern "C" int addk_bn_finalize_batch(const addk_bn_finalize_args* dev_table, int32_t n, int32_t max_C, void* stream) {
+  ADDK_REQUIRE(dev_table && n > 0 && max_C > 0, "bn_finalize_batch: bad args");
+  hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(cdiv(max_C, BN_CH), n), dim3(1024), 0, (hipStream_t)stream, dev_table);
+  return addk_check_launch("bn_finalize_batch");
+}
+extern "C" int addk_bn_bwd_batch(const addk_bn_bwd_args* dev_table, int32_t n, int32_t max_C, void* stream) {
+  ADDK_REQUIRE(dev_table && n > 0 && max_C > 0, "bn_bwd_batch: bad args");
+  hipLaunchKernelGGL(bn_bwd_batch_kernel, dim3(cdiv(max_C, BN_CH), n), dim3(1024), 0, (hipStream_t)stream, dev_table);
+  return addk_check_launch("bn_bwd_batch");
 }

@@ -136,6 +136,30 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* g, i
   }
 }
 
+// several independent tensors in one launch (vector-aligned items only): block (x, y) strides over the pixels of item y
+struct BnApplyItem { const float* g; const float* x; const float* c1; const float* c2; float* out; long P; int ldg, ldx, ldo, C; };
+__global__ void __launch_bounds__(256) bn_bwd_apply_batch_kernel(const BnApplyItem* __restrict__ tab) {
+  const BnApplyItem it = tab[blockIdx.y];
+  const int nq = it.C >> 2, npl = 256 / nq;
+  const int q = threadIdx.x % nq, pl = threadIdx.x / nq;
+  if (pl >= npl) return;
+  const int c = 4 * q;
+  long pp = (long)blockIdx.x * npl + pl;
+  if (pp >= it.P) return;
+  const float4 k1 = ld4(it.c1 + c), k2 = ld4(it.c2 + c);
+  const long step = (long)gridDim.x * npl;
+  float4 gv = ld4(it.g + pp * it.ldg + c), xv = ld4(it.x + pp * it.ldx + c);
+  for (;;) {
+    const long nx = pp + step;
+    float4 gn = zero4(), xn = zero4();
+    if (nx < it.P) { gn = ld4(it.g + nx * it.ldg + c); xn = ld4(it.x + nx * it.ldx + c); }
+    st4(it.out + pp * it.ldo + c, make_float4(gv.x + fmaf(k2.x, xv.x, k1.x), gv.y + fmaf(k2.y, xv.y, k1.y),
+                                              gv.z + fmaf(k2.z, xv.z, k1.z), gv.w + fmaf(k2.w, xv.w, k1.w)));
+    if (nx >= it.P) break;
+    pp = nx; gv = gn; xv = xn;
+  }
+}
+
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* g, int ldg, const float* x, int ldx, const float* alpha,
                                                            const float* c1, const float* c2, long P, int C, float* out, int ldo,
                                                            int nq, int npl, int vec) {
@@ -256,4 +280,15 @@ extern "C" int addk_sgd_step(float* p, const float* g, float* buf, int64_t n, co
   hipLaunchKernelGGL(sgd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, lr_dev, momentum, weight_decay, nesterov,
                      first, gscale);
   return addk_check_launch("sgd_step");
+}
+
+// table entries as addk_bn_apply_item (include/addk.h); every item must be vector-aligned (16-byte pointers, ld % 4 == 0,
+// C % 4 == 0, C <= 1024) with alpha = NULL and c1, c2 given
+extern "C" int addk_bn_bwd_apply_batch(const addk_bn_apply_item* dev_table, int32_t n, int64_t max_P, void* stream) {
+  ADDK_REQUIRE(dev_table && n > 0 && max_P > 0, "bn_bwd_apply_batch: bad args");
+  static_assert(sizeof(addk_bn_apply_item) == sizeof(BnApplyItem), "item layout");
+  long b = cdiv(max_P, 6); if (b > 2048) b = 2048; if (b < 1) b = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_batch_kernel, dim3((unsigned)b, n), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const BnApplyItem*>(dev_table));
+  return addk_check_launch("bn_bwd_apply_batch");
 }

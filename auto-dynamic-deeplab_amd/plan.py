@@ -98,12 +98,13 @@ class Act:
 class Cmd:
     """One kernel launch of a plan: fn(*args, stream).  `rd`/`wr` are the memory regions it reads / writes
     (keys from `_region`), used to schedule independent launches on parallel HIP streams."""
-    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag')
+    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag', 'payload')
 
     def __init__(self, name, fn, args, rd=(), wr=(), pin=False):
         self.name, self.fn, self.args = name, fn, list(args)
         self.rd, self.wr = [k for k in (_region(x) for x in rd) if k], [k for k in (_region(x) for x in wr) if k]
         self.stream, self.waits, self.event, self.pin, self.tag = 0, (), None, pin, ''
+        self.payload = None            # argument struct of a launch that has a table-driven batched form (level_batch)
 
     def __iter__(self):                # unpacks like the (name, fn, args) triple it replaces
         return iter((self.name, self.fn, self.args))
@@ -124,7 +125,9 @@ def _region(x):
     if isinstance(x, Buf):
         return (id(x), 0, 1 << 30)
     if isinstance(x, torch.Tensor):
-        return (x.untyped_storage().data_ptr(), 0, 1 << 30)
+        # byte interval inside the storage: views of one flat parameter / gradient buffer (train.TrainStep) are distinct regions
+        lo = x.storage_offset() * x.element_size()
+        return (x.untyped_storage().data_ptr(), lo, lo + max(1, x.numel()) * x.element_size())
     if isinstance(x, tuple):
         return x
     raise TypeError(type(x))
@@ -307,6 +310,9 @@ class Graph:
             tab = tab.to(self.device) if self.device.type == 'cuda' else tab.clone()
             self.keep.append(tab)
             self._pack_cmd.args[0], self._pack_cmd.args[1] = tab.data_ptr(), len(self._packs)
+        if self.training and self.want_grad and self.world is None and os.environ.get('ADDK_LEVEL_BATCH', '1') == '1':
+            self._level_batch(self.fwd)
+            self._level_batch(self.bwd)
         for lst in (self.fwd, self.bwd):
             for i, c in enumerate(lst):
                 if not isinstance(c, Cmd):           # commands appended as plain triples (e.g. collectives): pinned to the main stream
@@ -315,6 +321,57 @@ class Graph:
             for c in lst:
                 if c.event:
                     c.event = torch.cuda.Event()
+
+    _BATCHED = {'bn_finalize': ('addk_bn_finalize_batch', lambda p: p.C), 'bn_bwd': ('addk_bn_bwd_batch', lambda p: p.C),
+                'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P)}
+
+    def _level_batch(self, lst):
+        """Reorder a launch list by dependency LEVEL (longest path from the inputs) and merge the mutually independent
+        BatchNorm vector launches of one level into one table-driven launch each.  The cell DAG offers ~10 independent
+        branches per level, so the 312 finalize / 312 backward / 312 apply launches of a step — each a ~10 us latency
+        chain on the critical path — shrink to one launch per level.  Commands of one level never depend on each other,
+        so any order inside a level is valid; program order of the original list is kept."""
+        writers, readers, level = {}, {}, []
+        for i, c in enumerate(lst):
+            deps = set()
+            for k in c.rd:
+                deps.update(j for r, j in writers.get(k[0], ()) if _overlap(r, k))
+            for k in c.wr:
+                deps.update(j for r, j in writers.get(k[0], ()) if _overlap(r, k))
+                deps.update(j for r, j in readers.get(k[0], ()) if _overlap(r, k))
+            level.append(1 + max(level[j] for j in deps) if deps else 0)
+            for k in c.wr:
+                writers[k[0]] = [(r, j) for r, j in writers.get(k[0], ()) if not (r[1] >= k[1] and r[2] <= k[2])] + [(k, i)]
+                readers[k[0]] = [(r, j) for r, j in readers.get(k[0], ()) if not _overlap(r, k)]
+            for k in c.rd:
+                readers.setdefault(k[0], []).append((k, i))
+        buckets = collections.defaultdict(list)
+        for i, c in enumerate(lst):
+            buckets[level[i]].append(c)
+        out = []
+        for lv in sorted(buckets):
+            groups = collections.defaultdict(list)
+            for c in buckets[lv]:
+                if c.name in self._BATCHED and c.payload is not None:
+                    groups[c.name].append(c)
+                else:
+                    out.append(c)
+            for name, cs in groups.items():
+                if len(cs) == 1:
+                    out.append(cs[0])
+                    continue
+                fname, size_of = self._BATCHED[name]
+                n = len(cs)
+                arr = (type(cs[0].payload) * n)(*[c.payload for c in cs])
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
+                self.keep += [arr, tab]
+                m = Cmd(name + '_batch', getattr(self.lib, fname), (tab.data_ptr(), n, max(int(size_of(c.payload)) for c in cs)))
+                m.rd = [r for c in cs for r in c.rd]
+                m.wr = [r for c in cs for r in c.wr]
+                m.tag = cs[0].tag
+                out.append(m)
+        lst[:] = out
 
     def _hoist_pack(self, desc_fn, args, weight, wpk, create):
         """Move the weight pack of a halo-patch conv launch out of the launch: all packs of the plan (forward and data
@@ -630,9 +687,10 @@ class Graph:
             fa.eps = mod.eps
             fa.a, fa.b, fa.mean, fa.invstd = a.ptr, b.ptr, st.mean.ptr, st.invstd.ptr
             self.keep.append(fa)
-            self._add(self.fwd, 'bn_finalize', lib.addk_bn_finalize, C.byref(fa),
-                      rd=[red if sync else slab, mod.weight, mod.bias],
-                      wr=[a, b, st.mean, st.invstd] + ([mod.running_mean, mod.running_var] if fa.running_mean else []))
+            cfin = self._add(self.fwd, 'bn_finalize', lib.addk_bn_finalize, C.byref(fa),
+                             rd=[red if sync else slab, mod.weight, mod.bias],
+                             wr=[a, b, st.mean, st.invstd] + ([mod.running_mean, mod.running_var] if fa.running_mean else []))
+            cfin.payload = fa
         else:
             # inference: (a, b) of ALL BatchNorms come from one batched launch placed where the first one is emitted
             e = L.BnEvalEntry()
@@ -679,10 +737,15 @@ class Graph:
                               rd=[dmv], wr=[c1, c2])
                 else:
                     ba.c1, ba.c2 = c1.ptr, c2.ptr
-                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2])
+                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2]).payload = ba
                 # dy_raw = G + c1 + c2*x, in place on the accumulated gradient
-                self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, None, c1.ptr, c2.ptr,
-                          raw.P, Cc, g.ptr, g.ld, rd=[g, raw, c1, c2], wr=[g])
+                cap = self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, None, c1.ptr, c2.ptr,
+                                raw.P, Cc, g.ptr, g.ld, rd=[g, raw, c1, c2], wr=[g])
+                if Cc % 4 == 0 and Cc <= 1024 and g.ld % 4 == 0 and raw.ld % 4 == 0 and g.ptr % 16 == 0 and raw.ptr % 16 == 0:
+                    it = L.BnApplyItem()
+                    it.g, it.x, it.c1, it.c2, it.out, it.P = g.ptr, raw.ptr, c1.ptr, c2.ptr, g.ptr, raw.P
+                    it.ldg, it.ldx, it.ldo, it.C = g.ld, raw.ld, g.ld, Cc
+                    cap.payload = it
             self._bwd_emitters.append(emit_bwd)
         return act
 

@@ -208,6 +208,8 @@ typedef struct addk_bn_finalize_args {
   float* mean; float* invstd;    /* out: saved for backward */
 } addk_bn_finalize_args;
 int addk_bn_finalize(const addk_bn_finalize_args* a, void* stream);
+/* n independent BatchNorms in one launch; dev_table = device array of n argument structs, max_C = largest C among them */
+int addk_bn_finalize_batch(const addk_bn_finalize_args* dev_table, int32_t n, int32_t max_C, void* stream);
 
 /* sum the rows of a partial slab into out[C][2] (the vector that is all-reduced over RCCL) */
 int addk_slab_reduce(const double* partial, int32_t rows, int32_t C, double* out, void* stream);
@@ -235,6 +237,7 @@ typedef struct addk_bn_bwd_args {
   float* dmv;                    /* out [C][2] (dmean_tot, dvar) or NULL */
 } addk_bn_bwd_args;
 int addk_bn_bwd(const addk_bn_bwd_args* a, void* stream);
+int addk_bn_bwd_batch(const addk_bn_bwd_args* dev_table, int32_t n, int32_t max_C, void* stream);
 int addk_bn_bwd_coeffs_from_dmv(const float* dmv, int32_t C, double count, float* c1, float* c2, void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -266,6 +269,12 @@ int addk_ew_rows(int64_t P, int32_t C);
 int addk_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* alpha,
                       const float* c1, const float* c2, int64_t P, int32_t C, float* out, int32_t ldo,
                       void* stream);
+/* the same for n independent tensors in one launch (vector-aligned items only: 16-byte pointers, ld % 4 == 0, C % 4 == 0;
+ * alpha = 1): out[p,c] = g[p,c] + c1[c] + c2[c]*x[p,c] */
+typedef struct addk_bn_apply_item {
+  const float* g; const float* x; const float* c1; const float* c2; float* out; int64_t P; int32_t ldg, ldx, ldo, C;
+} addk_bn_apply_item;
+int addk_bn_bwd_apply_batch(const addk_bn_apply_item* dev_table, int32_t n, int64_t max_P, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=False, no antialias (F.interpolate call sites ADD.py:76-77,
