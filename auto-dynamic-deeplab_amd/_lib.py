@@ -108,6 +108,11 @@ _SIGS = {
     'addk_get_fast_paths': (i32, []),
     'addk_conv_fwd_pack_floats': (i64, [C.POINTER(ConvArgs)]),
     'addk_conv_dgrad_pack_floats': (i64, [C.POINTER(ConvDgradArgs)]),
+    'addk_conv_fwd_batch_key': (i32, [C.POINTER(ConvArgs)]),
+    'addk_conv_dgrad_batch_key': (i32, [C.POINTER(ConvDgradArgs)]),
+    'addk_conv_fwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),
+    'addk_conv_dgrad_batch_prepare': (i64, [vp, i32, vp, i64, vp]),
+    'addk_conv_batch_run': (i32, [vp, vp, vp]),
     'addk_conv_pack_desc_bytes': (i64, []),
     'addk_conv_fwd_pack_desc': (i32, [C.POINTER(ConvArgs), vp]),
     'addk_conv_dgrad_pack_desc': (i32, [C.POINTER(ConvDgradArgs), vp]),

@@ -26,7 +26,8 @@ struct PwK {
   const float* bias;
   double* slab; int slab_ld;
   addk_src dst; int accumulate;          // dgrad epilogue
-  int P; int ntiles16; int rows;       // rows: slab rows the caller allocated (>= gridDim.x; the extra rows are zero-filled)
+  int P; int ntiles16; int rows;       // rows: slab rows the caller allocated (>= gx; the extra rows are zero-filled)
+  int gx, gy;                          // grid of this launch (a batched launch runs several descriptors on one larger grid)
 };
 
 // These launches are latency chains (kernel arguments -> weight panel -> one or two pixel tiles -> store -> statistics)
@@ -35,8 +36,7 @@ struct PwK {
 // latency) and, for maps of >= 4096 pixels, per-lane statistics in fp32 (a lane sums at most a handful of values; the
 // cross-lane / cross-wave / cross-block sums stay fp64).
 template <int CT, int KG, int MODE, bool RED32>     // CT column tiles of 16, KG groups of 16 reduction channels
-__global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p) {
-  __shared__ double red[4][CT * 16][2];
+__device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.y * (CT * 16);
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s1[i][e] = 0; s2[i][e] = 0; }
 
-  const int wstride = gridDim.x * 4;
+  const int wstride = p.gx * 4;
   float4 xf[KG];
   auto load_tile = [&](int tile, float4 (&x)[KG]) {
     const int pp = tile * 16 + li;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p)
       double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
       o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
       o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
-      for (int r = blockIdx.x + gridDim.x; r < p.rows; r += gridDim.x) {     // rows no workgroup owns
+      for (int r = blockIdx.x + p.gx; r < p.rows; r += p.gx) {     // rows no workgroup owns
         double* z = p.slab + ((long)r * p.slab_ld + n0 + t) * 2;
         z[0] = 0.0; z[1] = 0.0;
       }
@@ -181,56 +181,155 @@ __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p)
   }
 }
 
+template <int CT, int KG, int MODE, bool RED32>
+__global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p) {
+  __shared__ double red[4][CT * 16][2];
+  pw_body<CT, KG, MODE, RED32>(p, red);
+}
+// several independent pointwise convs of one dependency level in ONE launch: block (x, y, z) runs descriptor z
+template <int CT, int KG, int MODE, bool RED32>
+__global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_batch_kernel(const PwK* __restrict__ tab) {
+  __shared__ double red[4][CT * 16][2];
+  const PwK p = tab[blockIdx.z];
+  if ((int)blockIdx.x >= p.gx || (int)blockIdx.y >= p.gy) return;
+  pw_body<CT, KG, MODE, RED32>(p, red);
+}
+
+struct PwCfg { int ct, kg, red32, gx, gy; };
+static bool pw_config(PwK& k, int rows, PwCfg& c) {
+  c.kg = cdiv(k.K, 16);
+  if (!(c.kg == 3 || c.kg == 5)) return false;
+  c.ct = c.kg == 5 ? 2 : 3;
+  if (cdiv(k.Cn, 16) < c.ct) c.ct = cdiv(k.Cn, 16);
+  if (c.ct < 1) c.ct = 1;
+  k.rows = rows;
+  c.gx = rows;
+  if (c.gx > cdiv(k.ntiles16, 4)) c.gx = cdiv(k.ntiles16, 4);
+  if (c.gx < 1) c.gx = 1;
+  c.gy = cdiv(k.Cn, 16 * c.ct);
+  c.red32 = k.P >= 4096;
+  k.gx = c.gx; k.gy = c.gy;
+  return true;
+}
+
 template <int MODE>
 int pw_launch(PwK& k, int rows, hipStream_t st) {
-  const int kg = cdiv(k.K, 16);
-  // up to 3 column tiles per block (K <= 80: <= 60 weight VGPRs)
-  int ct = kg == 5 ? (getenv("ADDK_PW_CT5") ? atoi(getenv("ADDK_PW_CT5")) : 2) : 3;      // K = 80: two column tiles keep the kernel spill-free at 3 waves / SIMD
-  if (cdiv(k.Cn, 16) < ct) ct = cdiv(k.Cn, 16);
-  if (ct < 1) ct = 1;
-  k.rows = rows;
-  int gx = rows;                           // measured: fewer, fatter workgroups are slower (14 -> 36 us); parallelism wins
-  if (gx > cdiv(k.ntiles16, 4)) gx = cdiv(k.ntiles16, 4);
-  if (gx < 1) gx = 1;
-  dim3 grid(gx, cdiv(k.Cn, 16 * ct));
-  const bool red32 = k.P >= 4096;
+  PwCfg c;
+  if (!pw_config(k, rows, c)) return 1;                  // no instantiation: caller falls back to the general kernel
+  dim3 grid(c.gx, c.gy);          // measured: fewer, fatter workgroups are slower (14 -> 36 us); parallelism wins
 #define ADDK_PW(CT_, KG_) \
-  if (ct == CT_ && kg == KG_) { \
-    if (red32) hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, k); \
+  if (c.ct == CT_ && c.kg == KG_) { \
+    if (c.red32) hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, k); \
     else hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, false>), grid, dim3(256), 0, st, k); \
     return addk_check_launch("pw_conv"); }
   ADDK_PW(1, 3) ADDK_PW(2, 3) ADDK_PW(3, 3)
-  ADDK_PW(1, 5) ADDK_PW(2, 5) ADDK_PW(3, 5)
+  ADDK_PW(1, 5) ADDK_PW(2, 5)
 #undef ADDK_PW
-  return 1;       // no instantiation: caller falls back to the general kernel
+  return 1;
 }
+
+template <int MODE>
+int pw_batch_launch(const PwK* tab, int n, int ct, int kg, int red32, int gx, int gy, hipStream_t st) {
+  dim3 grid(gx, gy, n);
+#define ADDK_PW(CT_, KG_) \
+  if (ct == CT_ && kg == KG_) { \
+    if (red32) hipLaunchKernelGGL((pw_batch_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, tab); \
+    else hipLaunchKernelGGL((pw_batch_kernel<CT_, KG_, MODE, false>), grid, dim3(256), 0, st, tab); \
+    return addk_check_launch("pw_conv_batch"); }
+  ADDK_PW(1, 3) ADDK_PW(2, 3) ADDK_PW(3, 3)
+  ADDK_PW(1, 5) ADDK_PW(2, 5)
+#undef ADDK_PW
+  addk_set_error("pw_batch: no instantiation");
+  return ADDK_ERR_UNSUPPORTED;
+}
+
+bool pw_fill_fwd(const addk_conv_args* a, PwK& k) {
+  if (a->nsrc != 1 || a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->bias_n) return false;
+  const addk_src& s = a->src[0];
+  const int kg = cdiv(s.C, 16);
+  if (!(kg == 3 || kg == 5) || !src_vec_ok(s) || !aligned16(a->y) || a->ldy % 4 || a->Cout % 4 || a->H != a->OH || a->W != a->OW) return false;
+  if (!aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return false;
+  k = PwK{};
+  k.src = s; k.K = s.C; k.Cn = a->Cout; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
+  k.y = a->y; k.ldy = a->ldy; k.bias = a->bias;
+  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.P = a->N * a->OH * a->OW; k.ntiles16 = cdiv(k.P, 16);
+  return true;
+}
+bool pw_fill_dgrad(const addk_conv_dgrad_args* a, PwK& k) {
+  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->H != a->OH || a->W != a->OW) return false;
+  const int kg = cdiv(a->Cout, 16);
+  addk_src dy{a->dy, nullptr, nullptr, a->lddy, a->Cout, 0, 0};
+  if (!(kg == 3 || kg == 5) || !src_vec_ok(dy) || !src_vec_ok(a->dst) || !aligned16(a->g) || a->ldg % 4) return false;
+  k = PwK{};
+  k.src = dy; k.K = a->Cout; k.Cn = a->dst.C; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
+  k.y = a->g; k.ldy = a->ldg; k.slab = (double*)a->dab; k.slab_ld = a->dst.C;
+  k.dst = a->dst; k.accumulate = a->accumulate;
+  k.P = a->N * a->H * a->W; k.ntiles16 = cdiv(k.P, 16);
+  return true;
+}
+inline int pw_key(const PwCfg& c, int mode) { return (mode << 12) | (c.ct << 8) | (c.kg << 4) | c.red32; }
 
 }  // namespace
 
 // Returns 0 when the launch was taken, 1 when the shape is not covered (caller falls back), <0 on error.
 int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream) {
-  if (a->nsrc != 1 || a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->bias_n) return 1;
-  const addk_src& s = a->src[0];
-  const int kg = cdiv(s.C, 16);
-  if (!(kg == 3 || kg == 5) || !src_vec_ok(s) || !aligned16(a->y) || a->ldy % 4 || a->Cout % 4 || a->H != a->OH || a->W != a->OW) return 1;
-  if (!aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return 1;
-  PwK k{};
-  k.src = s; k.K = s.C; k.Cn = a->Cout; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
-  k.y = a->y; k.ldy = a->ldy; k.bias = a->bias;
-  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
-  k.P = a->N * a->OH * a->OW; k.ntiles16 = cdiv(k.P, 16);
+  PwK k;
+  if (!pw_fill_fwd(a, k)) return 1;
   return pw_launch<PW_FWD>(k, rows, (hipStream_t)stream);
 }
-
 int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
-  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->H != a->OH || a->W != a->OW) return 1;
-  const int kg = cdiv(a->Cout, 16);
-  addk_src dy{a->dy, nullptr, nullptr, a->lddy, a->Cout, 0, 0};
-  if (!(kg == 3 || kg == 5) || !src_vec_ok(dy) || !src_vec_ok(a->dst) || !aligned16(a->g) || a->ldg % 4) return 1;
-  PwK k{};
-  k.src = dy; k.K = a->Cout; k.Cn = a->dst.C; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
-  k.y = a->g; k.ldy = a->ldg; k.slab = (double*)a->dab; k.slab_ld = a->dst.C;
-  k.dst = a->dst; k.accumulate = a->accumulate;
-  k.P = a->N * a->H * a->W; k.ntiles16 = cdiv(k.P, 16);
+  PwK k;
+  if (!pw_fill_dgrad(a, k)) return 1;
   return pw_launch<PW_DGRAD>(k, rows, (hipStream_t)stream);
+}
+
+// ---- batched form: mutually independent pointwise convs (one dependency level of the cell DAG) in one launch -------
+// key >= 0: the launch runs on pw_kernel with that template variant (launches with equal keys can share a batch); -1: not
+extern "C" int addk_conv_fwd_batch_key(const addk_conv_args* a) {
+  if (!a || addk_get_conv_precision() != 0 || !(addk_get_fast_paths() & ADDK_FAST_PW)) return -1;
+  PwK k; PwCfg c;
+  if (!pw_fill_fwd(a, k) || !pw_config(k, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), c)) return -1;
+  return pw_key(c, PW_FWD);
+}
+extern "C" int addk_conv_dgrad_batch_key(const addk_conv_dgrad_args* a) {
+  if (!a || addk_get_conv_precision() != 0 || !(addk_get_fast_paths() & ADDK_FAST_PW)) return -1;
+  PwK k; PwCfg c;
+  if (!pw_fill_dgrad(a, k) || !pw_config(k, addk_conv_rows((long)a->N * a->H * a->W, a->dst.C), c)) return -1;
+  return pw_key(c, PW_DGRAD);
+}
+// host_blob = NULL: returns the blob size in bytes.  meta[0..5] = key, n, gx, gy, reserved
+template <typename Args, typename Fill, typename Rows>
+static int64_t pw_batch_prepare(const Args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta, int mode, Fill fill, Rows rows_of) {
+  if (!a || n <= 0 || !meta) { addk_set_error("conv_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
+  const int64_t total = (int64_t)n * sizeof(PwK);
+  if (host_blob && blob_bytes < total) { addk_set_error("conv_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
+  int key0 = -1, gx = 0, gy = 0;
+  for (int i = 0; i < n; ++i) {
+    PwK k; PwCfg c;
+    if (!fill(&a[i], k) || !pw_config(k, rows_of(&a[i]), c)) { addk_set_error("conv_batch_prepare: launch %d is not a pointwise-kernel shape", i); return ADDK_ERR_INVALID; }
+    const int key = pw_key(c, mode);
+    if (i == 0) key0 = key;
+    if (key != key0) { addk_set_error("conv_batch_prepare: mixed kernel variants"); return ADDK_ERR_INVALID; }
+    if (c.gx > gx) gx = c.gx;
+    if (c.gy > gy) gy = c.gy;
+    if (host_blob) reinterpret_cast<PwK*>(host_blob)[i] = k;
+  }
+  meta[0] = key0; meta[1] = n; meta[2] = gx; meta[3] = gy;
+  return total;
+}
+extern "C" int64_t addk_conv_fwd_batch_prepare(const addk_conv_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  return pw_batch_prepare(a, n, host_blob, blob_bytes, meta, PW_FWD, pw_fill_fwd,
+                          [](const addk_conv_args* x) { return addk_conv_rows((long)x->N * x->OH * x->OW, x->Cout); });
+}
+extern "C" int64_t addk_conv_dgrad_batch_prepare(const addk_conv_dgrad_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  return pw_batch_prepare(a, n, host_blob, blob_bytes, meta, PW_DGRAD, pw_fill_dgrad,
+                          [](const addk_conv_dgrad_args* x) { return addk_conv_rows((long)x->N * x->H * x->W, x->dst.C); });
+}
+extern "C" int addk_conv_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
+  ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0 && meta[3] > 0, "conv_batch_run: bad args");
+  const int key = (int)meta[0], mode = key >> 12, ct = (key >> 8) & 15, kg = (key >> 4) & 15, red32 = key & 1;
+  const PwK* tab = reinterpret_cast<const PwK*>(dev_blob);
+  if (mode == PW_FWD) return pw_batch_launch<PW_FWD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
+  return pw_batch_launch<PW_DGRAD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
 }

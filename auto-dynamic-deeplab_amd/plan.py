@@ -98,13 +98,14 @@ class Act:
 class Cmd:
     """One kernel launch of a plan: fn(*args, stream).  `rd`/`wr` are the memory regions it reads / writes
     (keys from `_region`), used to schedule independent launches on parallel HIP streams."""
-    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag', 'payload')
+    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag', 'payload', 'bkey')
 
     def __init__(self, name, fn, args, rd=(), wr=(), pin=False):
         self.name, self.fn, self.args = name, fn, list(args)
         self.rd, self.wr = [k for k in (_region(x) for x in rd) if k], [k for k in (_region(x) for x in wr) if k]
         self.stream, self.waits, self.event, self.pin, self.tag = 0, (), None, pin, ''
         self.payload = None            # argument struct of a launch that has a table-driven batched form (level_batch)
+        self.bkey = 0                  # kernel-variant key: only launches with equal keys share a batch
 
     def __iter__(self):                # unpacks like the (name, fn, args) triple it replaces
         return iter((self.name, self.fn, self.args))
@@ -323,7 +324,8 @@ class Graph:
                     c.event = torch.cuda.Event()
 
     _BATCHED = {'bn_finalize': ('addk_bn_finalize_batch', lambda p: p.C), 'bn_bwd': ('addk_bn_bwd_batch', lambda p: p.C),
-                'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P)}
+                'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P),
+                'conv_fwd': ('addk_conv_fwd_batch_prepare', None), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', None)}
 
     def _level_batch(self, lst):
         """Reorder a launch list by dependency LEVEL (longest path from the inputs) and merge the mutually independent
@@ -353,20 +355,35 @@ class Graph:
             groups = collections.defaultdict(list)
             for c in buckets[lv]:
                 if c.name in self._BATCHED and c.payload is not None:
-                    groups[c.name].append(c)
+                    groups[(c.name, c.bkey)].append(c)
                 else:
                     out.append(c)
-            for name, cs in groups.items():
+            for (name, _), cs in groups.items():
                 if len(cs) == 1:
                     out.append(cs[0])
                     continue
                 fname, size_of = self._BATCHED[name]
                 n = len(cs)
                 arr = (type(cs[0].payload) * n)(*[c.payload for c in cs])
-                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-                tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
-                self.keep += [arr, tab]
-                m = Cmd(name + '_batch', getattr(self.lib, fname), (tab.data_ptr(), n, max(int(size_of(c.payload)) for c in cs)))
+                if size_of is None:            # pointwise convs: the library turns the argument structs into kernel descriptors
+                    prep = getattr(self.lib, fname)
+                    meta = (C.c_int64 * 8)()
+                    size = prep(arr, n, None, 0, meta)
+                    if size < 0:
+                        L.check(int(size), fname)
+                    blob = (C.c_uint8 * size)()
+                    rc = prep(arr, n, blob, size, meta)
+                    if rc < 0:
+                        L.check(int(rc), fname)
+                    host = torch.frombuffer(bytearray(bytes(blob)), dtype=torch.uint8)
+                    tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
+                    self.keep += [arr, tab, meta]
+                    m = Cmd(name + '_batch', self.lib.addk_conv_batch_run, (tab.data_ptr(), meta))
+                else:
+                    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                    tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
+                    self.keep += [arr, tab]
+                    m = Cmd(name + '_batch', getattr(self.lib, fname), (tab.data_ptr(), n, max(int(size_of(c.payload)) for c in cs)))
                 m.rd = [r for c in cs for r in c.rd]
                 m.wr = [r for c in cs for r in c.wr]
                 m.tag = cs[0].tag
@@ -566,8 +583,11 @@ class Graph:
             ar.wpack, ar.wpack_floats = wpk.ptr, npk
             self._hoist_pack(lib.addk_conv_fwd_pack_desc, ar, weight, wpk, create=True)
         self.keep.append(ar)
-        self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
-                  rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
+        cf = self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
+                       rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
+        bk = int(lib.addk_conv_fwd_batch_key(C.byref(ar)))
+        if bk >= 0:
+            cf.payload, cf.bkey = ar, bk
         self.meta.append(dict(kind='conv_fwd', idx=len(self.fwd) - 1, flops=2.0 * N * OH * OW * Cout * k * k * csum,
                               bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
                               shape=(N, H, W, csum, Cout, k, stride, dil), halo=npk > 0))
@@ -617,8 +637,11 @@ class Graph:
                             da.wpack, da.wpack_floats = dpk.ptr, npk
                             self._hoist_pack(lib.addk_conv_dgrad_pack_desc, da, weight, dpk, create=False)
                         self.keep.append(da)
-                        self._add(self.bwd, 'conv_dgrad', lib.addk_conv_dgrad, C.byref(da), rd=[dy, weight] + self.lz(s),
-                                  wr=[gs, slab, dpk])
+                        cd = self._add(self.bwd, 'conv_dgrad', lib.addk_conv_dgrad, C.byref(da), rd=[dy, weight] + self.lz(s),
+                                       wr=[gs, slab, dpk])
+                        bk = int(lib.addk_conv_dgrad_batch_key(C.byref(da)))
+                        if bk >= 0:
+                            cd.payload, cd.bkey = da, bk
                     choff += s.C
             self._bwd_emitters.append(emit_bwd)
         return out

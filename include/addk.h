@@ -135,6 +135,15 @@ int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a);
 /* Weight packs hoisted out of the step: fill one opaque descriptor (addk_conv_pack_desc_bytes() bytes, host memory) per
  * launch that has a wpack workspace, upload the array and run addk_conv_pack_batch once per step before the first
  * launch; those launches then set wpack_ready = 1. */
+/* Batched pointwise convolutions: mutually independent 1x1 launches (one dependency level of the cell DAG) that map to the
+ * same kernel variant run as ONE launch.  key >= 0 names the variant (-1: the launch is not covered); prepare() fills a
+ * host blob of kernel descriptors (host_blob = NULL: returns its size) and meta[4]; the caller uploads the blob once and
+ * replays addk_conv_batch_run.  Same arithmetic as the single launches. */
+int addk_conv_fwd_batch_key(const addk_conv_args* a);
+int addk_conv_dgrad_batch_key(const addk_conv_dgrad_args* a);
+int64_t addk_conv_fwd_batch_prepare(const addk_conv_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int64_t addk_conv_dgrad_batch_prepare(const addk_conv_dgrad_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int addk_conv_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 int64_t addk_conv_pack_desc_bytes(void);
 int addk_conv_fwd_pack_desc(const addk_conv_args* a, void* host_desc);
 int addk_conv_dgrad_pack_desc(const addk_conv_dgrad_args* a, void* host_desc);
