@@ -588,7 +588,7 @@ class Graph:
         bk = int(lib.addk_conv_fwd_batch_key(C.byref(ar)))
         if bk >= 0:
             cf.payload, cf.bkey = ar, bk
-        self.meta.append(dict(kind='conv_fwd', idx=len(self.fwd) - 1, flops=2.0 * N * OH * OW * Cout * k * k * csum,
+        self.meta.append(dict(kind='conv_fwd', cmd=cf, flops=2.0 * N * OH * OW * Cout * k * k * csum,
                               bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
                               shape=(N, H, W, csum, Cout, k, stride, dil), halo=npk > 0))
 

@@ -86,9 +86,10 @@ def _cpu_baseline_child(genotype, n, h, w):
             'sample': '1 step fwd+bwd+SGD, bs=%d %dx%d, torch-CPU oracle, %.1f s' % (n, h, w, dt)}
 
 
-def time_launch(g, idx, reps=20):
-    """Average device time of ONE launch of plan command `idx`, with HIP events on the launch stream."""
-    name, fn, args = g.fwd[idx]
+def time_launch(cmd, reps=20):
+    """Average device time of ONE launch of a plan command (the launch lists are re-ordered by dependency level after
+    emission, so the command object, not its index, identifies it), with HIP events on the launch stream."""
+    name, fn, args = cmd
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         fn(*args, st)
@@ -179,7 +180,7 @@ def main():
     # halo-patch kernel conv3_kernel (its weight-packing pre-pass, ~5 us, is inside the timed launch)
     convs = [m for m in ts.g.meta if m['kind'] == 'conv_fwd']
     top = max(convs, key=lambda m: m['flops'])
-    tk = time_launch(ts.g, top['idx'])
+    tk = time_launch(top['cmd'])
     fwd_flops = sum(m['flops'] for m in convs)
     # HBM-side traffic of that launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), which cannot run
     # inside this process: the committed measurement of the same kernel and shape is reported when present
