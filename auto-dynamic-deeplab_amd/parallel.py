@@ -27,12 +27,26 @@ class SyncBNComm:
         self.calls += 1
         return 0
 
+    def _allreduce_multi(self, ts, stream):
+        """The exchanges of several independent BatchNorms (one dependency level of the launch list) as ONE grouped RCCL
+        call (ncclGroupStart/End through torch's coalescing manager): one launch and one latency instead of len(ts)."""
+        if dist.get_backend(self.group) == 'nccl' and len(ts) > 1:
+            with dist._coalescing_manager(self.group, device=ts[0].device, async_ops=False):
+                for t in ts:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            for t in ts:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.calls += 1
+        return 0
+
     def emit_allreduce(self, g, lst, vec):
         """Append an all-reduce of `vec` (Vec) to command list `lst`.  Forward statistics are fp64 pairs."""
         t = vec.view()
         if lst is g.fwd:
             t = t.view(torch.float64)
-        g._add(lst, 'allreduce', self._allreduce, t, rd=[vec], wr=[vec], pin=True)     # RCCL call: main stream only
+        c = g._add(lst, 'allreduce', self._allreduce, t, rd=[vec], wr=[vec], pin=True)     # RCCL call: main stream only
+        c.payload = t
 
 
 def init_sync_bn(group=None, force=False):

@@ -311,7 +311,7 @@ class Graph:
             tab = tab.to(self.device) if self.device.type == 'cuda' else tab.clone()
             self.keep.append(tab)
             self._pack_cmd.args[0], self._pack_cmd.args[1] = tab.data_ptr(), len(self._packs)
-        if self.training and self.want_grad and self.world is None and os.environ.get('ADDK_LEVEL_BATCH', '1') == '1':
+        if self.training and self.want_grad and os.environ.get('ADDK_LEVEL_BATCH', '1') == '1':
             self._level_batch(self.fwd)
             self._level_batch(self.bwd)
         for lst in (self.fwd, self.bwd):
@@ -325,7 +325,8 @@ class Graph:
 
     _BATCHED = {'bn_finalize': ('addk_bn_finalize_batch', lambda p: p.C), 'bn_bwd': ('addk_bn_bwd_batch', lambda p: p.C),
                 'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P),
-                'conv_fwd': ('addk_conv_fwd_batch_prepare', None), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', None)}
+                'conv_fwd': ('addk_conv_fwd_batch_prepare', None), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', None),
+                'allreduce': (None, None)}
 
     def _level_batch(self, lst):
         """Reorder a launch list by dependency LEVEL (longest path from the inputs) and merge the mutually independent
@@ -364,6 +365,13 @@ class Graph:
                     continue
                 fname, size_of = self._BATCHED[name]
                 n = len(cs)
+                if name == 'allreduce':        # SyncBN exchanges of one level: one grouped RCCL call, pinned to the main stream
+                    m = Cmd('allreduce_multi', self.world._allreduce_multi, ([c.payload for c in cs],), pin=True)
+                    m.rd = [r for c in cs for r in c.rd]
+                    m.wr = [r for c in cs for r in c.wr]
+                    m.tag = cs[0].tag
+                    out.append(m)
+                    continue
                 arr = (type(cs[0].payload) * n)(*[c.payload for c in cs])
                 if size_of is None:            # pointwise convs: the library turns the argument structs into kernel descriptors
                     prep = getattr(self.lib, fname)

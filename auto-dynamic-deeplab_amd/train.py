@@ -83,7 +83,7 @@ class TrainStep:
             # two HIP streams: independent branches of the cell DAG overlap (-4 ms of 82 at config 2, eager or captured);
             # 3, 4 and 6 streams measure the same or slightly worse (68.5 / 68.7 / 69.8 / 69.7 ms).  The SyncBN path
             # keeps its collectives on one stream.
-            nstreams = int(os.environ.get('ADDK_STREAMS', '1' if has_coll else '2'))
+            nstreams = int(os.environ.get('ADDK_STREAMS', '2'))
         g.finalize(nstreams)
         self.nbt = NbtCounter(g.nbt)
         self.nbt.bump(); self.nbt.flat.sub_(self.nbt.inc)      # flatten now (pointers must be fixed before graph capture)

@@ -158,7 +158,8 @@ def test_syncbn_path_world1_matches_local_bn(dev):
             losses = [ts.step().item() for _ in range(2)]
             res[sync] = (l0, g0, losses, comm.calls if comm else 0)
             parallel.disable_sync_bn()
-        assert res[True][3] == 3 * 624                      # 312 forward + 312 backward exchanges per pass
+        # 312 forward + 312 backward exchanges per pass; those of one dependency level share a grouped RCCL call
+        assert 3 * 150 <= res[True][3] < 3 * 624
         assert abs(res[True][0] - res[False][0]) < 1e-6 * abs(res[False][0])           # forward: same statistics
         gs, gl = res[True][1].double(), res[False][1].double()
         assert float((gs - gl).norm() / gl.norm()) < 1e-3                                # backward: same gradient (rounding only)

@@ -59,10 +59,17 @@ def _syncbn_math(rank, world):
 
         def _add(self, lst, name, fn, *args, **kw):
             lst.append((name, fn, args))
+            import types
+            return types.SimpleNamespace()
     g = G()
     comm.emit_allreduce(g, g.fwd, Vec(buf, 0, 4 * C))
     for name, fn, args in cmds:
         assert fn(*args, 0) == 0
+    # the grouped form used for the BatchNorms of one dependency level (falls back to a loop on gloo)
+    t1, t2 = torch.full((3,), float(rank + 1)), torch.full((5,), 2.0 * (rank + 1), dtype=torch.float64)
+    assert comm._allreduce_multi([t1, t2], 0) == 0
+    tri = world * (world + 1) / 2
+    assert torch.equal(t1, torch.full((3,), tri)) and torch.equal(t2, torch.full((5,), 2.0 * tri, dtype=torch.float64))
     tot = buf.t.view(torch.float64).reshape(C, 2)
     count = float(world * 2 * 5 * 7)
     mean = tot[:, 0] / count
@@ -98,7 +105,7 @@ def _syncbn_math(rank, world):
 
 def test_syncbn_exchange_matches_global_batch_norm():
     for err_fwd, err_bwd, calls in _spawn(_syncbn_math):
-        assert err_fwd < 1e-9 and err_bwd < 1e-5 and calls == 2
+        assert err_fwd < 1e-9 and err_bwd < 1e-5 and calls == 3        # forward, grouped probe, backward
 
 
 def _grads_and_broadcast(rank, world):
@@ -136,9 +143,14 @@ def _plan_with_syncbn(rank, world):
     plan = next(iter(m._plans().values()))
     f = collections.Counter(n for n, _, _ in plan.g.fwd)
     b = collections.Counter(n for n, _, _ in plan.g.bwd)
-    return f['allreduce'], b['allreduce'], f['slab_reduce'], b['bn_bwd_coeffs'], len(outs)
+
+    def exchanged(lst):      # tensors exchanged: single all-reduces + members of the grouped (one-level) ones
+        return sum(1 for c in lst if c.name == 'allreduce') + sum(len(c.args[0]) for c in lst if c.name == 'allreduce_multi')
+    calls = f['allreduce'] + f['allreduce_multi'] + b['allreduce'] + b['allreduce_multi']
+    return exchanged(plan.g.fwd), exchanged(plan.g.bwd), f['slab_reduce'], b['bn_bwd_coeffs'], len(outs), calls
 
 
 def test_add_plan_emits_one_allreduce_per_batchnorm():
-    for fa, ba, sr, co, n in _spawn(_plan_with_syncbn):
+    for fa, ba, sr, co, n, calls in _spawn(_plan_with_syncbn):
         assert (fa, ba, sr, co, n) == (312, 312, 312, 312, 2)
+        assert calls < 400          # the exchanges of one dependency level share a grouped collective call
