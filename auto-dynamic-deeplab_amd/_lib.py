@@ -69,6 +69,14 @@ class BnBwdArgs(C.Structure):
                 ('accumulate', i32), ('c1', vp), ('c2', vp), ('dmv', vp)]
 
 
+class SlabReduceItem(C.Structure):
+    _fields_ = [('partial', vp), ('out', vp), ('rows', i32), ('C', i32)]
+
+
+class BnCoeffsItem(C.Structure):
+    _fields_ = [('dmv', vp), ('c1', vp), ('c2', vp), ('count', f64), ('C', i32), ('_pad', i32)]
+
+
 class BnApplyItem(C.Structure):
     _fields_ = [('g', vp), ('x', vp), ('c1', vp), ('c2', vp), ('out', vp), ('P', i64), ('ldg', i32), ('ldx', i32), ('ldo', i32),
                 ('C', i32)]
@@ -127,6 +135,8 @@ _SIGS = {
     'addk_dw_rows': (i32, [i64, i32]),
     'addk_dw_wreduce_batch': (i32, [vp, i32, vp]),
     'addk_bn_finalize_batch': (i32, [vp, i32, i32, vp]),
+    'addk_slab_reduce_batch': (i32, [vp, i32, i32, vp]),
+    'addk_bn_bwd_coeffs_batch': (i32, [vp, i32, i32, vp]),
     'addk_bn_bwd_batch': (i32, [vp, i32, i32, vp]),
     'addk_bn_bwd_apply_batch': (i32, [vp, i32, i64, vp]),
     'addk_bn_finalize': (i32, [C.POINTER(BnFinalizeArgs), vp]),

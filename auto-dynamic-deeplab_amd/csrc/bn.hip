@@ -142,6 +142,22 @@ __global__ void __launch_bounds__(1024) bn_bwd_batch_kernel(const addk_bn_bwd_ar
   bn_bwd_body(p, sh);
 }
 
+__global__ void __launch_bounds__(1024) slab_reduce_batch_kernel(const addk_slab_reduce_item* __restrict__ tab) {
+  __shared__ double sh[BN_RG][BN_CH][2];
+  const addk_slab_reduce_item it = tab[blockIdx.y];
+  if (blockIdx.x * BN_CH >= it.C) return;
+  const int cl = threadIdx.x % BN_CH, rg = threadIdx.x / BN_CH;
+  const int c = blockIdx.x * BN_CH + cl;
+  double s0, s1;
+  slab_sum(it.partial, it.rows, it.C, c, rg, s0, s1, sh);
+  if (rg == 0 && c < it.C) { it.out[2 * c] = s0; it.out[2 * c + 1] = s1; }
+}
+__global__ void bn_coeffs_batch_kernel(const addk_bn_coeffs_item* __restrict__ tab) {
+  const addk_bn_coeffs_item it = tab[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < it.C) { it.c1[c] = (float)((double)it.dmv[2 * c] / it.count); it.c2[c] = (float)(2.0 * (double)it.dmv[2 * c + 1] / it.count); }
+}
+
 __global__ void bn_coeffs_kernel(const float* dmv, int C, double count, float* c1, float* c2) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) { c1[c] = (float)((double)dmv[2 * c] / count); c2[c] = (float)(2.0 * (double)dmv[2 * c + 1] / count); }
@@ -199,4 +215,15 @@ extern "C" int addk_bn_bwd_batch(const addk_bn_bwd_args* dev_table, int32_t n, i
   ADDK_REQUIRE(dev_table && n > 0 && max_C > 0, "bn_bwd_batch: bad args");
   hipLaunchKernelGGL(bn_bwd_batch_kernel, dim3(cdiv(max_C, BN_CH), n), dim3(1024), 0, (hipStream_t)stream, dev_table);
   return addk_check_launch("bn_bwd_batch");
+}
+
+extern "C" int addk_slab_reduce_batch(const addk_slab_reduce_item* dev_table, int32_t n, int32_t max_C, void* stream) {
+  ADDK_REQUIRE(dev_table && n > 0 && max_C > 0, "slab_reduce_batch: bad args");
+  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(cdiv(max_C, BN_CH), n), dim3(1024), 0, (hipStream_t)stream, dev_table);
+  return addk_check_launch("slab_reduce_batch");
+}
+extern "C" int addk_bn_bwd_coeffs_batch(const addk_bn_coeffs_item* dev_table, int32_t n, int32_t max_C, void* stream) {
+  ADDK_REQUIRE(dev_table && n > 0 && max_C > 0, "bn_bwd_coeffs_batch: bad args");
+  hipLaunchKernelGGL(bn_coeffs_batch_kernel, dim3(cdiv(max_C, 256), n), dim3(256), 0, (hipStream_t)stream, dev_table);
+  return addk_check_launch("bn_bwd_coeffs_batch");
 }

@@ -325,6 +325,7 @@ class Graph:
 
     _BATCHED = {'bn_finalize': ('addk_bn_finalize_batch', lambda p: p.C), 'bn_bwd': ('addk_bn_bwd_batch', lambda p: p.C),
                 'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P),
+                'slab_reduce': ('addk_slab_reduce_batch', lambda p: p.C), 'bn_bwd_coeffs': ('addk_bn_bwd_coeffs_batch', lambda p: p.C),
                 'conv_fwd': ('addk_conv_fwd_batch_prepare', None), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', None),
                 'allreduce': (None, None)}
 
@@ -702,7 +703,9 @@ class Graph:
             fa = L.BnFinalizeArgs()
             if sync:
                 red = self.vec(4 * Cc)      # fp64 [C][2]
-                self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, red.ptr, rd=[slab], wr=[red])
+                sri = L.SlabReduceItem()
+                sri.partial, sri.out, sri.rows, sri.C = slab.ptr, red.ptr, rows, Cc
+                self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, red.ptr, rd=[slab], wr=[red]).payload = sri
                 self.world.emit_allreduce(self, self.fwd, red)    # every rank has the same per-rank count
                 fa.partial, fa.rows = red.ptr, 1
                 st.count = count * self.world.size
@@ -764,8 +767,10 @@ class Graph:
                     ba.dmv = dmv.ptr
                     self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [dmv])
                     self.world.emit_allreduce(self, self.bwd, dmv)
+                    cit = L.BnCoeffsItem()
+                    cit.dmv, cit.c1, cit.c2, cit.count, cit.C = dmv.ptr, c1.ptr, c2.ptr, st.count, Cc
                     self._add(self.bwd, 'bn_bwd_coeffs', lib.addk_bn_bwd_coeffs_from_dmv, dmv.ptr, Cc, st.count, c1.ptr, c2.ptr,
-                              rd=[dmv], wr=[c1, c2])
+                              rd=[dmv], wr=[c1, c2]).payload = cit
                 else:
                     ba.c1, ba.c2 = c1.ptr, c2.ptr
                     self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2]).payload = ba

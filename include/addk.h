@@ -222,6 +222,8 @@ int addk_bn_finalize_batch(const addk_bn_finalize_args* dev_table, int32_t n, in
 
 /* sum the rows of a partial slab into out[C][2] (the vector that is all-reduced over RCCL) */
 int addk_slab_reduce(const double* partial, int32_t rows, int32_t C, double* out, void* stream);
+typedef struct addk_slab_reduce_item { const double* partial; double* out; int32_t rows, C; } addk_slab_reduce_item;
+int addk_slab_reduce_batch(const addk_slab_reduce_item* dev_table, int32_t n, int32_t max_C, void* stream);
 
 /* eval mode: a = gamma/sqrt(running_var+eps), b = beta - running_mean*a */
 int addk_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -248,6 +250,8 @@ typedef struct addk_bn_bwd_args {
 int addk_bn_bwd(const addk_bn_bwd_args* a, void* stream);
 int addk_bn_bwd_batch(const addk_bn_bwd_args* dev_table, int32_t n, int32_t max_C, void* stream);
 int addk_bn_bwd_coeffs_from_dmv(const float* dmv, int32_t C, double count, float* c1, float* c2, void* stream);
+typedef struct addk_bn_coeffs_item { const float* dmv; float* c1; float* c2; double count; int32_t C, _pad; } addk_bn_coeffs_item;
+int addk_bn_bwd_coeffs_batch(const addk_bn_coeffs_item* dev_table, int32_t n, int32_t max_C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Elementwise "materialise" kernels.

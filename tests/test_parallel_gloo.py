@@ -147,7 +147,9 @@ def _plan_with_syncbn(rank, world):
     def exchanged(lst):      # tensors exchanged: single all-reduces + members of the grouped (one-level) ones
         return sum(1 for c in lst if c.name == 'allreduce') + sum(len(c.args[0]) for c in lst if c.name == 'allreduce_multi')
     calls = f['allreduce'] + f['allreduce_multi'] + b['allreduce'] + b['allreduce_multi']
-    return exchanged(plan.g.fwd), exchanged(plan.g.bwd), f['slab_reduce'], b['bn_bwd_coeffs'], len(outs), calls
+    def total(lst, name):
+        return sum(1 for c in lst if c.name == name) + sum(c.args[1] for c in lst if c.name == name + '_batch')
+    return exchanged(plan.g.fwd), exchanged(plan.g.bwd), total(plan.g.fwd, 'slab_reduce'), total(plan.g.bwd, 'bn_bwd_coeffs'), len(outs), calls
 
 
 def test_add_plan_emits_one_allreduce_per_batchnorm():
