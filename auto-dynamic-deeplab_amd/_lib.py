@@ -184,6 +184,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AddkError('libaddk.so not found at %s — run `python -c "import __graft_entry__ as g; g.build()"` '
                         '(hipcc --offload-arch=gfx950).  addk has no CPU fallback.' % LIB_PATH)
+    # libaddk.so needs libamdhip64.so.7; PyTorch bundles its own copy under the same soname.  Import torch FIRST so that the
+    # process has one HIP runtime (torch's): loaded the other way round, launches on torch's streams fail with
+    # hipErrorNoDevice ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
