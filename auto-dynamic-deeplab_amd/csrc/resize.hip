@@ -223,9 +223,34 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
         }
       } else {
         float4 dz = zero4();
+        // trim the conservative candidate ranges to the taps that really read this pixel (weights > 0 form one run)
+        while (hlo < hhi && tap_weight(hlo, ih, sh, p.H) == 0.f) ++hlo;
+        while (hhi > hlo && tap_weight(hhi, ih, sh, p.H) == 0.f) --hhi;
+        while (wlo < whi && tap_weight(wlo, iw, sw, p.W) == 0.f) ++wlo;
+        while (whi > wlo && tap_weight(whi, iw, sw, p.W) == 0.f) --whi;
         const int nh = hhi - hlo + 1, nw = whi - wlo + 1;
-        if (nh <= 8 && nw <= 8) {
-          // up to x2 up-sampling: per-axis weights in registers (static indexing), then at most 8x8 taps
+        if (nh <= 5 && nw <= 5 && p.vec && nrem >= 4) {
+          // up to x2 up-sampling: <= 5x5 taps, every load of a row unconditional (clamped column, zero weight) and independent
+          float ww5[5]; int wo5[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            ww5[k] = k < nw ? tap_weight(wlo + k, iw, sw, p.W) : 0.f;
+            wo5[k] = (k < nw ? wlo + k : wlo) * p.lddy;
+          }
+          for (int a = 0; a < nh; ++a) {
+            const float wh = tap_weight(hlo + a, ih, sh, p.H);
+            const float* rowp = p.dy + (long)(n * p.OH + hlo + a) * p.OW * p.lddy + c;
+            float4 d5[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) d5[b] = ld4(rowp + wo5[b]);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+              const float k = wh * ww5[b];
+              dz.x = fmaf(k, d5[b].x, dz.x); dz.y = fmaf(k, d5[b].y, dz.y); dz.z = fmaf(k, d5[b].z, dz.z); dz.w = fmaf(k, d5[b].w, dz.w);
+            }
+          }
+        } else if (nh <= 8 && nw <= 8) {
+          // per-axis weights in registers (static indexing), then at most 8x8 taps
           float wh8[8], ww8[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
