@@ -467,6 +467,163 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
     }
 }
 
+// Halo-patch weight gradient of the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5: 40/80/160 channels,
+// dilation <= 2).  Same staging as wgrad_h3_kernel — per 64-pixel row segment dy [64][16*CT] and the KS activation rows
+// [KS][64+(KS-1)d][16] go to LDS once and every tap reads its shifted window — but the accumulators are split the other
+// way round: all four waves use every output-channel tile and each owns a QUARTER OF THE TAPS (7 of 25, 3 of 9), so a
+// 40-channel conv keeps 3x7 = 21 accumulator tiles per wave with 83 % useful rows.  On the per-tap kernels these launches
+// re-read dy and the activation once per tap (25x) and were bound by L2 bandwidth.
+constexpr int HK_ZW = H3_KP + 4 * 2;       // widest patch row: 5x5, dilation 2
+
+template <int KS, int CT, bool BATCH>
+__global__ void __launch_bounds__(256, 2) wgrad_hk_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
+  if (BATCH) {
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK& p = BATCH ? ops[op] : pv;
+  constexpr int TAPS = KS * KS, TPW = (TAPS + 3) / 4, HK = KS / 2;
+  constexpr int BCO = 16 * CT, LY = BCO, YQ = BCO / 4;            // 48 and 80 are = 16 mod 32: conflict-free fragment reads
+  constexpr int NYJ = (H3_KP * YQ + 255) / 256;
+  constexpr int NZJ = (KS * HK_ZW * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Ys[H3_KP * LY];
+  __shared__ __attribute__((aligned(16))) float Zs[KS * HK_ZW * 16];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
+  const int co0 = yt * BCO, c0 = zt * 16;
+  const int d = p.dil, ZW = H3_KP + (KS - 1) * d;
+  const int spr = (p.OW + H3_KP - 1) / H3_KP;
+  const int nseg = p.N * p.OH * spr;
+  const int sbeg = blk_y * p.chunkP;
+  int send = sbeg + p.chunkP; if (send > nseg) send = nseg;
+
+  int yrow[NYJ], yqv[NYJ];
+#pragma unroll
+  for (int k = 0; k < NYJ; ++k) { const int slot = t + 256 * k; yrow[k] = slot / YQ; yqv[k] = slot - yrow[k] * YQ; }   // yrow >= 64: outside
+  const int zq = t & 3, zc = c0 + 4 * zq, nremz = p.src.C - zc;
+  int zr[NZJ], zj[NZJ];
+#pragma unroll
+  for (int k = 0; k < NZJ; ++k) {
+    const int pix = (t + 256 * k) >> 2;
+    zr[k] = pix / ZW; zj[k] = pix - zr[k] * ZW;         // zr >= KS marks a slot outside the patch
+  }
+  float4 za = make_float4(1.f, 1.f, 1.f, 1.f), zb = zero4();
+  if (p.src.a && nremz > 0) { za = ld4(p.src.a + zc); zb = ld4(p.src.b + zc); }
+  const bool zrelu = p.src.relu != 0;
+  int zbase[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    int tap = wave * TPW + j; if (tap > TAPS - 1) tap = TAPS - 1;      // surplus slots of the last wave recompute the last tap (discarded)
+    zbase[j] = (((tap / KS) * HK_ZW) + kq + (tap % KS) * d) * 16 + li;
+  }
+
+  f32x4 acc[CT][TPW];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ry[NYJ], rz[NZJ];
+  unsigned ymask = 0, zmask = 0;
+  auto load_step = [&](int seg) {
+    const int rowid = seg / spr, sx = seg - rowid * spr;
+    const int n = rowid / p.OH, oh = rowid - n * p.OH;
+    const int ow0 = sx * H3_KP;
+    const long pp0 = (long)rowid * p.OW + ow0;
+    ymask = 0; zmask = 0;
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      const int co = co0 + 4 * yqv[k];
+      const bool ok = yrow[k] < H3_KP && co < p.Cout && ow0 + yrow[k] < p.OW;
+      ry[k] = ld4(ok ? p.dy + (pp0 + yrow[k]) * p.lddy + co : p.dy);
+      ymask |= (ok ? 1u : 0u) << k;
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      const int ih = oh + (zr[k] - HK) * d, iw = ow0 - HK * d + zj[k];
+      const bool ok = zr[k] < KS && nremz > 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rz[k] = ld4(ok ? p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + zc : p.src.x);
+      zmask |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      float4 v = ry[k];
+      const bool ok = (ymask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (yrow[k] < H3_KP) st4(&Ys[yrow[k] * LY + 4 * yqv[k]], v);
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      float4 v = rz[k];
+      v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
+      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const bool ok = (zmask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (zr[k] < KS) st4(&Zs[(zr[k] * HK_ZW + zj[k]) * 16 + 4 * zq], v);
+    }
+  };
+
+  if (sbeg < send) {
+    load_step(sbeg);
+    store_step();
+    __syncthreads();
+    const float* yw = &Ys[kq * LY + li];
+    for (int seg = sbeg; seg < send; ++seg) {
+      const bool more = seg + 1 < send;
+      if (more) load_step(seg + 1);
+      float yfA[CT], zfA[TPW], yfB[CT], zfB[TPW];
+      auto rd = [&](int s4, float* yf, float* zf) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) yf[i] = yw[s4 * 4 * LY + i * 16];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) zf[j] = Zs[zbase[j] + s4 * 64];
+      };
+      auto mma = [&](const float* yf, const float* zf) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[i], zf[j], acc[i][j], 0, 0, 0);
+      };
+      rd(0, yfA, zfA);
+#pragma unroll
+      for (int s4 = 0; s4 < H3_KP / 4; s4 += 2) {
+        rd(s4 + 1, yfB, zfB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(yfA, zfA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s4 + 2 < H3_KP / 4) rd(s4 + 2, yfA, zfA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(yfB, zfB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      if (more) { store_step(); __syncthreads(); }
+    }
+  }
+  const int C = p.src.C;
+  float* wsb = p.ws + (long)blk_y * p.Cout * TAPS * C;
+  const int c = c0 + li;
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cow = co0 + i * 16 + kq * 4 + r;
+      if (cow < p.Cout && c < C) {
+        float* o = wsb + (long)cow * TAPS * C + c;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const int tap = wave * TPW + j;
+          if (tap < TAPS) o[tap * C] = acc[i][j][r];
+        }
+      }
+    }
+}
+
 // Register-streaming weight gradient for the narrow cell convolutions (Cout, C <= 160; 1x1, dilated k x k, strided):
 // no LDS staging and no barrier in the main loop.  A wave walks its own pixel range four pixels per MFMA k-step; lane
 // (li, kq) loads its slice of dy (pixel kq) and of the activation (tap-shifted pixel kq) straight from global memory and
@@ -718,7 +875,17 @@ inline int rs_tile(int Cn) {
   const int nt = cdiv(Cn, RS_T); return cdiv(cdiv(Cn, nt), 4) * 4;
 }
 inline int rs_lay(int tile) { return tile <= 48 ? 3 : 4; }
-int kind_of(const addk_conv_wgrad_args* a) { return h3_ok(a) ? 5 : rs_ok(a) ? 6 : os_kind(a->Cout, a->src.C); }
+// 7: halo-patch kernel with the taps split across waves (the cells' dilated 3x3 / 5x5 convolutions)
+// output-channel tiles per block: 3 for the 5x5 (7 taps per wave -> 21 accumulator tiles), up to 5 for the 3x3 (3 taps per wave)
+inline int hk_ct(int Cout, int ks) { return (ks == 5 || Cout <= 48) ? 3 : 5; }
+inline int hk_tiles(int Cout, int C, int ks) { return cdiv(Cout, 16 * hk_ct(Cout, ks)) * cdiv(C, 16); }
+bool hk_ok(const addk_conv_wgrad_args* a) {
+  return (addk_get_fast_paths() & ADDK_FAST_WGRAD_RS) && a->KH == a->KW && (a->KH == 3 || a->KH == 5) && a->stride == 1 &&
+         a->dil >= 1 && a->dil <= 2 && a->pad == a->dil * (a->KH / 2) && a->OH == a->H && a->OW == a->W &&
+         a->Cout >= 32 && a->Cout <= 160 && a->Cout % 4 == 0 && a->src.C >= 16 && a->OW >= 32 &&
+         aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) && (long)a->N * a->H * a->W >= 4096;
+}
+int kind_of(const addk_conv_wgrad_args* a) { return h3_ok(a) ? 5 : hk_ok(a) ? 7 : rs_ok(a) ? 6 : os_kind(a->Cout, a->src.C); }
 // Halo-patch scheduling.  A block runs `steps` row segments; blocks are dispatched in grid order as CU slots free up
 // (2 resident blocks per CU at NT=2, 3 at NT=1), so what matters is that the LAST round of blocks is nearly full:
 // pick the segment count per block that minimises  ceil(blocks / slots) * (steps + start-up)  over the whole launch.
@@ -766,6 +933,10 @@ extern "C" int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_
   int cty, ctz; pick_tiles(Cout, C, &cty, &ctz);
   int tiles = cdiv(Cout, 16 * cty) * taps * cdiv(C, 16 * ctz);
   int splits = pick_splits(P, tiles);
+  if ((taps == 9 || taps == 25) && Cout >= 32 && Cout <= 160 && C >= 16) {      // cells' dilated convs: wgrad_hk_kernel
+    const int hs = h3_max_splits(hk_tiles(Cout, C, taps == 9 ? 3 : 5));
+    if (hs > splits) splits = hs;
+  }
   if (taps == 9 && Cout % 64 == 0 && C >= 16) {      // the halo-patch kernel may be chosen
     const int hs = h3_max_splits(h3_tiles(Cout, C));
     if (hs > splits) splits = hs;
@@ -789,7 +960,7 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   k.P = a->N * a->OH * a->OW;
   tiles = k.nyt * k.taps * k.nzt;
   k.splits = pick_splits(k.P, tiles, budget, min_steps);
-  ADDK_REQUIRE(!check_ws || h3_ok(a) || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  ADDK_REQUIRE(!check_ws || h3_ok(a) || hk_ok(a) || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   k.chunkP = cdiv(cdiv(k.P, k.splits), KP) * KP;
   if (h3_ok(a)) {      // halo-patch kernel: pixel range in 64-pixel row segments, never more slices than the workspace bound
     const int nt = a->Cout % 128 == 0 ? 2 : 1;
@@ -804,6 +975,17 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   }
   k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
   k.vecZ = src_vec_ok(a->src);
+  if (!h3_ok(a) && hk_ok(a)) {      // halo-patch kernel, taps split across waves: 64-pixel row segments like wgrad_h3
+    const int ct = hk_ct(a->Cout, a->KH);
+    cty = ct; ctz = a->KH;
+    k.nyt = cdiv(a->Cout, 16 * ct); k.nzt = cdiv(a->src.C, 16);
+    tiles = k.nyt * k.nzt;
+    const long nseg = (long)a->N * a->OH * cdiv(a->OW, H3_KP);
+    if (h3_steps <= 0) { H3Op o{tiles, nseg}; h3_steps = h3_pick_steps(&o, 1, ct == 3 ? 1 : 2); }
+    k.splits = h3_splits(nseg, h3_steps, tiles);
+    k.chunkP = cdiv(nseg, k.splits);
+    ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  } else
   if (!h3_ok(a) && rs_ok(a)) {      // register-streaming kernel: <= 64-channel tiles, 2048-pixel chunks (128 k-steps per wave), vecY/vecZ carry the tile strides
     const int cap = pick_splits(k.P, tiles);
     k.vecY = rs_tile(a->Cout); k.vecZ = rs_tile(a->src.C);
@@ -829,6 +1011,13 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_OS(1, 4, 2) ADDK_OS(2, 3, 3) ADDK_OS(3, 2, 2) ADDK_OS(4, 4, 4)
 #undef ADDK_OS
+#define ADDK_HK(K_, C_) \
+  if (kind == 7 && ctz == K_ && cty == C_) { \
+    if (ops) hipLaunchKernelGGL((wgrad_hk_kernel<K_, C_, true>), grid, dim3(256), 0, st, k, ops, work); \
+    else hipLaunchKernelGGL((wgrad_hk_kernel<K_, C_, false>), grid, dim3(256), 0, st, k, ops, work); \
+    done = true; }
+  ADDK_HK(3, 3) ADDK_HK(3, 5) ADDK_HK(5, 3)
+#undef ADDK_HK
 #define ADDK_RS(A_, B_) \
   if (kind == 6 && cty == A_ && ctz == B_) { \
     if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true>), grid, dim3(256), 0, st, k, ops, work); \
@@ -893,6 +1082,12 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
   int budget = 8192 / n; if (budget < 32) budget = 32; if (budget > 1536) budget = 1536;
   const int min_steps = n >= 4 ? 8 : 1;
   int h3_steps = 0;
+  if (!h3_ok(&a[0]) && hk_ok(&a[0])) {
+    H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
+    for (int i = 0; i < n; ++i) { ho[i].tiles = hk_tiles(a[i].Cout, a[i].src.C, a[i].KH); ho[i].nseg = (long)a[i].N * a[i].OH * cdiv(a[i].OW, H3_KP); }
+    h3_steps = h3_pick_steps(ho, n, hk_ct(a[0].Cout, a[0].KH) == 3 ? 1 : 2);
+    free(ho);
+  }
   if (h3_ok(&a[0])) {
     H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
     const int nt = a[0].Cout % 128 == 0 ? 2 : 1;

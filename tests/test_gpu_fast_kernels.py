@@ -104,6 +104,8 @@ def _run(L, fast, shape, data):
         L.check(lib.addk_conv_wgrad_config(C.byref(wa), cfg), 'wgrad_config')
         if Ci >= 16 and ks == 3 and Cout % 64 == 0:
             assert (cfg[0] == 5) == bool(fast & 4), 'weight gradient: kernel kind %d with mask %d' % (cfg[0], fast)
+        elif Ci >= 16 and Cout <= 160 and dil <= 2:
+            assert (cfg[0] == 7) == bool(fast & 16), 'cell dilated conv: kernel kind %d with mask %d' % (cfg[0], fast)
         L.check(lib.addk_conv_wgrad(C.byref(wa), st), 'conv_wgrad')
         choff += Ci
     torch.cuda.synchronize()
