@@ -314,27 +314,47 @@ def test_add_whole_net(dev, golden, tag, Fv, arch):
             assert int(ba[n]) == int(b), n
 
 
-def test_add_whole_net_frozen_bn_gradients(dev):
+@pytest.mark.parametrize('Fv,hw', [(4, (65, 129)), (20, (512, 1024))], ids=['F4_65x129', 'F20_512x1024'])
+def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
     """Whole-network wiring of the backward pass (dense connections, shared heads, stems, low-level path) in a
     well-conditioned setting: BatchNorm frozen (model.eval(), running statistics) removes the small-batch
-    amplification, so conv-weight gradients can be held elementwise against the fp32 oracle."""
-    ma, mo, _ = _build_add(dev, 4, ARCH_C2)
+    amplification, so conv-weight gradients can be held elementwise against the fp32 oracle.  The 512x1024 case is the
+    one whose maps are large enough (>= 8192 pixels at the cell levels) to run the halo-patch, register-streaming and
+    LDS-tiled kernels inside the real network."""
+    ma, mo, _ = _build_add(dev, Fv, ARCH_C2)
     ma.eval(); mo.eval()
-    x = rand_tensor(61, 'frozen_x', (2, 3, 65, 129))
-    tgt = torch.from_numpy(np.random.default_rng(62).integers(0, 19, (2, 65, 129))).long()
+    x = rand_tensor(61, 'frozen_x', (2, 3) + hw)
+    tgt = torch.from_numpy(np.random.default_rng(62).integers(0, 19, (2,) + hw)).long()
     crit = nn.CrossEntropyLoss(ignore_index=255)
     ya = ma(x.to(dev)); yo = mo(x)
     (sum(crit(y, tgt.to(dev)) for y in ya) / 2).backward()
     (sum(crit(y, tgt) for y in yo) / 2).backward()
     torch.cuda.synchronize()
     pa = dict(ma.named_parameters())
+    big = hw[0] >= 512
+    if big:
+        # at 2 x 512 x 1024 the fp32 reference itself is 2e-4 (median) .. 3e-3 (first cell, stems) away from fp64 arithmetic
+        # (sums over 10^5-10^6 pixels through 12 cells): hold addk against the fp64 oracle, relative to the fp32 oracle's own error
+        m64 = oracle.ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(Fv), ARCH_C2['low_level_layer']).double()
+        m64.load_state_dict(mo.state_dict()); m64.eval()
+        (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
+        p64 = dict(m64.named_parameters())
     n = 0
+    ours, theirs = [], []
     for k, p in mo.named_parameters():
         if p.dim() == 4 and p.grad is not None:
             assert pa[k].grad is not None, k
-            _chk('frozen_bn/g:' + k, pa[k].grad, p.grad, 2e-3)
+            if big:
+                ours.append(_chk('frozen_bn%d/g:%s' % (hw[0], k), pa[k].grad.cpu().double(), p64[k].grad, 1e-2))
+                theirs.append(rel_err(p.grad.double(), p64[k].grad))
+            else:
+                _chk('frozen_bn%d/g:%s' % (hw[0], k), pa[k].grad, p.grad, 2e-3)
             n += 1
     assert n > 400
+    if big:
+        med = lambda v: sorted(v)[len(v) // 2]
+        REPORT.append('frozen_bn512 vs fp64: addk max %.2e median %.2e | fp32 oracle max %.2e median %.2e' % (max(ours), med(ours), max(theirs), med(theirs)))
+        assert max(ours) <= 3 * max(theirs) and med(ours) <= 3 * med(theirs)
 
 
 @pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])
