@@ -48,6 +48,8 @@ class DynamicPlan:
         self.x_static = torch.empty_like(x, dtype=torch.float32, memory_format=torch.contiguous_format)
         self.inref.bind(self.x_static)
         self.graphs = {}          # (begin, end) -> hipGraph of that launch-list segment
+        self.segs = {}            # (begin, end) -> that segment's launch list, level-ordered / batched / scheduled on two streams
+        g.nstreams = 2
         self.calls = 0
 
     def check_params(self):
@@ -60,15 +62,25 @@ class DynamicPlan:
         g = self.g
         if i1 < 0:
             i1 = len(g.fwd)
+        cmds = self.segs.get((i0, i1))
+        if cmds is None:          # every command belongs to exactly one segment: re-order and schedule the slice on its own
+            cmds = list(g.fwd[i0:i1])
+            if os.environ.get('ADDK_LEVEL_BATCH', '1') == '1':
+                g._level_batch(cmds)
+            _plan.schedule(cmds, g.nstreams)
+            for c in cmds:
+                if c.event:
+                    c.event = torch.cuda.Event()
+            self.segs[(i0, i1)] = cmds
         if self.calls < 3 or os.environ.get('ADDK_GRAPH_INFER', '1') != '1':
-            g.run(g.fwd[i0:i1], _plan.current_stream())
+            g.run_parallel(cmds, None)
             return
         gr = self.graphs.get((i0, i1))
         if gr is None:
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
-                g.run(g.fwd[i0:i1], _plan.current_stream())
+                g.run_parallel(cmds, None)
             self.graphs[(i0, i1)] = gr
         gr.replay()
 

@@ -69,7 +69,10 @@ class Plan:
                 self.outs.append(('out', r))
             else:
                 raise TypeError('emit returned %r' % type(r))
-        g.finalize()
+        # whole lists are always replayed front to back here: level-ordered, batched and on two streams like the fused train step
+        g.reorder = True
+        import os
+        g.finalize(int(os.environ.get('ADDK_STREAMS', '2')))
         self.params = list(g.params)
         self.param_ptrs = [p.data_ptr() for p in self.params]
         self.serial = 0
@@ -101,7 +104,7 @@ class Plan:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.g.run(self.g.fwd, _plan.current_stream())
+                self.g.run_parallel(self.g.fwd, None)
         for xs, x in zip(self.static_in, inputs):
             xs.copy_(x)
         self.graph.replay()
@@ -112,8 +115,7 @@ class Plan:
         if not self._forward_graphed(inputs):
             for r, x in zip(self.inrefs, inputs):
                 r.bind(x)
-            st = _plan.current_stream()
-            self.g.run(self.g.fwd, st)
+            self.g.run_parallel(self.g.fwd, None)
         self.nbt.bump()
         self.serial += 1
         outs = []
@@ -130,8 +132,7 @@ class Plan:
             if gy is None:
                 gy = torch.zeros_like(o.y)
             hold.append(o.set_grad(gy))
-        st = _plan.current_stream()
-        self.g.run(self.g.bwd, st)
+        self.g.run_parallel(self.g.bwd, None)
         gin = [r.grad for r in self.inrefs]
         # passthrough outputs route their gradient straight back to the input
         for (kind, o), gy in zip(self.outs, gouts):

@@ -311,7 +311,7 @@ class Graph:
             tab = tab.to(self.device) if self.device.type == 'cuda' else tab.clone()
             self.keep.append(tab)
             self._pack_cmd.args[0], self._pack_cmd.args[1] = tab.data_ptr(), len(self._packs)
-        if self.training and self.want_grad and os.environ.get('ADDK_LEVEL_BATCH', '1') == '1':
+        if ((self.training and self.want_grad) or getattr(self, 'reorder', False)) and os.environ.get('ADDK_LEVEL_BATCH', '1') == '1':
             self._level_batch(self.fwd)
             self._level_batch(self.bwd)
         for lst in (self.fwd, self.bwd):
@@ -504,6 +504,10 @@ class Graph:
         branches of the cell DAG overlap, which is what fills 256 CUs when single launches are small.  Works eagerly
         and under hipGraph capture (fork/join through events)."""
         ns = self.nstreams
+        if self.device.type != 'cuda':          # dry-run planning on CPU (tests): launches are stubbed
+            return self.run(cmds, current_stream())
+        if main is None:
+            main = torch.cuda.current_stream()
         if ns == 1:
             return self.run(cmds, main.cuda_stream)
         streams = [main] + self._side_streams()
