@@ -598,21 +598,44 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
     // for the four (row, column) parity classes.  One launch per class over that class's quarter of the pixels does
     // 9/4 tap-chunks per pixel instead of 9 masked ones; each class writes its own quarter of the (dA,dB) slab rows.
     const long Pfull = k.P;
-    for (int ph = 0; ph < 2; ++ph)
-      for (int pw = 0; pw < 2; ++pw) {
+    // classes that no tap reaches (3 of 4 for a 1x1 stride-2 conv: FactorizedReduce) have a zero gradient: they are only
+    // launched when the gradient buffer is being first-touched (to write the zeros), and the (dA,dB) slab rows are shared
+    // out among the classes that do have taps.
+    int ntl[4], tl[4][9], nvalid = 0;
+    for (int cl = 0; cl < 4; ++cl) {
+      const int ph = cl >> 1, pw = cl & 1;
+      ntl[cl] = 0;
+      for (int kh = 0; kh < a->KH; ++kh)
+        for (int kw = 0; kw < a->KW; ++kw)
+          if ((ph + a->pad - kh * a->dil) % 2 == 0 && (pw + a->pad - kw * a->dil) % 2 == 0) tl[cl][ntl[cl]++] = kh * a->KW + kw;
+      if (ntl[cl]) ++nvalid;
+    }
+    if (nvalid == 0 || rows % nvalid != 0) nvalid = 0;       // 0: fall back to a quarter of the rows per class, every class launched
+    int vi = 0;
+    for (int cl = 0; cl < 4; ++cl) {
+        const int ph = cl >> 1, pw = cl & 1;
         ConvK c = k;
         c.sub = 2; c.ph = ph; c.pw = pw;
         c.MH = (a->H - ph + 1) / 2; c.MW = (a->W - pw + 1) / 2;
         c.P = (long)a->N * c.MH * c.MW;
-        c.ntaps_l = 0;
-        for (int kh = 0; kh < a->KH; ++kh)
-          for (int kw = 0; kw < a->KW; ++kw)
-            if ((ph + a->pad - kh * a->dil) % 2 == 0 && (pw + a->pad - kw * a->dil) % 2 == 0) c.taplist[c.ntaps_l++] = kh * a->KW + kw;
-        if (c.ntaps_l == 0) { c.taplist[0] = 0; c.ntaps_l = 1; c.kill = 1; }
-        if (c.slab) c.slab = k.slab + (long)(ph * 2 + pw) * (rows / 4) * k.slab_ld * 2;
-        int rc = launch<MODE_DGRAD>(c, (hipStream_t)stream, rows / 4);
+        c.ntaps_l = ntl[cl];
+        for (int i = 0; i < ntl[cl]; ++i) c.taplist[i] = tl[cl][i];
+        int gx = rows / 4;
+        if (c.ntaps_l == 0) {
+          c.taplist[0] = 0; c.ntaps_l = 1; c.kill = 1;
+          if (nvalid) {
+            if (a->accumulate) continue;            // nothing to add
+            c.slab = nullptr;
+          }
+        } else if (nvalid) {
+          gx = rows / nvalid;
+          if (c.slab) c.slab = k.slab + (long)vi * gx * k.slab_ld * 2;
+          ++vi;
+        }
+        if (!nvalid && c.slab) c.slab = k.slab + (long)cl * (rows / 4) * k.slab_ld * 2;
+        int rc = launch<MODE_DGRAD>(c, (hipStream_t)stream, gx);
         if (rc) return rc;
-      }
+    }
     (void)Pfull;
     return ADDK_OK;
   }
