@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """BASELINE config 4: EDM-gated dynamic inference on one MI355X, bs=1, Cityscapes-shaped input.
-Reports per-exit forward latency (early exit / final exit), static all-exit forward latency and the CPU oracle beside it.
+Reports per-exit forward latency (early exit / final exit) and static all-exit forward latency (the CPU oracle's forward
+is timed by tests/tools/time_oracle_infer.py: only tests/ may touch oracle/).
     python scripts/bench_infer.py [--height 1024 --width 2048] [--reps 20]
 """
 import argparse, json, os, sys, time
@@ -13,7 +14,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--height', type=int, default=1024); ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--reps', type=int, default=20); ap.add_argument('--math', default='fp32')
-    ap.add_argument('--cpu', action='store_true', help='also time the CPU oracle forward (bs=1)')
     a = ap.parse_args()
     import addk
     from addk.modeling.ADD import ADD, EDM
@@ -44,13 +44,6 @@ def main():
         res['static_all_exits'] = {'ms_mean': 1e3 * (time.perf_counter() - t0) / a.reps}
     out = {'metric': 'per-exit forward ms, EDM-gated dynamic inference, bs=1', 'input': [1, 3, a.height, a.width], 'dtype': a.math,
            'results': res}
-    if a.cpu:
-        import oracle
-        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-        mo = oracle.ADD(NETWORK_ARCH, C_INDEX, g, 19, make_args(20), 0).eval()
-        xc = x.cpu()
-        with torch.no_grad():
-            mo(xc); t0 = time.perf_counter(); mo(xc); out['cpu_oracle_static_all_exits_ms'] = 1e3 * (time.perf_counter() - t0)
     print(json.dumps(out))
 
 if __name__ == '__main__':

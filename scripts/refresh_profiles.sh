@@ -14,7 +14,8 @@ cp $(ls gpurun_out/pt/*/*kernel_stats.csv | head -1) gpurun_out/step_kernel_stat
 rm -rf gpurun_out/pt
 timeout -k 10 200 python3 scripts/segment_roofline.py --mode eval > gpurun_out/segment_roofline_eval.json 2>/dev/null
 timeout -k 10 200 python3 scripts/segment_roofline.py --mode train > gpurun_out/segment_roofline_train.json 2>/dev/null
-timeout -k 10 300 python3 scripts/bench_infer.py --cpu > gpurun_out/infer_1024x2048.json 2>/dev/null
+timeout -k 10 300 python3 scripts/bench_infer.py > gpurun_out/infer_1024x2048.json 2>/dev/null
+timeout -k 10 300 python3 tests/tools/time_oracle_infer.py > gpurun_out/infer_cpu_oracle.json 2>/dev/null
 head -3 gpurun_out/step_last_step_summary.txt
 python3 -c "
 import json

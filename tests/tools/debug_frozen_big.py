@@ -1,6 +1,6 @@
 """Frozen-BN whole-network gradients at 512x1024 (F=20): ours vs the fp64 oracle, next to the fp32 oracle vs the fp64 oracle."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, 'tests')): sys.path.insert(0, p)
 import numpy as np, torch, torch.nn as nn
 import addk, oracle

@@ -1,6 +1,6 @@
 """Debug: whole-net training gradients — addk vs oracle(fp32) vs oracle(fp64)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch, torch.nn as nn
 import addk, oracle
