@@ -261,7 +261,7 @@ def test_add_whole_net(dev, golden, tag, Fv, arch):
         return
     # ---- training step.  Whole-network fp32 gradients are chaotic at these sizes: the REFERENCE arithmetic itself
     # (oracle fp32, same ATen kernels as the reference) sits 5-25 % from an fp64 evaluation of the same graph
-    # (ReLU-mask flips amplified through 12 cells of small-batch BatchNorm; scripts/debug_whole_net.py).  An
+    # (ReLU-mask flips amplified through 12 cells of small-batch BatchNorm; tests/tools/debug_whole_net.py).  An
     # elementwise 1e-3 bound against fp32 is therefore not a property the reference has; the bar here is that
     # the HIP path is as close to the fp64 truth as the reference's own fp32 path is (per-module gradients ARE
     # held to 1e-3 above, where the arithmetic is well conditioned).
