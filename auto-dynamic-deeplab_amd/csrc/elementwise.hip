@@ -91,21 +91,23 @@ __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
       }
     }
   }
+  // Block reduction over the pixel lanes through an [npl][C4][2] fp64 panel: one barrier, then one thread per (channel, A|B)
+  // adds the npl rows in fixed order (the former lane-after-lane accumulation cost npl barrier rounds per term).
+  const int C4 = p.nq * 4;
 #pragma unroll
   for (int i = 0; i < ADDK_MAX_TERMS; ++i) {
     if (i < p.nterm && p.dab[i]) {          // block-uniform
-      for (int r = 0; r < p.npl; ++r) {
-        if (active && pl == r) {
+      if (active) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            double* d = &redt[(c + e) * 2];
-            d[0] = (r == 0) ? sA[i][e] : d[0] + sA[i][e];
-            d[1] = (r == 0) ? sB[i][e] : d[1] + sB[i][e];
-          }
-        }
-        __syncthreads();
+        for (int e = 0; e < 4; ++e) { redt[((pl * C4) + c + e) * 2] = sA[i][e]; redt[((pl * C4) + c + e) * 2 + 1] = sB[i][e]; }
       }
-      for (int k = threadIdx.x; k < p.C * 2; k += 256) p.dab[i][(long)blockIdx.x * p.C * 2 + k] = redt[k];
+      __syncthreads();
+      for (int k = threadIdx.x; k < p.C * 2; k += 256) {
+        const int ch = k >> 1, ab = k & 1;
+        double acc = 0.0;
+        for (int r = 0; r < p.npl; ++r) acc += redt[((r * C4) + ch) * 2 + ab];
+        p.dab[i][(long)blockIdx.x * p.C * 2 + k] = acc;
+      }
       __syncthreads();
     }
   }
@@ -243,7 +245,7 @@ extern "C" int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stre
   }
   k.nterm = a->nterm; k.P = a->P; k.C = a->C; k.dout = a->dout; k.lddo = a->lddo; k.fout = a->out; k.ldfo = a->ldo; k.relu_out = a->relu_out;
   EwMap m = ew_map(a->C); k.nq = m.nq; k.npl = m.npl;
-  size_t sh = (size_t)m.nq * 4 * 2 * sizeof(double);
+  size_t sh = (size_t)m.npl * m.nq * 4 * 2 * sizeof(double);
   hipLaunchKernelGGL(affine_sum_bwd_kernel, dim3(ew_rows(a->P, a->C)), dim3(256), sh, (hipStream_t)stream, k);
   return addk_check_launch("affine_sum_bwd");
 }

@@ -303,18 +303,19 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
     }
   }
   if (!NCHW && p.dab) {
-    for (int r = 0; r < p.npl; ++r) {
-      if (active && pl == r) {
+    // [npl][C4][2] panel, one barrier, fixed-order column sums (see affine_sum_bwd_kernel)
+    const int C4 = p.nq * 4;
+    if (active) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          double* d = &redt[(c + e) * 2];
-          d[0] = (r == 0) ? sA[e] : d[0] + sA[e];
-          d[1] = (r == 0) ? sB[e] : d[1] + sB[e];
-        }
-      }
-      __syncthreads();
+      for (int e = 0; e < 4; ++e) { redt[((pl * C4) + c + e) * 2] = sA[e]; redt[((pl * C4) + c + e) * 2 + 1] = sB[e]; }
     }
-    for (int k = threadIdx.x; k < C * 2; k += 256) p.dab[(long)blockIdx.x * C * 2 + k] = redt[k];
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * 2; k += 256) {
+      const int ch = k >> 1, ab = k & 1;
+      double acc = 0.0;
+      for (int r = 0; r < p.npl; ++r) acc += redt[((r * C4) + ch) * 2 + ab];
+      p.dab[(long)blockIdx.x * C * 2 + k] = acc;
+    }
   }
 }
 
@@ -403,7 +404,7 @@ extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
     k.vec = aligned16(a->dy) && a->lddy % 4 == 0 && aligned16(a->g) && a->ldg % 4 == 0 && a->src.C % 4 == 0 &&
             (!a->src.x || src_vec_ok(a->src));
     int rows = rs_rows(k.P, a->src.C);
-    size_t sh = (size_t)m.nq * 4 * 2 * sizeof(double);
+    size_t sh = (size_t)m.npl * m.nq * 4 * 2 * sizeof(double);
     hipLaunchKernelGGL(resize_bwd_kernel<false>, dim3(rows), dim3(256), sh, st, k);
   }
   return addk_check_launch("resize_bwd");
