@@ -367,13 +367,29 @@ __global__ void __launch_bounds__(256) dw_wreduce_kernel(const float* ws, int ro
 
 // batched form: block b = (item, 4 weight elements); the items' tables live in device memory
 __global__ void __launch_bounds__(256) dw_wreduce_batch_kernel(const addk_dw_wreduce_item* __restrict__ items, int max_blocks_per_item) {
+  // 64 consecutive weight elements x 4 row groups per block: every load is a coalesced 256-byte row segment (lanes along the
+  // elements; the wave-per-element form strides its lanes over the rows, 64 cache lines per load), fixed-order combine in LDS
+  __shared__ float part[4][64];
   const addk_dw_wreduce_item it = items[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < it.n; i += max_blocks_per_item * 4) {
-    float s = 0.f;
-    for (int r = lane; r < it.rows; r += 64) s += it.ws[(long)r * it.n + i];
-    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
-    if (lane == 0) it.dw[i] = it.accumulate ? it.dw[i] + s : s;
+  const int e = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  for (int i0 = blockIdx.x * 64; i0 < it.n; i0 += max_blocks_per_item * 64) {
+    const int i = i0 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < it.n) {
+      int r = rg;
+      for (; r + 12 < it.rows; r += 16) {
+        s0 += it.ws[(long)r * it.n + i]; s1 += it.ws[(long)(r + 4) * it.n + i];
+        s2 += it.ws[(long)(r + 8) * it.n + i]; s3 += it.ws[(long)(r + 12) * it.n + i];
+      }
+      for (; r < it.rows; r += 4) s0 += it.ws[(long)r * it.n + i];
+    }
+    part[rg][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && i < it.n) {
+      const float s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+      it.dw[i] = it.accumulate ? it.dw[i] + s : s;
+    }
+    __syncthreads();
   }
 }
 
@@ -488,7 +504,7 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
 
 extern "C" int addk_dw_wreduce_batch(const addk_dw_wreduce_item* dev_items, int32_t n_items, void* stream) {
   ADDK_REQUIRE(dev_items && n_items > 0, "dw_wreduce_batch: bad args");
-  const int per = 256;          // blocks per item: 1024 weight elements per pass (C*taps <= 160*25 = 4000 -> 4 passes)
+  const int per = 64;           // blocks per item: 4096 weight elements per pass (C*taps <= 160*25 = 4000)
   hipLaunchKernelGGL(dw_wreduce_batch_kernel, dim3(per, n_items), dim3(256), 0, (hipStream_t)stream, dev_items, per);
   return addk_check_launch("dw_wreduce_batch");
 }

@@ -788,8 +788,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_wave_kernel(const float* ws,
   }
 }
 
-// batched reduce: rwork[b] = (op, first element, mode): mode 1 = one wave per element (4 per block), 0 = thread per element
+// batched reduce: rwork[b] = (op, first element, mode): mode 1 = many slices, few elements: 64 consecutive elements x 4 slice
+// groups per block (every load a coalesced 256-byte segment; fixed-order combine in LDS), 0 = thread per element
 __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const WgK* __restrict__ ops, const int4* __restrict__ rwork) {
+  __shared__ float part[4][64];
   const int4 wk = rwork[blockIdx.x];
   const WgK p = ops[wk.x];
   const int C = p.src.C;
@@ -797,13 +799,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const WgK* __re
   long i; float s;
   bool writer;
   if (wk.z) {
-    const int lane = threadIdx.x & 63;
-    i = (long)wk.y + (threadIdx.x >> 6);
-    if (i >= n) return;
-    s = 0.f;
-    for (int k = lane; k < p.splits; k += 64) s += p.ws[(long)k * n + i];
-    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
-    writer = lane == 0;
+    const int e = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    i = (long)wk.y + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int k = rg;
+      for (; k + 12 < p.splits; k += 16) {
+        s0 += p.ws[(long)k * n + i]; s1 += p.ws[(long)(k + 4) * n + i]; s2 += p.ws[(long)(k + 8) * n + i]; s3 += p.ws[(long)(k + 12) * n + i];
+      }
+      for (; k < p.splits; k += 4) s0 += p.ws[(long)k * n + i];
+    }
+    part[rg][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    writer = rg == 0 && i < n;
   } else {
     i = (long)wk.y + threadIdx.x;
     if (i >= n) return;
@@ -1108,7 +1117,7 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
     if (kind != kind0 || cty != cty0 || ctz != ctz0) { addk_set_error("wgrad_batch_prepare: mixed tile configurations"); return ADDK_ERR_INVALID; }
     nblocks += (long)tiles * k.splits;
     long ne = (long)a[i].Cout * k.taps * a[i].src.C;
-    nrblocks += (k.splits > 16 && ne <= 65536) ? cdiv(ne, 4) : cdiv(ne, 256);
+    nrblocks += (k.splits > 16 && ne <= 65536) ? cdiv(ne, 64) : cdiv(ne, 256);
   }
   const int64_t off_work = ((int64_t)n * sizeof(WgK) + 15) / 16 * 16;
   const int64_t off_rwork = off_work + nblocks * (int64_t)sizeof(int4);
@@ -1137,7 +1146,7 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
     for (int y = 0; y < ops[i].splits; ++y)
       for (int x = 0; x < tiles; ++x) work[b++] = make_int4(i, x, y, 0);
     long ne = (long)a[i].Cout * ops[i].taps * a[i].src.C;
-    if (ops[i].splits > 16 && ne <= 65536) { for (long e = 0; e < ne; e += 4) rwork[rb++] = make_int4(i, (int)e, 1, 0); }
+    if (ops[i].splits > 16 && ne <= 65536) { for (long e = 0; e < ne; e += 64) rwork[rb++] = make_int4(i, (int)e, 1, 0); }
     else { for (long e = 0; e < ne; e += 256) rwork[rb++] = make_int4(i, (int)e, 0, 0); }
   }
   return total;
