@@ -134,6 +134,11 @@ _SIGS = {
     'addk_dw_bwd': (i32, [C.POINTER(DwBwdArgs), vp]),
     'addk_dw_rows': (i32, [i64, i32]),
     'addk_dw_wreduce_batch': (i32, [vp, i32, vp]),
+    'addk_dw_fwd_batch_key': (i32, [C.POINTER(DwArgs)]),
+    'addk_dw_bwd_batch_key': (i32, [C.POINTER(DwBwdArgs)]),
+    'addk_dw_fwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),
+    'addk_dw_bwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),
+    'addk_dw_batch_run': (i32, [vp, vp, vp]),
     'addk_bn_finalize_batch': (i32, [vp, i32, i32, vp]),
     'addk_slab_reduce_batch': (i32, [vp, i32, i32, vp]),
     'addk_bn_bwd_coeffs_batch': (i32, [vp, i32, i32, vp]),

@@ -69,12 +69,13 @@ struct DwT {
   int nqb, ngrp;          // channel quads per block, channel groups
   int TH, PH, PW;         // output rows per tile, patch rows / columns
   int tiles_x, tiles_y;
+  int gx, ntiles, rows;   // grid.x of this launch, tiles (backward: walked with stride gx), workspace rows (backward)
+  unsigned shbytes;       // dynamic LDS bytes
 };
 constexpr int DW_TW = 16;
 
 template <int KS>
-__global__ void __launch_bounds__(256) dw_fwd_tile_kernel(const DwT t) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void dw_fwd_tile_body(const DwT& t, float* sm) {
   const DwK& p = t.k;
   const int C4b = t.nqb * 4;
   float* wl = sm;                              // [KS*KS][C4b]
@@ -134,6 +135,20 @@ __global__ void __launch_bounds__(256) dw_fwd_tile_kernel(const DwT t) {
       }
     st4(p.y + ((long)(n * p.OH + oh) * p.OW + ow) * p.ldy + c, acc);
   }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) dw_fwd_tile_kernel(const DwT t) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  dw_fwd_tile_body<KS>(t, sm);
+}
+// several independent depthwise convs of one dependency level in one launch: block (x, y, z) runs descriptor z
+template <int KS>
+__global__ void __launch_bounds__(256) dw_fwd_tile_batch_kernel(const DwT* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const DwT t = tab[blockIdx.z];
+  if ((int)blockIdx.x >= t.gx || (int)blockIdx.y >= t.ngrp) return;
+  dw_fwd_tile_body<KS>(t, sm);
 }
 
 // Backward, organised by INPUT pixel: for input pixel p and tap t the output pixel o(p,t) that read p
@@ -236,9 +251,9 @@ __global__ void __launch_bounds__(256) dw_bwd_kernel(const DwK p) {
 // every tap reads LDS; the weight-gradient and (dA,dB) sums stay in registers across all tiles of the block and are
 // reduced once, in the same fixed order as the kernel above.  Workspace rows beyond gridDim.x are zero-filled.
 template <int KS>
-__global__ void __launch_bounds__(256) dw_bwd_tile_kernel(const DwT t, int ntiles, int rows) {
+__device__ __forceinline__ void dw_bwd_tile_body(const DwT& t, float* sm) {
   constexpr int NT = KS * KS;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ntiles = t.ntiles, rows = t.rows, gxs = t.gx;
   const DwK& p = t.k;
   const int C4b = t.nqb * 4, C = p.src.C;
   float* wl = sm;                              // [NT][C4b]
@@ -260,7 +275,7 @@ __global__ void __launch_bounds__(256) dw_bwd_tile_kernel(const DwT t, int ntile
   for (int i = 0; i < NT; ++i) dwacc[i] = zero4();
   double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
   const int halo = (KS - 1) * p.dil;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gxs) {
     int b = tile;
     const int tx = b % t.tiles_x; b /= t.tiles_x;
     const int ty = b % t.tiles_y; const int n = b / t.tiles_y;
@@ -333,7 +348,7 @@ __global__ void __launch_bounds__(256) dw_bwd_tile_kernel(const DwT t, int ntile
       float sacc = 0.f;
       for (int r = 0; r < npl; ++r) sacc += redt[(u * npl + r) * C4b + ch];
       p.ws[((long)blockIdx.x * C + cg0 + ch) * NT + t0 + u] = sacc;
-      for (int rr = blockIdx.x + gridDim.x; rr < rows; rr += gridDim.x) p.ws[((long)rr * C + cg0 + ch) * NT + t0 + u] = 0.f;
+      for (int rr = blockIdx.x + gxs; rr < rows; rr += gxs) p.ws[((long)rr * C + cg0 + ch) * NT + t0 + u] = 0.f;
     }
   }
   if (p.dab) {
@@ -349,9 +364,22 @@ __global__ void __launch_bounds__(256) dw_bwd_tile_kernel(const DwT t, int ntile
       for (int r = 0; r < npl; ++r) { a += redd[(r * C4b + ch) * 2]; b2 += redd[(r * C4b + ch) * 2 + 1]; }
       p.dab[((long)blockIdx.x * C + cg0 + ch) * 2] = a;
       p.dab[((long)blockIdx.x * C + cg0 + ch) * 2 + 1] = b2;
-      for (int rr = blockIdx.x + gridDim.x; rr < rows; rr += gridDim.x) { p.dab[((long)rr * C + cg0 + ch) * 2] = 0.0; p.dab[((long)rr * C + cg0 + ch) * 2 + 1] = 0.0; }
+      for (int rr = blockIdx.x + gxs; rr < rows; rr += gxs) { p.dab[((long)rr * C + cg0 + ch) * 2] = 0.0; p.dab[((long)rr * C + cg0 + ch) * 2 + 1] = 0.0; }
     }
   }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) dw_bwd_tile_kernel(const DwT t) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  dw_bwd_tile_body<KS>(t, sm);
+}
+template <int KS>
+__global__ void __launch_bounds__(256) dw_bwd_tile_batch_kernel(const DwT* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const DwT t = tab[blockIdx.z];
+  if ((int)blockIdx.x >= t.gx || (int)blockIdx.y >= t.ngrp) return;
+  dw_bwd_tile_body<KS>(t, sm);
 }
 
 // one 64-lane wave per weight element: lanes stride over the partial rows, then a fixed-order butterfly
@@ -415,6 +443,51 @@ static int dw_fill(DwK& k, const addk_src& src, int N, int H, int W, int OH, int
   return 0;
 }
 
+
+// tile geometry of the LDS-tiled kernels; false: the launch is not covered (generic kernel)
+static bool dw_tile_fwd(const addk_dw_args* a, const DwK& k, DwT& t) {
+  if (!(k.vec && a->KH == a->KW && (a->KH == 3 || a->KH == 5) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) && k.P >= 2048)) return false;
+  t.k = k;
+  t.nqb = k.nq <= 10 ? k.nq : (k.nq % 10 == 0 ? 10 : 8);
+  t.ngrp = cdiv(k.nq, t.nqb);
+  const int span = (a->KH - 1) * a->dil + 1;
+  t.PW = (DW_TW - 1) * a->stride + span;
+  const long row_bytes = (long)t.PW * t.nqb * 16;
+  const int ph = (int)((48 * 1024) / row_bytes);                       // patch rows that fit the LDS budget
+  int th = (ph - span) / a->stride + 1;
+  if (th > 16) th = 16;
+  if (th > a->OH) th = a->OH;
+  if (th < 2) return false;
+  t.TH = th; t.PH = (th - 1) * a->stride + span;
+  t.tiles_x = cdiv(a->OW, DW_TW); t.tiles_y = cdiv(a->OH, th);
+  t.ntiles = a->N * t.tiles_y * t.tiles_x; t.gx = t.ntiles; t.rows = 0;
+  t.shbytes = (unsigned)(((size_t)a->KH * a->KW * t.nqb * 4 + (size_t)t.PH * t.PW * t.nqb * 4) * sizeof(float));
+  return true;
+}
+static bool dw_tile_bwd(const addk_dw_bwd_args* a, const DwK& k, int rows, DwT& t) {
+  if (!(k.vec && a->stride == 1 && a->KH == a->KW && (a->KH == 3 || a->KH == 5) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) && k.P >= 2048)) return false;
+  t.k = k;
+  t.nqb = k.nq <= 10 ? k.nq : (k.nq % 10 == 0 ? 10 : 8);
+  t.ngrp = cdiv(k.nq, t.nqb);
+  const int halo = (a->KH - 1) * a->dil, taps = a->KH * a->KW;
+  t.PW = DW_TW + halo;
+  const long row_bytes = (long)t.PW * t.nqb * 16;
+  int th = (int)((40 * 1024) / row_bytes) - halo;
+  if (th > 16) th = 16;
+  if (th > a->H) th = a->H;
+  if (th < 2) return false;
+  const int npl = 256 / t.nqb;
+  const size_t panel = (size_t)5 * npl * t.nqb * 4 * sizeof(float);          // [TG<=5][npl][C4b] floats >= [npl][C4b][2] doubles
+  t.TH = th; t.PH = th + halo;
+  t.tiles_x = cdiv(a->W, DW_TW); t.tiles_y = cdiv(a->H, th);
+  t.ntiles = a->N * t.tiles_y * t.tiles_x;
+  t.rows = rows; t.gx = t.ntiles < rows ? t.ntiles : rows;
+  size_t pbytes = (size_t)t.PH * t.PW * t.nqb * 16;
+  if (pbytes < panel) pbytes = panel;
+  t.shbytes = (unsigned)((size_t)taps * t.nqb * 16 + pbytes);
+  return true;
+}
+
 extern "C" int addk_dw_fwd(const addk_dw_args* a, void* stream) {
   ADDK_REQUIRE(a && a->w && a->y && a->ldy >= a->src.C, "dw_fwd: null/short output");
   DwK k{};
@@ -423,26 +496,12 @@ extern "C" int addk_dw_fwd(const addk_dw_args* a, void* stream) {
   k.w = a->w; k.y = a->y; k.ldy = a->ldy;
   k.P = (long)a->N * a->OH * a->OW;
   k.vec = src_vec_ok(a->src) && aligned16(a->y) && a->ldy % 4 == 0;
-  if (k.vec && a->KH == a->KW && (a->KH == 3 || a->KH == 5) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) && k.P >= 2048) {
-    DwT t; t.k = k;
-    t.nqb = k.nq <= 10 ? k.nq : (k.nq % 10 == 0 ? 10 : 8);
-    t.ngrp = cdiv(k.nq, t.nqb);
-    const int span = (a->KH - 1) * a->dil + 1;
-    t.PW = (DW_TW - 1) * a->stride + span;
-    const long row_bytes = (long)t.PW * t.nqb * 16;
-    int ph = (int)((48 * 1024) / row_bytes);                       // patch rows that fit the LDS budget
-    int th = (ph - span) / a->stride + 1;
-    if (th > 16) th = 16;
-    if (th > a->OH) th = a->OH;
-    if (th >= 2) {
-      t.TH = th; t.PH = (th - 1) * a->stride + span;
-      t.tiles_x = cdiv(a->OW, DW_TW); t.tiles_y = cdiv(a->OH, th);
-      const size_t shb = ((size_t)a->KH * a->KW * t.nqb * 4 + (size_t)t.PH * t.PW * t.nqb * 4) * sizeof(float);
-      dim3 grid((unsigned)(a->N * t.tiles_y * t.tiles_x), (unsigned)t.ngrp);
-      if (a->KH == 3) hipLaunchKernelGGL(dw_fwd_tile_kernel<3>, grid, dim3(256), shb, (hipStream_t)stream, t);
-      else            hipLaunchKernelGGL(dw_fwd_tile_kernel<5>, grid, dim3(256), shb, (hipStream_t)stream, t);
-      return addk_check_launch("dw_fwd_tile");
-    }
+  DwT t;
+  if (dw_tile_fwd(a, k, t)) {
+    dim3 grid((unsigned)t.gx, (unsigned)t.ngrp);
+    if (a->KH == 3) hipLaunchKernelGGL(dw_fwd_tile_kernel<3>, grid, dim3(256), t.shbytes, (hipStream_t)stream, t);
+    else            hipLaunchKernelGGL(dw_fwd_tile_kernel<5>, grid, dim3(256), t.shbytes, (hipStream_t)stream, t);
+    return addk_check_launch("dw_fwd_tile");
   }
   long blocks = cdiv(k.P, k.npl); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
   size_t sh = (size_t)a->KH * a->KW * k.nq * 4 * sizeof(float);
@@ -465,30 +524,12 @@ extern "C" int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream) {
   size_t sh = (size_t)(taps * C4 + k.npl * C4 * 5) * sizeof(float);     // tap weights + [TG<=5][npl][C4] reduction panel (>= the fp64 (dA,dB) panel)
   hipStream_t st = (hipStream_t)stream;
   bool tiled = false;
-  if (k.vec && a->stride == 1 && a->KH == a->KW && (a->KH == 3 || a->KH == 5) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) && k.P >= 2048) {
-    DwT t; t.k = k;
-    t.nqb = k.nq <= 10 ? k.nq : (k.nq % 10 == 0 ? 10 : 8);
-    t.ngrp = cdiv(k.nq, t.nqb);
-    const int halo = (a->KH - 1) * a->dil;
-    t.PW = DW_TW + halo;
-    const long row_bytes = (long)t.PW * t.nqb * 16;
-    int th = (int)((40 * 1024) / row_bytes) - halo;
-    if (th > 16) th = 16;
-    if (th > a->H) th = a->H;
-    const int npl = 256 / t.nqb;
-    const size_t panel = (size_t)5 * npl * t.nqb * 4 * sizeof(float);          // [TG<=5][npl][C4b] floats >= [npl][C4b][2] doubles
-    if (th >= 2) {
-      t.TH = th; t.PH = th + halo;
-      t.tiles_x = cdiv(a->W, DW_TW); t.tiles_y = cdiv(a->H, th);
-      const int ntiles = a->N * t.tiles_y * t.tiles_x;
-      size_t pbytes = (size_t)t.PH * t.PW * t.nqb * 16;
-      if (pbytes < panel) pbytes = panel;
-      const size_t shb = (size_t)taps * t.nqb * 16 + pbytes;
-      dim3 grid((unsigned)(ntiles < rows ? ntiles : rows), (unsigned)t.ngrp);
-      if (taps == 9) hipLaunchKernelGGL(dw_bwd_tile_kernel<3>, grid, dim3(256), shb, st, t, ntiles, rows);
-      else           hipLaunchKernelGGL(dw_bwd_tile_kernel<5>, grid, dim3(256), shb, st, t, ntiles, rows);
-      tiled = true;
-    }
+  DwT t;
+  if (dw_tile_bwd(a, k, rows, t)) {
+    dim3 grid((unsigned)t.gx, (unsigned)t.ngrp);
+    if (taps == 9) hipLaunchKernelGGL(dw_bwd_tile_kernel<3>, grid, dim3(256), t.shbytes, st, t);
+    else           hipLaunchKernelGGL(dw_bwd_tile_kernel<5>, grid, dim3(256), t.shbytes, st, t);
+    tiled = true;
   }
   if (tiled) {}
   else if (taps == 9) hipLaunchKernelGGL(dw_bwd_kernel<9>, dim3(rows), dim3(256), sh, st, k);
@@ -507,4 +548,75 @@ extern "C" int addk_dw_wreduce_batch(const addk_dw_wreduce_item* dev_items, int3
   const int per = 64;           // blocks per item: 4096 weight elements per pass (C*taps <= 160*25 = 4000)
   hipLaunchKernelGGL(dw_wreduce_batch_kernel, dim3(per, n_items), dim3(256), 0, (hipStream_t)stream, dev_items, per);
   return addk_check_launch("dw_wreduce_batch");
+}
+
+// ---- batched form of the LDS-tiled kernels: the independent depthwise convs of one dependency level in one launch --------
+static bool dw_fill_fwd_k(const addk_dw_args* a, DwK& k) {
+  if (!a || !a->w || !a->y || a->ldy < a->src.C) return false;
+  if (dw_fill(k, a->src, a->N, a->H, a->W, a->OH, a->OW, a->KH, a->KW, a->stride, a->pad, a->dil)) return false;
+  k.w = a->w; k.y = a->y; k.ldy = a->ldy;
+  k.P = (long)a->N * a->OH * a->OW;
+  k.vec = src_vec_ok(a->src) && aligned16(a->y) && a->ldy % 4 == 0;
+  return true;
+}
+static bool dw_fill_bwd_k(const addk_dw_bwd_args* a, DwK& k) {
+  if (!a || !a->dy || !a->w || !a->dw || !a->ws || a->lddy < a->src.C || (a->g && a->ldg < a->src.C)) return false;
+  if (dw_fill(k, a->src, a->N, a->H, a->W, a->OH, a->OW, a->KH, a->KW, a->stride, a->pad, a->dil)) return false;
+  k.w = a->w; k.dy = a->dy; k.lddy = a->lddy; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate;
+  k.dab = (double*)a->dab; k.ws = a->ws;
+  k.P = (long)a->N * a->H * a->W;
+  k.vec = src_vec_ok(a->src) && aligned16(a->dy) && a->lddy % 4 == 0 && (!a->g || (aligned16(a->g) && a->ldg % 4 == 0));
+  return true;
+}
+// key >= 0 (= kernel size | backward << 4): the launch runs on the tiled kernel and can share a batch with equal keys
+extern "C" int addk_dw_fwd_batch_key(const addk_dw_args* a) {
+  DwK k{}; DwT t;
+  return (dw_fill_fwd_k(a, k) && dw_tile_fwd(a, k, t)) ? a->KH : -1;
+}
+extern "C" int addk_dw_bwd_batch_key(const addk_dw_bwd_args* a) {
+  DwK k{}; DwT t;
+  if (!a || !a->defer_wreduce) return -1;               // the batched launch has no per-conv weight reduction
+  return (dw_fill_bwd_k(a, k) && dw_tile_bwd(a, k, dw_rows(k.P, a->src.C), t)) ? (a->KH | 16) : -1;
+}
+template <typename Args, typename Setup>
+static int64_t dw_batch_prepare(const Args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta, int bwd, Setup setup) {
+  if (!a || n <= 0 || !meta) { addk_set_error("dw_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
+  const int64_t total = (int64_t)n * sizeof(DwT);
+  if (host_blob && blob_bytes < total) { addk_set_error("dw_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
+  int ks = 0, gx = 0, gy = 0; unsigned sh = 0;
+  for (int i = 0; i < n; ++i) {
+    DwT t;
+    if (!setup(&a[i], t)) { addk_set_error("dw_batch_prepare: launch %d is not a tiled-kernel shape", i); return ADDK_ERR_INVALID; }
+    if (i == 0) ks = a[i].KH;
+    if (a[i].KH != ks) { addk_set_error("dw_batch_prepare: mixed kernel sizes"); return ADDK_ERR_INVALID; }
+    if (t.gx > gx) gx = t.gx;
+    if (t.ngrp > gy) gy = t.ngrp;
+    if (t.shbytes > sh) sh = t.shbytes;
+    if (host_blob) reinterpret_cast<DwT*>(host_blob)[i] = t;
+  }
+  meta[0] = ks | (bwd << 4); meta[1] = n; meta[2] = gx; meta[3] = gy; meta[4] = sh;
+  return total;
+}
+extern "C" int64_t addk_dw_fwd_batch_prepare(const addk_dw_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  return dw_batch_prepare(a, n, host_blob, blob_bytes, meta, 0, [](const addk_dw_args* x, DwT& t) { DwK k{}; return dw_fill_fwd_k(x, k) && dw_tile_fwd(x, k, t); });
+}
+extern "C" int64_t addk_dw_bwd_batch_prepare(const addk_dw_bwd_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  return dw_batch_prepare(a, n, host_blob, blob_bytes, meta, 1, [](const addk_dw_bwd_args* x, DwT& t) {
+    DwK k{}; return x->defer_wreduce && dw_fill_bwd_k(x, k) && dw_tile_bwd(x, k, dw_rows(k.P, x->src.C), t); });
+}
+extern "C" int addk_dw_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
+  ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0 && meta[3] > 0, "dw_batch_run: bad args");
+  const int ks = (int)meta[0] & 15, bwd = ((int)meta[0] >> 4) & 1;
+  const DwT* tab = reinterpret_cast<const DwT*>(dev_blob);
+  dim3 grid((unsigned)meta[2], (unsigned)meta[3], (unsigned)meta[1]);
+  const size_t sh = (size_t)meta[4];
+  hipStream_t st = (hipStream_t)stream;
+  if (!bwd) {
+    if (ks == 3) hipLaunchKernelGGL(dw_fwd_tile_batch_kernel<3>, grid, dim3(256), sh, st, tab);
+    else         hipLaunchKernelGGL(dw_fwd_tile_batch_kernel<5>, grid, dim3(256), sh, st, tab);
+  } else {
+    if (ks == 3) hipLaunchKernelGGL(dw_bwd_tile_batch_kernel<3>, grid, dim3(256), sh, st, tab);
+    else         hipLaunchKernelGGL(dw_bwd_tile_batch_kernel<5>, grid, dim3(256), sh, st, tab);
+  }
+  return addk_check_launch("dw_batch");
 }

@@ -326,7 +326,8 @@ class Graph:
     _BATCHED = {'bn_finalize': ('addk_bn_finalize_batch', lambda p: p.C), 'bn_bwd': ('addk_bn_bwd_batch', lambda p: p.C),
                 'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P),
                 'slab_reduce': ('addk_slab_reduce_batch', lambda p: p.C), 'bn_bwd_coeffs': ('addk_bn_bwd_coeffs_batch', lambda p: p.C),
-                'conv_fwd': ('addk_conv_fwd_batch_prepare', None), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', None),
+                'conv_fwd': ('addk_conv_fwd_batch_prepare', 'addk_conv_batch_run'), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', 'addk_conv_batch_run'),
+                'dw_fwd': ('addk_dw_fwd_batch_prepare', 'addk_dw_batch_run'), 'dw_bwd': ('addk_dw_bwd_batch_prepare', 'addk_dw_batch_run'),
                 'allreduce': (None, None)}
 
     def _level_batch(self, lst):
@@ -374,7 +375,7 @@ class Graph:
                     out.append(m)
                     continue
                 arr = (type(cs[0].payload) * n)(*[c.payload for c in cs])
-                if size_of is None:            # pointwise convs: the library turns the argument structs into kernel descriptors
+                if isinstance(size_of, str):   # pointwise / depthwise convs: the library turns the argument structs into kernel descriptors
                     prep = getattr(self.lib, fname)
                     meta = (C.c_int64 * 8)()
                     size = prep(arr, n, None, 0, meta)
@@ -387,7 +388,7 @@ class Graph:
                     host = torch.frombuffer(bytearray(bytes(blob)), dtype=torch.uint8)
                     tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
                     self.keep += [arr, tab, meta]
-                    m = Cmd(name + '_batch', self.lib.addk_conv_batch_run, (tab.data_ptr(), meta))
+                    m = Cmd(name + '_batch', getattr(self.lib, size_of), (tab.data_ptr(), meta))
                 else:
                     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
                     tab = host.to(self.device) if self.device.type == 'cuda' else host.clone()
@@ -819,7 +820,10 @@ class Graph:
         ar.N, ar.H, ar.W, ar.OH, ar.OW, ar.KH, ar.KW, ar.stride, ar.pad, ar.dil = N, H, W, OH, OW, k, k, stride, pad, dil
         ar.w, ar.y, ar.ldy = wptr, out.ptr, out.ld
         self.keep.append(ar)
-        self._add(self.fwd, 'dw_fwd', lib.addk_dw_fwd, C.byref(ar), rd=self.lz(src) + [conv_mod.weight], wr=[out])
+        cdw = self._add(self.fwd, 'dw_fwd', lib.addk_dw_fwd, C.byref(ar), rd=self.lz(src) + [conv_mod.weight], wr=[out])
+        bk = int(lib.addk_dw_fwd_batch_key(C.byref(ar)))
+        if bk >= 0:
+            cdw.payload, cdw.bkey = ar, bk
         act = Act(out, None, False, self.want_grad)
         if self.want_grad:
             def emit_bwd():
@@ -850,8 +854,11 @@ class Graph:
                 it.ws, it.dw, it.rows, it.n, it.accumulate = ws.ptr, gp, rows, Cc * k * k, acc
                 self._dwreds.append((it, ws, self.pgrad[conv_mod.weight]))
                 self.keep.append(ba)
-                self._add(self.bwd, 'dw_bwd', lib.addk_dw_bwd, C.byref(ba), rd=[dy, conv_mod.weight] + self.lz(src),
-                          wr=[gs, slab, ws])
+                cdb = self._add(self.bwd, 'dw_bwd', lib.addk_dw_bwd, C.byref(ba), rd=[dy, conv_mod.weight] + self.lz(src),
+                                wr=[gs, slab, ws])
+                bk = int(lib.addk_dw_bwd_batch_key(C.byref(ba)))
+                if bk >= 0:
+                    cdb.payload, cdb.bkey = ba, bk
             self._bwd_emitters.append(emit_bwd)
         return act
 

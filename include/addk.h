@@ -201,6 +201,14 @@ int addk_dw_bwd(const addk_dw_bwd_args* a, void* stream);
  * independent and only needed by the optimizer): table entry i reduces ws_i [rows_i][n_i] into dw_i [n_i]. */
 typedef struct addk_dw_wreduce_item { const float* ws; float* dw; int32_t rows, n, accumulate, _pad; } addk_dw_wreduce_item;
 int addk_dw_wreduce_batch(const addk_dw_wreduce_item* dev_items, int32_t n_items, void* stream);
+/* Batched depthwise launches (same scheme as addk_conv_*_batch_*): mutually independent depthwise convs of one dependency
+ * level that run on the LDS-tiled kernel of one size share ONE launch.  key >= 0 names the variant (-1: not covered; the
+ * backward form needs defer_wreduce = 1); prepare() fills the host blob of kernel descriptors and meta[5]. */
+int addk_dw_fwd_batch_key(const addk_dw_args* a);
+int addk_dw_bwd_batch_key(const addk_dw_bwd_args* a);
+int64_t addk_dw_fwd_batch_prepare(const addk_dw_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int64_t addk_dw_bwd_batch_prepare(const addk_dw_bwd_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int addk_dw_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 int addk_dw_rows(int64_t P, int32_t C);
 
 /* ---------------------------------------------------------------------------------------
