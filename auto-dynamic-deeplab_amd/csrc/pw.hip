@@ -195,6 +195,133 @@ __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_batch_kernel(const 
   pw_body<CT, KG, MODE, RED32>(p, red);
 }
 
+// Streaming-K pointwise forward for the 1x1 convs the register-stationary kernel does not take: many input channels
+// (the dense-connection preprocess convs, K = 200..800) and virtual concatenations (up to 12 sources).  Same lane
+// layout and arithmetic as pw_kernel, but the weight fragments are streamed per 16-channel group (every wave reads the
+// same panel: L1/L2 hits) instead of being held for the whole kernel, and the loads of group g+1 are in flight while the
+// 4*CT MFMAs of group g issue — no LDS, no barrier.  On the generic implicit-GEMM kernel these launches paid two
+// barriers and an exposed global-load round trip per 32 input channels for 16 MFMAs per wave (8 TF/s).
+struct PwkK {
+  addk_src src[ADDK_MAX_SRC]; int nsrc;
+  int Cn; const float* w; int ldw; int w_off;
+  float* y; int ldy; const float* bias;
+  double* slab; int slab_ld;
+  int P, ntiles16, rows, gx;
+};
+
+template <int CT, bool RED32>
+__global__ void __launch_bounds__(256, 3) pwk_kernel(const PwkK p) {
+  __shared__ double red[4][CT * 16][2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.y * (CT * 16);
+  typedef typename std::conditional<RED32, float, double>::type red_t;
+  red_t s1[CT][4], s2[CT][4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[i][e] = 0; s2[i][e] = 0; }
+  bool nok[CT]; const float* wrow[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int n = n0 + i * 16 + li;
+    nok[i] = n < p.Cn;
+    wrow[i] = p.w + (long)(nok[i] ? n : 0) * p.ldw + p.w_off;
+  }
+  const int wstride = p.gx * 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles16; tile += wstride) {
+    const int pp = tile * 16 + li;
+    const bool pok = pp < p.P;
+    f32x4 acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one group = 16 input channels of one source: x quad, prologue coefficients, CT weight quads
+    struct Grp { float4 x, a, b, w[CT]; bool ok, pro, relu; };
+    int s = 0, g = 0, choff = 0;
+    auto load = [&](Grp& G, int s_, int g_, int choff_) {
+      const addk_src S = p.src[s_];
+      const int k = 16 * g_ + 4 * kq;
+      const bool kok = k < S.C;
+      G.ok = kok && pok; G.pro = S.a != nullptr; G.relu = S.relu != 0;
+      G.x = ld4(S.x + (G.ok ? (long)pp * S.ld + k : 0));
+      G.a = make_float4(1.f, 1.f, 1.f, 1.f); G.b = zero4();
+      if (S.a) { G.a = ld4(S.a + (kok ? k : 0)); G.b = ld4(S.b + (kok ? k : 0)); }
+#pragma unroll
+      for (int i = 0; i < CT; ++i) G.w[i] = ld4(wrow[i] + (kok ? choff_ + k : 0));
+    };
+    auto advance = [&](int& s_, int& g_, int& choff_) {
+      ++g_;
+      if (16 * g_ >= p.src[s_].C) { choff_ += p.src[s_].C; g_ = 0; ++s_; }
+    };
+    auto compute = [&](const Grp& G) {
+      float4 v = G.x;
+      v.x = fmaf(G.a.x, v.x, G.b.x); v.y = fmaf(G.a.y, v.y, G.b.y); v.z = fmaf(G.a.z, v.z, G.b.z); v.w = fmaf(G.a.w, v.w, G.b.w);
+      if (G.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      v.x = G.ok ? v.x : 0.f; v.y = G.ok ? v.y : 0.f; v.z = G.ok ? v.z : 0.f; v.w = G.ok ? v.w : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          // masked k slots carry x = 0, rows beyond Cout are never stored: the weight operand needs no masking
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(G.w[i], e), get4(v, e), acc[i], 0, 0, 0);
+        }
+    };
+    Grp A, B;
+    load(A, s, g, choff);
+    while (true) {
+      int s2_ = s, g2 = g, c2 = choff;
+      advance(s2_, g2, c2);
+      const bool more = s2_ < p.nsrc;
+      if (more) load(B, s2_, g2, c2);
+      compute(A);
+      if (!more) break;
+      s = s2_; g = g2; choff = c2;
+      int s3 = s, g3 = g, c3 = choff;
+      advance(s3, g3, c3);
+      const bool more2 = s3 < p.nsrc;
+      if (more2) load(A, s3, g3, c3);
+      compute(B);
+      if (!more2) break;
+      s = s3; g = g3; choff = c3;
+    }
+    if (pok) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int c = n0 + i * 16 + kq * 4;
+        const int nrem = p.Cn - c;
+        if (nrem <= 0) continue;
+        float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        st4g(p.y + (long)pp * p.ldy + c, v, nrem, true);
+        if (p.slab) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const red_t f = e < nrem ? (red_t)get4(v, e) : (red_t)0; s1[i][e] += f; s2[i][e] += f * f; }
+        }
+      }
+    }
+  }
+  if (p.slab) {
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red_t a = s1[i][e], b = s2[i][e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = (double)a; red[wave][i * 16 + kq * 4 + e][1] = (double)b; }
+      }
+    __syncthreads();
+    if (t < CT * 16 && n0 + t < p.Cn) {
+      double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+      o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
+      o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
+      for (int r = blockIdx.x + p.gx; r < p.rows; r += p.gx) {
+        double* z = p.slab + ((long)r * p.slab_ld + n0 + t) * 2;
+        z[0] = 0.0; z[1] = 0.0;
+      }
+    }
+  }
+}
+
 struct PwCfg { int ct, kg, red32, gx, gy; };
 static bool pw_config(PwK& k, int rows, PwCfg& c) {
   c.kg = cdiv(k.K, 16);
@@ -273,10 +400,41 @@ inline int pw_key(const PwCfg& c, int mode) { return (mode << 12) | (c.ct << 8) 
 }  // namespace
 
 // Returns 0 when the launch was taken, 1 when the shape is not covered (caller falls back), <0 on error.
+static int pwk_try_fwd(const addk_conv_args* a, int rows, hipStream_t st) {
+  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->bias_n || a->H != a->OH || a->W != a->OW) return 1;
+  if (!aligned16(a->y) || a->ldy % 4 || a->Cout % 4 || !aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return 1;
+  int ktot = 0;
+  for (int i = 0; i < a->nsrc; ++i) { if (!src_vec_ok(a->src[i])) return 1; ktot += a->src[i].C; }
+  // narrow outputs only: with 256 output channels (ASPP 1x1 1280->256) every wave would stream the whole 1.3 MB weight panel
+  // and the LDS-staged kernel's operand reuse wins (63 vs 42 TF/s)
+  if (ktot < 64 || a->Cout > 160 || (long)a->N * a->OH * a->OW < 1024) return 1;
+  PwkK k{};
+  for (int i = 0; i < a->nsrc; ++i) k.src[i] = a->src[i];
+  k.nsrc = a->nsrc; k.Cn = a->Cout; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
+  k.y = a->y; k.ldy = a->ldy; k.bias = a->bias;
+  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.P = a->N * a->OH * a->OW; k.ntiles16 = cdiv(k.P, 16); k.rows = rows;
+  int ct = cdiv(a->Cout, 16); if (ct > 3) ct = 3;
+  k.gx = rows; if (k.gx > cdiv(k.ntiles16, 4)) k.gx = cdiv(k.ntiles16, 4); if (k.gx < 1) k.gx = 1;
+  dim3 grid(k.gx, cdiv(a->Cout, 16 * ct));
+  const bool red32 = k.P >= 4096;
+#define ADDK_PWK(CT_) \
+  if (ct == CT_) { \
+    if (red32) hipLaunchKernelGGL((pwk_kernel<CT_, true>), grid, dim3(256), 0, st, k); \
+    else hipLaunchKernelGGL((pwk_kernel<CT_, false>), grid, dim3(256), 0, st, k); \
+    return addk_check_launch("pwk_conv"); }
+  ADDK_PWK(1) ADDK_PWK(2) ADDK_PWK(3)
+#undef ADDK_PWK
+  return 1;
+}
+
 int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream) {
   PwK k;
-  if (!pw_fill_fwd(a, k)) return 1;
-  return pw_launch<PW_FWD>(k, rows, (hipStream_t)stream);
+  if (pw_fill_fwd(a, k)) {
+    const int r = pw_launch<PW_FWD>(k, rows, (hipStream_t)stream);
+    if (r <= 0) return r;
+  }
+  return pwk_try_fwd(a, rows, (hipStream_t)stream);       // many input channels / several sources: streaming-K kernel
 }
 int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
   PwK k;

@@ -57,6 +57,8 @@ int main(int argc, char** argv) {
     {"cell 1x1 160->160 @32x64", 2, 32, 64, 160, 160, 1, 1},
     {"cell 1x1 200->40 @125x253", 2, 125, 253, 200, 40, 1, 1},
     {"cell 5x5 40->40 @125x253", 2, 125, 253, 40, 40, 5, 1},
+    {"glue 1x1 400->80 @63x127", 2, 63, 127, 400, 80, 1, 1},
+    {"glue 1x1 800->160 @32x64", 2, 32, 64, 800, 160, 1, 1},
   };
   const char* only = getenv("SHAPES");
   int reps = argc > 1 ? atoi(argv[1]) : 20;
