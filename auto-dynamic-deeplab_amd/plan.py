@@ -185,7 +185,7 @@ def schedule(cmds, nstreams):
         tail[st] = i
         for k in c.wr:
             writers[k[0]] = [(r, j) for r, j in writers.get(k[0], ()) if not (r[1] >= k[1] and r[2] <= k[2])] + [(k, i)]
-            readers[k[0]] = [(r, j) for r, j in readers.get(k[0], ()) if not _overlap(r, k)]
+            readers[k[0]] = [(r, j) for r, j in readers.get(k[0], ()) if not (r[1] >= k[1] and r[2] <= k[2])]   # only readers this write fully covers are implied by it
         for k in c.rd:
             readers.setdefault(k[0], []).append((k, i))
     need = set(j for c in cmds for j in c.waits)
@@ -347,7 +347,7 @@ class Graph:
             level.append(1 + max(level[j] for j in deps) if deps else 0)
             for k in c.wr:
                 writers[k[0]] = [(r, j) for r, j in writers.get(k[0], ()) if not (r[1] >= k[1] and r[2] <= k[2])] + [(k, i)]
-                readers[k[0]] = [(r, j) for r, j in readers.get(k[0], ()) if not _overlap(r, k)]
+                readers[k[0]] = [(r, j) for r, j in readers.get(k[0], ()) if not (r[1] >= k[1] and r[2] <= k[2])]   # only readers this write fully covers are implied by it
             for k in c.rd:
                 readers.setdefault(k[0], []).append((k, i))
         buckets = collections.defaultdict(list)

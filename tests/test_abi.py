@@ -35,7 +35,9 @@ def test_struct_layouts_match_header():
                'addk_conv_wgrad_args': L.ConvWgradArgs, 'addk_dw_args': L.DwArgs, 'addk_dw_bwd_args': L.DwBwdArgs,
                'addk_bn_finalize_args': L.BnFinalizeArgs, 'addk_bn_bwd_args': L.BnBwdArgs,
                'addk_affine_sum_args': L.AffineSumArgs, 'addk_affine_sum_bwd_args': L.AffineSumBwdArgs,
-               'addk_resize_args': L.ResizeArgs, 'addk_resize_bwd_args': L.ResizeBwdArgs}
+               'addk_resize_args': L.ResizeArgs, 'addk_resize_bwd_args': L.ResizeBwdArgs,
+               'addk_dw_wreduce_item': L.DwWreduceItem, 'addk_bn_apply_item': L.BnApplyItem,
+               'addk_slab_reduce_item': L.SlabReduceItem, 'addk_bn_coeffs_item': L.BnCoeffsItem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "addk.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
