@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
   constexpr int TAPS = KS * KS, HK = KS / 2;
   constexpr int C3_PWMAX = c3_pwmax(KS);
   constexpr int C3_NS = (KS * C3_PWMAX * 4 + 255) / 256;   // 16-byte patch slots per thread
-  constexpr int WC = BCT == 8 ? 2 : 1;      // waves across output channels
+  constexpr int WC = (BCT == 8 || BCT == 4) ? 2 : 1;      // waves across output channels
   constexpr int WP = 4 / WC;                // waves across pixels
   constexpr int PT = 8 / WP;                // 16-pixel tiles per wave
   constexpr int CT = BCT / WC;              // 16-channel tiles per wave
