@@ -146,8 +146,7 @@ def schedule(cmds, nstreams):
     writers, readers = {}, {}            # buffer id -> [(region, idx)]
     tail = [-1] * nstreams               # index of the last command on each stream
     # vector clocks: clock[i][t] = latest command of stream t known to have completed before command i starts.  A wait
-    # that a previous wait already implies TRANSITIVELY (A -> B -> C and A -> C) is dropped: besides being useless,
-    # such redundant edges crash hipStreamEndCapture on ROCm 7.2 once three or more streams are captured.
+    # that a previous wait already implies TRANSITIVELY (A -> B -> C and A -> C) is dropped (fewer event edges in the graph).
     clock = []
     for i, c in enumerate(cmds):
         deps = set()
