@@ -454,8 +454,19 @@ class Graph:
                 waves.append((groups, used))
             used.append(region)
             groups.setdefault(key, []).append((wa, rd, grad))
+        nchunk = int(os.environ.get('ADDK_WGRAD_CHUNKS', '3'))
         for groups, _ in waves:
+            split = {}
             for key, items in groups.items():
+                # big groups (the cells' 1x1 / dilated convs: ~100-300 ops) are cut into `nchunk` batches in emission order
+                # (= backward order): the early batches only need the gradients of the late cells, so the level pass can
+                # place them in the middle of the backward pass where they overlap with it on the second stream
+                k = nchunk if len(items) >= 32 * nchunk else 1
+                per = -(-len(items) // k)
+                for c in range(k):
+                    if items[c * per:(c + 1) * per]:
+                        split[(key, c)] = items[c * per:(c + 1) * per]
+            for (key, _c), items in split.items():
                 n = len(items)
                 arr = (L.ConvWgradArgs * n)()
                 for i, (wa, _, _) in enumerate(items):
