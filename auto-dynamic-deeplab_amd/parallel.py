@@ -30,8 +30,9 @@ class SyncBNComm:
     def _allreduce_multi(self, ts, stream):
         """The exchanges of several independent BatchNorms (one dependency level of the launch list) as ONE grouped RCCL
         call (ncclGroupStart/End through torch's coalescing manager): one launch and one latency instead of len(ts)."""
-        if dist.get_backend(self.group) == 'nccl' and len(ts) > 1:
-            with dist._coalescing_manager(self.group, device=ts[0].device, async_ops=False):
+        cm = getattr(dist, '_coalescing_manager', None)          # private API: fall back to single calls if it is not there
+        if cm is not None and dist.get_backend(self.group) == 'nccl' and len(ts) > 1:
+            with cm(self.group, device=ts[0].device, async_ops=False):
                 for t in ts:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         else:
