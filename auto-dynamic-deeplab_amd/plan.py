@@ -423,7 +423,13 @@ class Graph:
                 waves.append(([], set()))
             waves[-1][0].append((it, ws, grad))
             waves[-1][1].add(it.dw)
-        for items, _ in waves:
+        nchunk = int(os.environ.get('ADDK_WGRAD_CHUNKS', '3'))
+        parts = []
+        for items, _ in waves:           # cut in emission (= backward) order so the early parts overlap with the backward pass
+            k = nchunk if len(items) >= 8 * nchunk else 1
+            per = -(-len(items) // k)
+            parts += [items[c * per:(c + 1) * per] for c in range(k) if items[c * per:(c + 1) * per]]
+        for items in parts:
             n = len(items)
             arr = (L.DwWreduceItem * n)(*[it for it, _, _ in items])
             host = bytes(arr)

@@ -81,7 +81,7 @@ def test_add_plan_structure_train(dry):
     # backward: every conv has a wgrad per source, every BN a bn_bwd
     bn = collections.Counter(n for n, _, _ in plan.g.bwd)
     assert total(plan.g.bwd, 'bn_bwd') == 312 and total(plan.g.bwd, 'bn_bwd_apply') == 312
-    assert bn['dw_bwd'] == 168 and bn['affine_sum_bwd'] == 60 and bn['dw_wreduce_batch'] == 1
+    assert bn['dw_bwd'] == 168 and bn['affine_sum_bwd'] == 60 and 1 <= bn['dw_wreduce_batch'] <= 3
     loss = sum(o.sum() for o in outs)
     loss.backward()
     assert 1 <= dry['conv_wgrad_batch'] <= 40            # ~640 weight gradients in a few batched launches
