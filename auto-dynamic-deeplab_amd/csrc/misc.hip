@@ -8,6 +8,7 @@ struct GapK {
   float* y; int ldy; float* ws; int rows;
   const float* dy; int lddy; float* g; int ldg; int accumulate; double* dab;
   int nq, npl, vec;
+  int Cfull, c0;        // channel chunk [c0, c0 + src.C) of a Cfull-channel tensor (chunks of <= 1024 channels per launch)
 };
 
 // partial sums: ws[(n*rows + r)*C + c] = sum over the r-th pixel slice of image n of relu?(a*x+b)
@@ -32,7 +33,7 @@ __global__ void __launch_bounds__(256) gap_partial_kernel(const GapK p) {
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < C; i += 256) p.ws[((long)n * p.rows + r) * C + i] = redt[i];
+  for (int i = threadIdx.x; i < C; i += 256) p.ws[((long)n * p.rows + r) * p.Cfull + p.c0 + i] = redt[i];
 }
 
 // one wave per (image, channel): lanes stride over the partial rows, fixed-order butterfly
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(256) gap_bwd_kernel(const GapK p) {
       }
       __syncthreads();
     }
-    for (int k = threadIdx.x; k < C * 2; k += 256) p.dab[(long)blockIdx.x * C * 2 + k] = redd[k];
+    for (int k = threadIdx.x; k < C * 2; k += 256) p.dab[((long)blockIdx.x * p.Cfull + p.c0) * 2 + k] = redd[k];
   }
 }
 
@@ -232,31 +233,49 @@ int rows_for(long P, int C) {
 
 }  // namespace
 
+// Channel chunk c0.. of `src` (pointers advanced; a chunk is at most 1024 channels = 256 threads x 4)
+static addk_src gap_chunk(const addk_src& s, int c0, int n) {
+  addk_src c = s;
+  c.x = s.x + c0; c.C = n;
+  if (s.a) { c.a = s.a + c0; c.b = s.b + c0; }
+  return c;
+}
+
 extern "C" int addk_gap_fwd(const addk_src* src, int32_t N, int32_t HW, float* y, int32_t ldy, float* ws, int32_t mean, void* stream) {
-  ADDK_REQUIRE(src && src->x && y && ws && N > 0 && HW > 0 && src->C > 0 && src->C <= 1024 && ldy >= src->C, "gap_fwd: bad args");
+  ADDK_REQUIRE(src && src->x && y && ws && N > 0 && HW > 0 && src->C > 0 && ldy >= src->C, "gap_fwd: bad args");
   ADDK_REQUIRE((src->a == nullptr) == (src->b == nullptr), "gap_fwd: a/b must come together");
-  GapK k{};
-  k.src = *src; k.N = N; k.HW = HW; k.y = y; k.ldy = ldy; k.ws = ws;
-  EwMap m = ew_map(src->C); k.nq = m.nq; k.npl = m.npl; k.vec = src_vec_ok(*src);
-  k.rows = rows_for(HW, src->C);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gap_partial_kernel, dim3(k.rows, N), dim3(256), (size_t)m.nq * 4 * sizeof(float), st, k);
-  int rc = addk_check_launch("gap_partial");
-  if (rc) return rc;
-  hipLaunchKernelGGL(gap_final_kernel, dim3(cdiv((long)N * src->C, 4)), dim3(256), 0, st, ws, N, k.rows, src->C, mean ? 1.f / (float)HW : 1.f, y, ldy);
+  const int rows = rows_for(HW, src->C);
+  for (int c0 = 0; c0 < src->C; c0 += 1024) {          // F=40 with a level-3 last stage has 1600 ASPP input channels
+    const int n = src->C - c0 < 1024 ? src->C - c0 : 1024;
+    GapK k{};
+    k.src = gap_chunk(*src, c0, n); k.N = N; k.HW = HW; k.y = y; k.ldy = ldy; k.ws = ws; k.Cfull = src->C; k.c0 = c0;
+    EwMap m = ew_map(n); k.nq = m.nq; k.npl = m.npl; k.vec = src_vec_ok(k.src);
+    k.rows = rows;
+    hipLaunchKernelGGL(gap_partial_kernel, dim3(k.rows, N), dim3(256), (size_t)m.nq * 4 * sizeof(float), st, k);
+    int rc = addk_check_launch("gap_partial");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(gap_final_kernel, dim3(cdiv((long)N * src->C, 4)), dim3(256), 0, st, ws, N, rows, src->C, mean ? 1.f / (float)HW : 1.f, y, ldy);
   return addk_check_launch("gap_final");
 }
 
 extern "C" int addk_gap_bwd(const addk_src* src, int32_t N, int32_t HW, const float* dy, int32_t lddy, float* g, int32_t ldg,
                             int32_t accumulate, double* dab, void* stream) {
-  ADDK_REQUIRE(src && src->x && dy && g && N > 0 && HW > 0 && src->C > 0 && src->C <= 1024 && ldg >= src->C && lddy >= src->C, "gap_bwd: bad args");
-  GapK k{};
-  k.src = *src; k.N = N; k.HW = HW; k.dy = dy; k.lddy = lddy; k.g = g; k.ldg = ldg; k.accumulate = accumulate; k.dab = (double*)dab;
-  EwMap m = ew_map(src->C); k.nq = m.nq; k.npl = m.npl;
-  k.vec = src_vec_ok(*src) && aligned16(g) && ldg % 4 == 0;
-  int rows = rows_for((long)N * HW, src->C);
-  hipLaunchKernelGGL(gap_bwd_kernel, dim3(rows), dim3(256), (size_t)m.nq * 8 * sizeof(double), (hipStream_t)stream, k);
-  return addk_check_launch("gap_bwd");
+  ADDK_REQUIRE(src && src->x && dy && g && N > 0 && HW > 0 && src->C > 0 && ldg >= src->C && lddy >= src->C, "gap_bwd: bad args");
+  const int rows = rows_for((long)N * HW, src->C);
+  for (int c0 = 0; c0 < src->C; c0 += 1024) {
+    const int n = src->C - c0 < 1024 ? src->C - c0 : 1024;
+    GapK k{};
+    k.src = gap_chunk(*src, c0, n); k.N = N; k.HW = HW; k.dy = dy + c0; k.lddy = lddy; k.g = g + c0; k.ldg = ldg; k.accumulate = accumulate;
+    k.dab = (double*)dab; k.Cfull = src->C; k.c0 = c0;
+    EwMap m = ew_map(n); k.nq = m.nq; k.npl = m.npl;
+    k.vec = src_vec_ok(k.src) && aligned16(k.g) && ldg % 4 == 0;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(rows), dim3(256), (size_t)m.nq * 8 * sizeof(double), (hipStream_t)stream, k);
+    int rc = addk_check_launch("gap_bwd");
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 static int pool_fill(PoolK& k, const addk_src* src, int N, int H, int W, int OH, int OW, int stride, int mode) {

@@ -6,6 +6,9 @@ import torch.nn as nn
 from . import _lib as L
 from . import plan as _plan
 
+import os
+_CHECK_TARGETS = os.environ.get('ADDK_CHECK_TARGETS', '0') == '1'
+
 
 class _CEFn(torch.autograd.Function):
     @staticmethod
@@ -13,9 +16,21 @@ class _CEFn(torch.autograd.Function):
         lib = L.load()
         _plan.require_device(logits)
         logits = logits.contiguous().float()
-        target = target.contiguous().long()
         N, Cc, H, W = logits.shape
         dev = logits.device
+        # the kernel dereferences raw pointers: anything still on the host (a class-weight buffer never moved with
+        # .cuda(), a CPU target) would be a GPU memory fault, so it is moved here like torch's own loss would refuse it
+        target = target.to(dev, non_blocking=True).contiguous().long()
+        if weight is not None:
+            weight = weight.to(dev).float().contiguous()
+            if weight.numel() != Cc:
+                raise ValueError('CrossEntropyLoss: weight has %d entries for %d classes' % (weight.numel(), Cc))
+        if tuple(target.shape) != (N, H, W):
+            raise ValueError('CrossEntropyLoss: target shape %s does not match logits %s' % (tuple(target.shape), tuple(logits.shape)))
+        if _CHECK_TARGETS:                   # ADDK_CHECK_TARGETS=1: torch raises on labels outside [0, C) that are not ignore_index
+            bad = (target != ignore_index) & ((target < 0) | (target >= Cc))
+            if bool(bad.any()):
+                raise IndexError('CrossEntropyLoss: target %d is out of bounds' % int(target[bad][0]))
         loss = torch.zeros(1, device=dev)
         wsum = torch.zeros(1, device=dev)
         ws = torch.empty(int(lib.addk_ce_ws_floats(N, H * W)), device=dev)

@@ -74,9 +74,19 @@ def broadcast_params(model, src=0, group=None):
         dist.broadcast(t.data, src, group=group)
 
 
-def shard_indices(n, rank, world):
-    """DistributedSampler's partition without shuffling (dataloaders/__init__.py:33; the reference never calls
-    set_epoch): rank r takes indices r, r+world, ... padded by wrap-around to equal length."""
+def shard_indices(n, rank, world, shuffle=True, seed=0, epoch=0):
+    """The index list `torch.utils.data.DistributedSampler(dataset, num_replicas=world, rank=rank)` yields — what the
+    reference builds (dataloaders/__init__.py:33, default shuffle=True, seed 0; it never calls set_epoch, so every epoch
+    replays the epoch-0 permutation): randperm(n) from a generator seeded seed+epoch, padded by wrap-around to a multiple
+    of `world`, then strided by rank.  tests/test_parallel_gloo.py checks equality against torch's sampler."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
+    else:
+        idx = list(range(n))
     total = (n + world - 1) // world * world
-    idx = list(range(n)) + list(range(total - n))
+    pad = total - n
+    if pad:
+        idx += (idx * ((pad + n - 1) // n))[:pad]
     return idx[rank:total:world]

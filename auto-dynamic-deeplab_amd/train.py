@@ -51,7 +51,11 @@ class TrainStep:
         N, Cin, H, W = batch_shape
         self.x = torch.zeros(batch_shape, dtype=torch.float32, device=dev)
         self.target = torch.zeros((N, H, W), dtype=torch.int64, device=dev)
-        self.world = sync_comm.size if sync_comm is not None else 1
+        # data-parallel world: from torch.distributed itself, NOT from the SyncBN communicator — the reference's DDP
+        # averages gradients with or without --sync-bn (train.py:173-175)
+        import torch.distributed as dist
+        self.group = sync_comm.group if sync_comm is not None else None
+        self.world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
         self.comm = sync_comm
         g = self.g = Graph(dev, True, True, sync_comm)
         g.pgrad_views = gviews
@@ -78,7 +82,7 @@ class TrainStep:
                    ignore_index, self.wsum.data_ptr(), 1.0 / nex, self.loss.data_ptr(), d.data_ptr(), ws.data_ptr(),
                    rd=[o.y, self.target, self.wsum], wr=[self.loss, d, ws])
             o.dy_ptr, o.dynamic = d.data_ptr(), False
-        has_coll = sync_comm is not None and (self.world > 1 or sync_comm.force)
+        has_coll = self.world > 1 or (sync_comm is not None and sync_comm.force)
         if nstreams is None:
             # two HIP streams: independent branches of the cell DAG overlap (-4 ms of 82 at config 2, eager or captured);
             # 3, 4 and 6 streams measure the same or slightly worse (68.5 / 68.7 / 69.8 / 69.7 ms).  The SyncBN path
@@ -103,7 +107,7 @@ class TrainStep:
         g.run_parallel(g.fwd, main)
         g.run_parallel(g.bwd, main)
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat_g)
+            torch.distributed.all_reduce(self.flat_g, group=self.group)
         mom, wd, nest = self.hyper
         L.check(self.lib.addk_sgd_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.mom_buf.data_ptr(), self.n_active,
                                        self.lr_dev.data_ptr(), mom, wd, nest, 0, 1.0 / self.world, st), 'sgd_step')

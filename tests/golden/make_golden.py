@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, '..'))
 sys.path.insert(0, '/root/reference')
 
-from _util import (ARCH_C2, ARCH_C3, GENOTYPE_AUTODEEPLAB, GENOTYPE_BASELINE_2, GENOTYPE_40_1,  # noqa: E402
+from _util import (ARCH_C2, ARCH_C3, ARCH_C4, GENOTYPE_AUTODEEPLAB, GENOTYPE_BASELINE_2, GENOTYPE_40_1,  # noqa: E402
                    NETWORK_PATH_BASELINE, fill_params, make_args, probe_weights, rand_tensor)
 
 import modeling.operations as R_ops            # noqa: E402
@@ -297,7 +297,40 @@ def gen_misc():
     save('misc', **out)
 
 
+def gen_configs():
+    """Round-2 additions: the C=4 network (train.py:84-87: three 1x1 conv_aspp adapters, level-3 cells feeding a level-2
+    head) and BASELINE config 5's architecture (F=40, both searched_arch/40_5e_38_lr genotypes), eval logits and one
+    train-mode step (loss, per-exit logits, sentinel gradients) from the real reference."""
+    out = {}
+    sa = os.path.join(HERE, '..', '..', 'searched_arch', '40_5e_38_lr')
+    cases = (('F4_C4_65', 4, ARCH_C4, GENOTYPE_AUTODEEPLAB, (65, 129)),
+             ('F40_g1_65', 40, ARCH_C2, np.load(os.path.join(sa, 'genotype_1.npy')), (65, 129)),
+             ('F40_g2_65', 40, ARCH_C2, np.load(os.path.join(sa, 'genotype_2.npy')), (65, 129)))
+    for tag, Fv, arch, geno, hw in cases:
+        m = ADD(arch['network_arch'], arch['C_index'], geno, 19, make_args(Fv), arch['low_level_layer'])
+        out[tag + '/chk'] = np.float64(fill_params(m, 600))
+        x = rand_tensor(61, 'add_x_' + tag, (2, 3) + hw)
+        m.eval()
+        with torch.no_grad():
+            ys = m(x)
+        for i, y in enumerate(ys):
+            store_big(out, tag + '/eval%d' % i, y)
+        fill_params(m, 600)
+        m.train()
+        tgt = torch.from_numpy(np.random.default_rng(62).integers(0, 19, (2,) + hw)).long()
+        tgt[torch.from_numpy(np.random.default_rng(63).random((2,) + hw) < 0.05)] = 255
+        ys = m(x)
+        crit = nn.CrossEntropyLoss(weight=None, ignore_index=255)
+        loss = sum(crit(y, tgt) for y in ys) / len(ys)
+        loss.backward()
+        out[tag + '/loss'] = np.float64(loss.item())
+        for i, y in enumerate(ys):
+            store_big(out, tag + '/train%d' % i, y)
+        out[tag + '/gnorm'] = np.float64(sum(float((p.grad.double() ** 2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5)
+    save('configs', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'bilinear', 'heads', 'cells', 'add', 'dynamic', 'baseline', 'misc']
+    which = sys.argv[1:] or ['ops', 'bilinear', 'heads', 'cells', 'add', 'dynamic', 'baseline', 'misc', 'configs']
     for w in which:
         globals()['gen_' + w]()

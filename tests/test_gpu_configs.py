@@ -1,0 +1,266 @@
+"""GPU parity at the BASELINE configurations the toy-sized suite did not reach:
+
+ * the C=4 network (train.py:84-87: three 1x1 `conv_aspp` adapters) and config 5's F=40 architecture (both
+   searched_arch/40_5e_38_lr genotypes) — eval logits, one train-mode step and frozen-BN gradients incl. backward;
+ * config 2 at its full 2x1024x2048 shape (eval logits, first-step training loss) and config 4's dynamic inference at
+   1x1024x2048 and 1x1025x2049, against the CPU oracle on the same seeded inputs;
+ * the train-mode whole-network gradient spread as a STATISTIC over several inputs (replaces the single-case 0.12 floor).
+
+Tolerance: 1e-3 relative fp32 (max-abs error / max-abs reference) unless a test states a different, measured bound."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+import oracle                       # noqa: E402  (the checker)
+from _util import (ARCH_C2, ARCH_C4, GENOTYPE_AUTODEEPLAB, fill_params, make_args, rand_tensor, rel_err)   # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = []
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    import addk
+    addk.load()
+    return torch.device('cuda:0')
+
+
+def teardown_module(module):
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/parity_report_configs.txt', 'w') as f:
+        f.write('\n'.join(REPORT) + '\n')
+
+
+def _log(fmt, *a):
+    REPORT.append(fmt % a)
+
+
+def _geno(name):
+    if name == 'autodeeplab':
+        return GENOTYPE_AUTODEEPLAB
+    return np.load(os.path.join(ROOT, 'searched_arch', '40_5e_38_lr', name + '.npy'))
+
+
+def _build(dev, Fv, arch, geno, seed=600):
+    from addk.modeling.ADD import ADD
+    args = (arch['network_arch'], arch['C_index'], geno, 19, make_args(Fv), arch['low_level_layer'])
+    mo = oracle.ADD(*args)
+    chk = fill_params(mo, seed)
+    ma = ADD(*args)
+    ma.load_state_dict(mo.state_dict())
+    return ma.to(dev), mo, chk, args
+
+
+def _target(hw, n=2, seed=62):
+    t = torch.from_numpy(np.random.default_rng(seed).integers(0, 19, (n,) + hw)).long()
+    t[torch.from_numpy(np.random.default_rng(seed + 1).random((n,) + hw) < 0.05)] = 255
+    return t
+
+
+def _check_big(g, key, t, tol, what):
+    t = t.detach().float().cpu()
+    if key in g.files:
+        e = rel_err(t, torch.from_numpy(g[key]))
+    else:
+        e = rel_err(t.reshape(-1)[::97], torch.from_numpy(g[key + '@sub97']))
+        n = float(t.double().norm())
+        assert abs(n - float(g[key + '@norm'])) <= tol * float(g[key + '@norm']), what + ' norm'
+    _log('%-60s %.3e', what, e)
+    assert e <= tol, '%s: %.3e > %.1e' % (what, e, tol)
+
+
+CASES = {'F4_C4_65': (4, ARCH_C4, 'autodeeplab'), 'F40_g1_65': (40, ARCH_C2, 'genotype_1'), 'F40_g2_65': (40, ARCH_C2, 'genotype_2')}
+
+
+@pytest.mark.parametrize('tag', list(CASES))
+def test_add_configs_eval_and_train_step(dev, golden, tag):
+    """Eval logits vs the oracle AND the reference golden; one train-mode step: loss vs the reference's, per-exit logits
+    as close to an fp64 evaluation as the fp32 oracle is (the train-mode forward amplifies rounding)."""
+    g = golden('configs')
+    Fv, arch, gname = CASES[tag]
+    ma, mo, chk, args = _build(dev, Fv, arch, _geno(gname))
+    assert abs(chk - float(g[tag + '/chk'])) <= 1e-9 * chk
+    x = rand_tensor(61, 'add_x_' + tag, (2, 3, 65, 129))
+    ma.eval(); mo.eval()
+    with torch.no_grad():
+        ya, yo = ma(x.to(dev)), mo(x)
+    assert len(ya) == len(arch['C_index']) + 1
+    for i, (a, o) in enumerate(zip(ya, yo)):
+        e = rel_err(a, o)
+        _log('%-60s %.3e', '%s/eval%d vs oracle' % (tag, i), e)
+        assert e <= 1e-3
+        _check_big(g, '%s/eval%d' % (tag, i), a, 1e-3, '%s/eval%d vs reference golden' % (tag, i))
+    fill_params(mo, 600)
+    ma.load_state_dict(mo.state_dict())
+    m64 = oracle.ADD(*args)
+    m64.load_state_dict(mo.state_dict())
+    m64.double()
+    ma.train(); mo.train(); m64.train()
+    tgt = _target((65, 129))
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    res = {}
+    for name, m, xx, tt in (('o32', mo, x, tgt), ('o64', m64, x.double(), tgt), ('addk', ma, x.to(dev), tgt.to(dev))):
+        ys = m(xx)
+        loss = sum(crit(y, tt) for y in ys) / len(ys)
+        loss.backward()
+        res[name] = (ys, loss.item(), {k: p.grad.detach().double().cpu() for k, p in m.named_parameters() if p.grad is not None})
+    torch.cuda.synchronize()
+    l32, l64, la, lg = res['o32'][1], res['o64'][1], res['addk'][1], float(g[tag + '/loss'])
+    _log('%-60s o32 %.7f o64 %.7f addk %.7f reference %.7f', tag + '/loss', l32, l64, la, lg)
+    assert abs(la - lg) < 1e-4 * abs(lg)
+    assert abs(la - l64) <= 3 * abs(l32 - l64) + 1e-4 * abs(l64)
+    for i in range(len(res['o64'][0])):
+        e32, ea = rel_err(res['o32'][0][i], res['o64'][0][i]), rel_err(res['addk'][0][i], res['o64'][0][i])
+        _log('%-60s o32-vs-fp64 %.3e  addk-vs-fp64 %.3e', '%s/train%d' % (tag, i), e32, ea)
+        assert ea <= 3 * e32 + 1e-3
+    g64, ga = res['o64'][2], res['addk'][2]
+    assert set(ga) == set(g64)               # every parameter of the architecture received a gradient (backward wiring)
+    dot = sum(float((ga[k] * g64[k]).sum()) for k in g64)
+    cos = dot / (sum(float((ga[k] ** 2).sum()) for k in g64) ** 0.5 * sum(float((g64[k] ** 2).sum()) for k in g64) ** 0.5)
+    _log('%-60s cos(addk, fp64) %.6f', tag + '/grad', cos)
+    assert cos >= 0.99
+
+
+@pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])
+def test_f40_frozen_bn_gradients(dev, gname):
+    """Config 5's architecture, backward included, at 2x256x512 (cell maps >= 8k pixels: the large-map kernels engage):
+    BatchNorm frozen, every conv-weight gradient held against the fp64 oracle relative to the fp32 oracle's own error."""
+    hw = (256, 512)
+    ma, mo, _, args = _build(dev, 40, ARCH_C2, _geno(gname), seed=900)
+    ma.eval(); mo.eval()
+    x = rand_tensor(61, 'f40_frozen_x', (2, 3) + hw)
+    tgt = _target(hw)
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    ya = ma(x.to(dev)); yo = mo(x)
+    for i, (a, o) in enumerate(zip(ya, yo)):
+        e = rel_err(a, o)
+        _log('%-60s %.3e', 'F40_%s_256x512/eval%d vs oracle' % (gname, i), e)
+        assert e <= 1e-3
+    (sum(crit(y, tgt.to(dev)) for y in ya) / 2).backward()
+    (sum(crit(y, tgt) for y in yo) / 2).backward()
+    m64 = oracle.ADD(*args).double()
+    m64.load_state_dict(mo.state_dict()); m64.eval()
+    (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
+    torch.cuda.synchronize()
+    pa, p64 = dict(ma.named_parameters()), dict(m64.named_parameters())
+    ours, theirs = [], []
+    for k, p in mo.named_parameters():
+        if p.dim() == 4 and p.grad is not None:
+            assert pa[k].grad is not None, k
+            ours.append(rel_err(pa[k].grad.cpu().double(), p64[k].grad))
+            theirs.append(rel_err(p.grad.double(), p64[k].grad))
+    assert len(ours) > 400
+    med = lambda v: sorted(v)[len(v) // 2]
+    _log('F40_%s frozen-BN 256x512, %d conv-weight gradients vs fp64: addk max %.2e median %.2e | fp32 oracle max %.2e median %.2e',
+         gname, len(ours), max(ours), med(ours), max(theirs), med(theirs))
+    assert max(ours) <= max(3 * max(theirs), 2e-3) and med(ours) <= max(3 * med(theirs), 2e-4)
+
+
+@pytest.mark.parametrize('hw', [(65, 129), (64, 128)], ids=['odd65x129', 'even64x128'])
+def test_train_mode_gradient_spread_is_the_references_own(dev, hw):
+    """Train-mode whole-network gradients are ill-conditioned in the REFERENCE arithmetic itself: the fp32 oracle sits
+    5e-2..1.5e-1 (rel-L2 over all parameters) from an fp64 evaluation of the same graph, at every batch / map size tried
+    (2x65x129 5.1e-2, 2x129x257 1.1e-1, 4x129x257 9.5e-2, 2x257x513 1.5e-1, 8x65x129 6.8e-2: no well-conditioned size
+    exists; the gradient norm grows 300x from the heads to the stems through 12 cells of small-batch BatchNorm).  A
+    single input therefore says little (round 1's F4_64 case: addk 6.1e-2 vs fp32 1.5e-2 was one draw from this spread).
+    The bound here is on the DISTRIBUTION over several inputs: addk's error against fp64 must look like the fp32
+    oracle's own — median within 2x, maximum within 3x — and the gradient direction must agree (cos >= 0.99)."""
+    from addk.modeling.ADD import ADD
+    args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4), 0)
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    e32s, eas, coss = [], [], []
+    for k in range(6):
+        mo = oracle.ADD(*args)
+        fill_params(mo, 600 + k)
+        m64 = oracle.ADD(*args); m64.load_state_dict(mo.state_dict()); m64.double()
+        ma = ADD(*args); ma.load_state_dict(mo.state_dict()); ma.to(dev)
+        x = rand_tensor(170 + k, 'spread_x', (2, 3) + hw)
+        tgt = _target(hw, seed=180 + 2 * k)
+        grads = {}
+        for name, m, xx, tt in (('o32', mo, x, tgt), ('o64', m64, x.double(), tgt), ('addk', ma, x.to(dev), tgt.to(dev))):
+            m.train()
+            ys = m(xx)
+            (sum(crit(y, tt) for y in ys) / len(ys)).backward()
+            grads[name] = {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
+        g64 = grads['o64']
+        den = sum(float((g64[n] ** 2).sum()) for n in g64) ** 0.5
+
+        def rel_l2(ga):
+            return sum(float(((ga[n] - g64[n]) ** 2).sum()) for n in g64) ** 0.5 / den
+        ga = grads['addk']
+        e32s.append(rel_l2(grads['o32'])); eas.append(rel_l2(ga))
+        coss.append(sum(float((ga[n] * g64[n]).sum()) for n in g64) / (den * sum(float((ga[n] ** 2).sum()) for n in g64) ** 0.5))
+    med = lambda v: sorted(v)[len(v) // 2]
+    _log('train-mode gradient rel-L2 vs fp64 over 6 inputs at %s: fp32 oracle %s | addk %s | cos %s', hw,
+         ' '.join('%.2e' % v for v in e32s), ' '.join('%.2e' % v for v in eas), ' '.join('%.5f' % v for v in coss))
+    assert med(eas) <= 2.0 * med(e32s), (eas, e32s)
+    assert max(eas) <= 3.0 * max(e32s), (eas, e32s)
+    assert min(coss) >= 0.99
+
+
+def _bench_model(dev, seed=1):
+    """The model bench.py times: ADD searched-dense C=2 F=20, weights from fill_params (name-keyed, identical in the oracle)."""
+    ma, mo, _, args = _build(dev, 20, ARCH_C2, GENOTYPE_AUTODEEPLAB, seed=1000 + seed)
+    return ma, mo
+
+
+def test_full_size_config2_eval_logits_and_first_step_loss(dev):
+    """BASELINE config 2 at its real shape, 2x1024x2048: eval-mode logits of both exits (subsampled every 8th pixel + the
+    L2 norm of the whole tensor) and the first training step's loss against the CPU oracle."""
+    hw = (1024, 2048)
+    ma, mo = _bench_model(dev)
+    x = rand_tensor(201, 'full_x', (2, 3) + hw)
+    ma.eval(); mo.eval()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ya = ma(x.to(dev))
+        ya = [y.cpu() for y in ya]
+        yo = mo(x)
+    for i, (a, o) in enumerate(zip(ya, yo)):
+        assert tuple(a.shape) == (2, 19) + hw
+        e = rel_err(a[:, :, ::8, ::8], o[:, :, ::8, ::8])
+        en = abs(float(a.double().norm()) - float(o.double().norm())) / float(o.double().norm())
+        _log('%-60s sub8 %.3e  norm %.3e', 'config2 2x1024x2048 eval logits exit %d vs oracle' % i, e, en)
+        assert e <= 1e-3 and en <= 1e-4
+    del ya, yo
+    ma.train(); mo.train()
+    tgt = _target(hw)
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    with torch.no_grad():
+        lo = sum(crit(y, tgt) for y in mo(x)) / 2
+    from addk.loss import CrossEntropyLoss
+    ca = CrossEntropyLoss(ignore_index=255)
+    with torch.no_grad():
+        ys = ma(x.to(dev))
+        la = sum(ca(y, tgt.to(dev)) for y in ys) / 2
+    _log('%-60s oracle %.7f addk %.7f', 'config2 2x1024x2048 train-mode first-step loss', float(lo), float(la))
+    assert abs(float(la) - float(lo)) <= 1e-4 * abs(float(lo))
+
+
+@pytest.mark.parametrize('hw', [(1024, 2048), (1025, 2049)], ids=['1024x2048', '1025x2049'])
+def test_full_size_config4_dynamic_inference(dev, hw):
+    """BASELINE config 4 at its real shapes (bs=1): EDM-gated dynamic inference, early and final exit, against the oracle
+    (reference ADD.py:379-438; 1025x2049 is the reference's padded eval size, 1024x2048 exercises the even-size quirk Q8)."""
+    from addk.modeling.ADD import EDM
+    ma, mo = _bench_model(dev, seed=2)
+    eo = oracle.EDM(); fill_params(eo, 701)
+    ea = EDM(); ea.load_state_dict(eo.state_dict()); ea.to(dev).eval()
+    ma.eval(); mo.eval(); eo.eval()
+    x = rand_tensor(202, 'dyn_full_x', (1, 3) + hw)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        for name, thr in (('early', 1e9), ('final', -1e9)):
+            ya, ee_a, secs, conf_a = ma.dynamic_inference(x.to(dev), threshold=thr, confidence='edm', edm=ea)
+            ya = ya.cpu()
+            yo, ee_o, _, conf_o = mo.dynamic_inference(x, threshold=thr, confidence='edm', edm=eo)
+            assert ee_a == ee_o == (1 if name == 'early' else 0)
+            e = rel_err(ya[:, :, ::8, ::8], yo[:, :, ::8, ::8])
+            ec = rel_err(conf_a, conf_o)
+            _log('%-60s logits sub8 %.3e  confidence %.3e  (%.1f ms)', 'config4 %dx%d dynamic %s exit vs oracle' % (hw + (name,)), e, ec, secs * 1e3)
+            assert tuple(ya.shape) == (1, 19) + hw and e <= 1e-3 and ec <= 1e-3

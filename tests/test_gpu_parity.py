@@ -302,9 +302,10 @@ def test_add_whole_net(dev, golden, tag, Fv, arch):
     e32, ea = rel_l2(res['o32'][2]), rel_l2(res['addk'][2])
     REPORT.append('%-60s o32-vs-fp64 %.3e  addk-vs-fp64 %.3e  cos %.6f / %.6f' % (tag + '/grad rel-L2 (all params)', e32, ea,
                                                                                cos(res['o32'][2]), cos(res['addk'][2])))
-    # the fp32-vs-fp64 spread itself varies 1.5e-2 .. 9e-2 between inputs (see the report lines): bound by the larger of
-    # 3x the reference's own spread and 0.12, and require the gradient direction to agree with fp64 (cos >= 0.99)
-    assert ea <= max(3.0 * e32, 0.12), 'gradient further from fp64 truth than the fp32 reference: %.3e vs %.3e' % (ea, e32)
+    # the fp32-vs-fp64 spread itself varies 1.5e-2 .. 1.5e-1 between inputs and sizes, so one input says little about it:
+    # the magnitude bound is held as a statistic over several inputs in tests/test_gpu_configs.py
+    # (test_train_mode_gradient_spread_is_the_references_own: median within 2x, maximum within 3x of the fp32 oracle's own);
+    # here the gradient direction must agree with fp64
     assert cos(res['addk'][2]) >= 0.99
     ba = dict(ma.named_buffers())
     for n, b in m64.named_buffers():

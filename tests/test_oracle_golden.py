@@ -209,3 +209,41 @@ def test_syncbn_definition_and_evaluator(golden):
     assert abs(float(ev.Pixel_Accuracy()) - float(g['eval/pa'])) < 1e-7
     assert abs(float(ev.Pixel_Accuracy_Class()) - float(g['eval/pac'])) < 1e-7
     assert abs(float(ev.Frequency_Weighted_Intersection_over_Union()) - float(g['eval/fwiou'])) < 1e-7
+
+
+def _config_case(tag):
+    import os
+    sa = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'searched_arch', '40_5e_38_lr')
+    from _util import ARCH_C4
+    return {'F4_C4_65': (4, ARCH_C4, GENOTYPE_AUTODEEPLAB), 'F40_g1_65': (40, ARCH_C2, np.load(os.path.join(sa, 'genotype_1.npy'))),
+            'F40_g2_65': (40, ARCH_C2, np.load(os.path.join(sa, 'genotype_2.npy')))}[tag]
+
+
+@pytest.mark.parametrize('tag', ['F4_C4_65', 'F40_g1_65', 'F40_g2_65'])
+def test_add_configs(golden, tag):
+    """C=4 network (train.py:84-87) and config 5's F=40 architecture: oracle vs the reference's eval logits and one
+    train-mode step (tests/golden/make_golden.py gen_configs)."""
+    g = golden('configs')
+    Fv, arch, geno = _config_case(tag)
+    m = oracle.ADD(arch['network_arch'], arch['C_index'], geno, 19, make_args(Fv), arch['low_level_layer'])
+    chk = fill_params(m, 600)
+    assert abs(chk - float(g[tag + '/chk'])) <= 1e-9 * chk
+    x = rand_tensor(61, 'add_x_' + tag, (2, 3, 65, 129))
+    m.eval()
+    with torch.no_grad():
+        ys = m(x)
+    assert len(ys) == len(arch['C_index']) + 1
+    for i, y in enumerate(ys):
+        check_big(g, tag + '/eval%d' % i, y, 1e-4)
+    fill_params(m, 600)
+    m.train()
+    tgt = torch.from_numpy(np.random.default_rng(62).integers(0, 19, (2, 65, 129))).long()
+    tgt[torch.from_numpy(np.random.default_rng(63).random((2, 65, 129)) < 0.05)] = 255
+    ys = m(x)
+    loss = oracle.cross_entropy_mean_exits(ys, tgt)
+    loss.backward()
+    assert abs(loss.item() - float(g[tag + '/loss'])) < 1e-5 * abs(float(g[tag + '/loss']))
+    for i, y in enumerate(ys):
+        check_big(g, tag + '/train%d' % i, y, 1e-4)
+    gn = sum(float((p.grad.double() ** 2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5
+    assert abs(gn - float(g[tag + '/gnorm'])) < 1e-3 * float(g[tag + '/gnorm'])
