@@ -70,6 +70,32 @@ class Vec:
         return self.buf.t[self.off:self.off + self.n]
 
 
+class LateVec:
+    """A small device vector whose storage is assigned only after the launch list has been ordered (Graph._bind_late):
+    the statistics vectors exchanged by the SyncBN all-reduces of ONE dependency level are laid out back to back in one
+    arena, so a level costs a single plain `all_reduce` on a contiguous tensor.  `n` counts 4-byte slots; `f64` marks
+    fp64 pairs (forward statistics).  Until bound, dependency tracking uses the object itself as its region."""
+    __slots__ = ('n', 'f64', 'buf', 'off', 'binders')
+
+    def __init__(self, n, f64=False):
+        self.n, self.f64, self.buf, self.off, self.binders = int(n), f64, None, 0, []
+
+    @property
+    def ptr(self):
+        if self.buf is None:
+            raise RuntimeError('LateVec used before Graph.finalize() bound it')
+        return self.buf.ptr + 4 * self.off
+
+    def bind(self, buf, off):
+        self.buf, self.off = buf, off
+        for b in self.binders:
+            b(self.ptr)
+
+    def view(self):
+        t = self.buf.t[self.off:self.off + self.n]
+        return t.view(torch.float64) if self.f64 else t
+
+
 class BNState:
     """Per-call state of one BatchNorm application: lazy affine + saved statistics + the
     partial (dA,dB) slabs its consumers produce in backward."""
@@ -98,7 +124,7 @@ class Act:
 class Cmd:
     """One kernel launch of a plan: fn(*args, stream).  `rd`/`wr` are the memory regions it reads / writes
     (keys from `_region`), used to schedule independent launches on parallel HIP streams."""
-    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag', 'payload', 'bkey')
+    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag', 'payload', 'bkey', 'arena', 'members')
 
     def __init__(self, name, fn, args, rd=(), wr=(), pin=False):
         self.name, self.fn, self.args = name, fn, list(args)
@@ -106,6 +132,7 @@ class Cmd:
         self.stream, self.waits, self.event, self.pin, self.tag = 0, (), None, pin, ''
         self.payload = None            # argument struct of a launch that has a table-driven batched form (level_batch)
         self.bkey = 0                  # kernel-variant key: only launches with equal keys share a batch
+        self.arena, self.members = None, 1
 
     def __iter__(self):                # unpacks like the (name, fn, args) triple it replaces
         return iter((self.name, self.fn, self.args))
@@ -123,6 +150,8 @@ def _region(x):
         return (id(x.buf), lo, lo + x.C)
     if isinstance(x, Vec):
         return (id(x.buf), 0, 1 << 30)
+    if isinstance(x, LateVec):
+        return (id(x), 0, 1 << 30)
     if isinstance(x, Buf):
         return (id(x), 0, 1 << 30)
     if isinstance(x, torch.Tensor):
@@ -217,6 +246,7 @@ class Graph:
         self._dwreds = []             # deferred depthwise weight-gradient reductions (item, workspace, grad tensor)
         self._packs, self._pack_cmd = [], None   # hoisted weight packs of the halo-patch conv launches (descriptor bytes)
         self.meta = []                # per-launch algorithmic work of the dense convs (bench / roofline)
+        self.grad_sync = None         # parallel.GradSync of a data-parallel train step (set before finalize)
 
     # ---------------- memory ----------------
     def buf(self, n, zero=False):
@@ -310,9 +340,13 @@ class Graph:
             tab = tab.to(self.device) if self.device.type == 'cuda' else tab.clone()
             self.keep.append(tab)
             self._pack_cmd.args[0], self._pack_cmd.args[1] = tab.data_ptr(), len(self._packs)
-        if ((self.training and self.want_grad) or getattr(self, 'reorder', False)) and os.environ.get('ADDK_LEVEL_BATCH', '1') == '1':
-            self._level_batch(self.fwd)
-            self._level_batch(self.bwd)
+        batch = ((self.training and self.want_grad) or getattr(self, 'reorder', False)) and os.environ.get('ADDK_LEVEL_BATCH', '1') == '1'
+        for lst in (self.fwd, self.bwd):
+            self._bind_late(lst, by_level=batch)          # storage of the exchanged statistics vectors: one arena per level
+            if batch:
+                self._level_batch(lst)
+        if self.grad_sync is not None:
+            self.grad_sync.insert(self, self.bwd)          # bucketed gradient all-reduces, each right after its last producer
         for lst in (self.fwd, self.bwd):
             for i, c in enumerate(lst):
                 if not isinstance(c, Cmd):           # commands appended as plain triples (e.g. collectives): pinned to the main stream
@@ -329,12 +363,9 @@ class Graph:
                 'dw_fwd': ('addk_dw_fwd_batch_prepare', 'addk_dw_batch_run'), 'dw_bwd': ('addk_dw_bwd_batch_prepare', 'addk_dw_batch_run'),
                 'allreduce': (None, None)}
 
-    def _level_batch(self, lst):
-        """Reorder a launch list by dependency LEVEL (longest path from the inputs) and merge the mutually independent
-        BatchNorm vector launches of one level into one table-driven launch each.  The cell DAG offers ~10 independent
-        branches per level, so the 312 finalize / 312 backward / 312 apply launches of a step — each a ~10 us latency
-        chain on the critical path — shrink to one launch per level.  Commands of one level never depend on each other,
-        so any order inside a level is valid; program order of the original list is kept."""
+    @staticmethod
+    def _levels(lst):
+        """Dependency level (longest path from the inputs) of every command of a launch list."""
         writers, readers, level = {}, {}, []
         for i, c in enumerate(lst):
             deps = set()
@@ -349,6 +380,39 @@ class Graph:
                 readers[k[0]] = [(r, j) for r, j in readers.get(k[0], ()) if not (r[1] >= k[1] and r[2] <= k[2])]   # only readers this write fully covers are implied by it
             for k in c.rd:
                 readers.setdefault(k[0], []).append((k, i))
+        return level
+
+    def _bind_late(self, lst, by_level):
+        """Give every exchanged statistics vector (LateVec payload of an 'allreduce' command) its storage.  With level
+        batching the vectors of one dependency level share one arena, in list order, and `_level_batch` replaces their
+        commands by ONE all-reduce of the arena; otherwise each gets its own buffer.  Runs before any table-driven batch is
+        built, because the producers (slab_reduce / bn_bwd) and consumers (bn_finalize / bn_bwd_coeffs) of a vector sit on
+        other levels and carry its address in their argument structs."""
+        ars = [(i, c) for i, c in enumerate(lst) if isinstance(c, Cmd) and c.name == 'allreduce' and isinstance(c.payload, LateVec)]
+        if not ars:
+            return
+        level = self._levels(lst) if by_level else list(range(len(lst)))
+        groups = collections.defaultdict(list)
+        for i, c in ars:
+            groups[(level[i], c.payload.f64)].append(c)
+        for (_, f64), cs in sorted(groups.items()):
+            unit = 4                                   # slots of 16 bytes: every vector starts 16-byte aligned
+            total = sum((c.payload.n + unit - 1) // unit * unit for c in cs)
+            arena = self.buf(total, zero=True)
+            off = 0
+            for c in cs:
+                c.payload.bind(arena, off)
+                off += (c.payload.n + unit - 1) // unit * unit
+            for c in cs:
+                c.arena = (arena, total, f64)
+
+    def _level_batch(self, lst):
+        """Reorder a launch list by dependency LEVEL (longest path from the inputs) and merge the mutually independent
+        BatchNorm vector launches of one level into one table-driven launch each.  The cell DAG offers ~10 independent
+        branches per level, so the 312 finalize / 312 backward / 312 apply launches of a step — each a ~10 us latency
+        chain on the critical path — shrink to one launch per level.  Commands of one level never depend on each other,
+        so any order inside a level is valid; program order of the original list is kept."""
+        level = self._levels(lst)
         buckets = collections.defaultdict(list)
         for i, c in enumerate(lst):
             buckets[level[i]].append(c)
@@ -361,16 +425,20 @@ class Graph:
                 else:
                     out.append(c)
             for (name, _), cs in groups.items():
-                if len(cs) == 1:
+                if len(cs) == 1 and name != 'allreduce':
                     out.append(cs[0])
                     continue
                 fname, size_of = self._BATCHED[name]
                 n = len(cs)
-                if name == 'allreduce':        # SyncBN exchanges of one level: one grouped RCCL call, pinned to the main stream
-                    m = Cmd('allreduce_multi', self.world._allreduce_multi, ([c.payload for c in cs],), pin=True)
+                if name == 'allreduce':        # SyncBN exchanges of one level: their vectors are contiguous in one arena (_bind_late) -> ONE plain all-reduce
+                    arena, total, f64 = cs[0].arena
+                    assert all(c.arena[0] is arena for c in cs)
+                    t = arena.t[:total]
+                    m = Cmd('allreduce_packed', self.world._allreduce, (t.view(torch.float64) if f64 else t,), pin=True)
                     m.rd = [r for c in cs for r in c.rd]
                     m.wr = [r for c in cs for r in c.wr]
                     m.tag = cs[0].tag
+                    m.members = len(cs)
                     out.append(m)
                     continue
                 arr = (type(cs[0].payload) * n)(*[c.payload for c in cs])
@@ -723,12 +791,15 @@ class Graph:
             sync = self.world is not None and getattr(mod, 'sync', False) and (self.world.size > 1 or self.world.force)
             fa = L.BnFinalizeArgs()
             if sync:
-                red = self.vec(4 * Cc)      # fp64 [C][2]
+                red = LateVec(4 * Cc, f64=True)      # fp64 [C][2], summed over ranks
                 sri = L.SlabReduceItem()
-                sri.partial, sri.out, sri.rows, sri.C = slab.ptr, red.ptr, rows, Cc
-                self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, red.ptr, rd=[slab], wr=[red]).payload = sri
+                sri.partial, sri.rows, sri.C = slab.ptr, rows, Cc
+                csr = self._add(self.fwd, 'slab_reduce', lib.addk_slab_reduce, slab.ptr, rows, Cc, None, rd=[slab], wr=[red])
+                csr.payload = sri
+                red.binders += [lambda p, sri=sri: setattr(sri, 'out', p), lambda p, csr=csr: csr.args.__setitem__(3, p),
+                                lambda p: setattr(fa, 'partial', p)]
                 self.world.emit_allreduce(self, self.fwd, red)    # every rank has the same per-rank count
-                fa.partial, fa.rows = red.ptr, 1
+                fa.rows = 1
                 st.count = count * self.world.size
             else:
                 fa.partial, fa.rows = slab.ptr, rows
@@ -784,14 +855,16 @@ class Graph:
                 sync = self.world is not None and getattr(mod, 'sync', False) and (self.world.size > 1 or self.world.force)
                 self.keep.append(ba)
                 if sync:
-                    dmv = self.vec(2 * Cc)
-                    ba.dmv = dmv.ptr
-                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [dmv])
+                    dmv = LateVec(2 * Cc)              # (dmean, dvar) contributions of this rank, summed over ranks
+                    self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [dmv]).payload = ba
                     self.world.emit_allreduce(self, self.bwd, dmv)
                     cit = L.BnCoeffsItem()
-                    cit.dmv, cit.c1, cit.c2, cit.count, cit.C = dmv.ptr, c1.ptr, c2.ptr, st.count, Cc
-                    self._add(self.bwd, 'bn_bwd_coeffs', lib.addk_bn_bwd_coeffs_from_dmv, dmv.ptr, Cc, st.count, c1.ptr, c2.ptr,
-                              rd=[dmv], wr=[c1, c2]).payload = cit
+                    cit.c1, cit.c2, cit.count, cit.C = c1.ptr, c2.ptr, st.count, Cc
+                    cco = self._add(self.bwd, 'bn_bwd_coeffs', lib.addk_bn_bwd_coeffs_from_dmv, None, Cc, st.count, c1.ptr, c2.ptr,
+                                    rd=[dmv], wr=[c1, c2])
+                    cco.payload = cit
+                    dmv.binders += [lambda p, ba=ba: setattr(ba, 'dmv', p), lambda p, cit=cit: setattr(cit, 'dmv', p),
+                                    lambda p, cco=cco: cco.args.__setitem__(0, p)]
                 else:
                     ba.c1, ba.c2 = c1.ptr, c2.ptr
                     self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2]).payload = ba

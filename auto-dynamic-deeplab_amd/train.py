@@ -83,6 +83,11 @@ class TrainStep:
                    rd=[o.y, self.target, self.wsum], wr=[self.loss, d, ws])
             o.dy_ptr, o.dynamic = d.data_ptr(), False
         has_coll = self.world > 1 or (sync_comm is not None and sync_comm.force)
+        self.gsync = None
+        if has_coll:
+            from .parallel import GradSync
+            self.gsync = g.grad_sync = GradSync(self.flat_g, gviews, self.group, int(os.environ.get('ADDK_GRAD_BUCKETS', '4')),
+                                                log=getattr(sync_comm, 'log', None))
         if nstreams is None:
             # two HIP streams: independent branches of the cell DAG overlap (-4 ms of 82 at config 2, eager or captured);
             # 3, 4 and 6 streams measure the same or slightly worse (68.5 / 68.7 / 69.8 / 69.7 ms).  The SyncBN path
@@ -94,7 +99,10 @@ class TrainStep:
         self.n_active = self.flat_p.numel()
         self.nbytes = g.nbytes
         if use_graph is None:
-            use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (not has_coll or os.environ.get('ADDK_GRAPH_DDP', '0') == '1')
+            # the collective step is captured too (RCCL calls are stream-ordered work like any kernel); ADDK_GRAPH_DDP=0 keeps
+            # the N>1 step on the eager launch list, and a failed capture falls back to it (step())
+            use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (not has_coll or os.environ.get('ADDK_GRAPH_DDP', '1') == '1')
+        self.has_coll = has_coll
         self.graph = None
         self.use_graph = use_graph
         self.steps = 0
@@ -105,19 +113,24 @@ class TrainStep:
         st = main.cuda_stream
         g = self.g
         g.run_parallel(g.fwd, main)
-        g.run_parallel(g.bwd, main)
-        if self.world > 1:
-            torch.distributed.all_reduce(self.flat_g, group=self.group)
+        g.run_parallel(g.bwd, main)          # the bucketed gradient all-reduces are commands of this list (parallel.GradSync)
+        if self.gsync is not None:
+            self.gsync.wait()
+        self._sgd(st)
+        self.nbt.flat.add_(self.nbt.inc)
+
+    def _sgd(self, st):
         mom, wd, nest = self.hyper
         L.check(self.lib.addk_sgd_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.mom_buf.data_ptr(), self.n_active,
                                        self.lr_dev.data_ptr(), mom, wd, nest, 0, 1.0 / self.world, st), 'sgd_step')
-        self.nbt.flat.add_(self.nbt.inc)
 
     def forward_backward_only(self):
         """Forward + loss + backward without the optimizer update (parity tests)."""
         main = torch.cuda.current_stream()
         self.g.run_parallel(self.g.fwd, main)
         self.g.run_parallel(self.g.bwd, main)
+        if self.gsync is not None:
+            self.gsync.wait()
 
     def load_batch(self, images, targets):
         self.x.copy_(images, non_blocking=True)
@@ -138,8 +151,20 @@ class TrainStep:
                 # one eager step first (also warms RCCL), then capture
                 self._run()
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._run()
+                    self.graph = graph
+                except Exception as e:            # a collective step whose capture the runtime refuses: stay on the eager list
+                    if not self.has_coll:
+                        raise
+                    import sys
+                    sys.stderr.write('[addk] hipGraph capture of the data-parallel step failed (%s): eager replay\n' % (str(e).splitlines()[0],))
+                    self.use_graph, self.graph = False, None
+                    if self.gsync is not None:
+                        del self.gsync.works[:]
+                    torch.cuda.synchronize()
                     self._run()
             else:
                 self.graph.replay()

@@ -39,7 +39,7 @@ def _syncbn_math(rank, world):
     import addk  # noqa: F401
     import oracle
     from addk.parallel import SyncBNComm
-    from addk.plan import Vec
+    from addk.plan import LateVec
     from _util import rand_tensor
     comm = SyncBNComm()
     C = 12
@@ -47,29 +47,31 @@ def _syncbn_math(rank, world):
     x = shards[rank].double()
     w, b = rand_tensor(91, 'sbn_w', (C,)).double() * 0.2 + 1, rand_tensor(91, 'sbn_b', (C,)).double() * 0.2
 
-    class FakeBuf:            # Vec.view() only needs .t
+    class FakeBuf:            # LateVec.view() only needs .t (and .ptr for the binders)
         def __init__(self, t):
-            self.t = t
+            self.t, self.ptr = t, 0
     stats = torch.stack([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))], dim=1).reshape(-1).contiguous()   # [C][2] fp64
-    buf = FakeBuf(stats.view(torch.float32))       # the plan stores fp64 pairs in an fp32 buffer
+    # the plan stores fp64 pairs in fp32 slots; a second vector shares the arena, as the BatchNorms of one level do
+    arena = FakeBuf(torch.cat([stats.view(torch.float32), torch.full((8,), float(rank + 1)).double().view(torch.float32)]))
     cmds = []
 
     class G:
         fwd = cmds
 
         def _add(self, lst, name, fn, *args, **kw):
-            lst.append((name, fn, args))
             import types
-            return types.SimpleNamespace()
+            c = types.SimpleNamespace(name=name, fn=fn, args=list(args), payload=None)
+            lst.append(c)
+            return c
     g = G()
-    comm.emit_allreduce(g, g.fwd, Vec(buf, 0, 4 * C))
-    for name, fn, args in cmds:
-        assert fn(*args, 0) == 0
-    # the grouped form used for the BatchNorms of one dependency level (falls back to a loop on gloo)
-    t1, t2 = torch.full((3,), float(rank + 1)), torch.full((5,), 2.0 * (rank + 1), dtype=torch.float64)
-    assert comm._allreduce_multi([t1, t2], 0) == 0
+    v1, v2 = LateVec(4 * C, f64=True), LateVec(16, f64=True)
+    comm.emit_allreduce(g, g.fwd, v1); comm.emit_allreduce(g, g.fwd, v2)
+    v1.bind(arena, 0); v2.bind(arena, 4 * C)
+    # the merged form plan.Graph._level_batch emits for one level: ONE plain all-reduce of the arena
+    assert comm._allreduce(arena.t.view(torch.float64), 0) == 0
     tri = world * (world + 1) / 2
-    assert torch.equal(t1, torch.full((3,), tri)) and torch.equal(t2, torch.full((5,), 2.0 * tri, dtype=torch.float64))
+    assert torch.equal(v2.view(), torch.full((8,), tri, dtype=torch.float64))
+    buf = FakeBuf(v1.view().clone().view(torch.float32))
     tot = buf.t.view(torch.float64).reshape(C, 2)
     count = float(world * 2 * 5 * 7)
     mean = tot[:, 0] / count
@@ -93,9 +95,11 @@ def _syncbn_math(rank, world):
     dmean_tot = -a * dB - 2 * mean * dvar
     dmv = torch.stack([dmean_tot, dvar], dim=1).reshape(-1).float().contiguous()
     cmds2 = []
-    comm.emit_allreduce(g, cmds2, Vec(FakeBuf(dmv), 0, 2 * C))
-    for name, fn, args in cmds2:
-        fn(*args, 0)
+    v3 = LateVec(2 * C)
+    comm.emit_allreduce(g, cmds2, v3)
+    v3.bind(FakeBuf(dmv), 0)
+    for c in cmds2:                      # the un-merged form (a level with level batching disabled)
+        assert c.fn(*c.args, 0) == 0
     dmv = dmv.double().reshape(C, 2)
     c1, c2 = dmv[:, 0] / count, 2 * dmv[:, 1] / count
     gx = dz * a.view(1, -1, 1, 1) + c1.view(1, -1, 1, 1) + c2.view(1, -1, 1, 1) * x
@@ -105,7 +109,7 @@ def _syncbn_math(rank, world):
 
 def test_syncbn_exchange_matches_global_batch_norm():
     for err_fwd, err_bwd, calls in _spawn(_syncbn_math):
-        assert err_fwd < 1e-9 and err_bwd < 1e-5 and calls == 3        # forward, grouped probe, backward
+        assert err_fwd < 1e-9 and err_bwd < 1e-5 and calls == 2        # packed forward arena, backward vector
 
 
 def _grads_and_broadcast(rank, world):
@@ -144,9 +148,9 @@ def _plan_with_syncbn(rank, world):
     f = collections.Counter(n for n, _, _ in plan.g.fwd)
     b = collections.Counter(n for n, _, _ in plan.g.bwd)
 
-    def exchanged(lst):      # tensors exchanged: single all-reduces + members of the grouped (one-level) ones
-        return sum(1 for c in lst if c.name == 'allreduce') + sum(len(c.args[0]) for c in lst if c.name == 'allreduce_multi')
-    calls = f['allreduce'] + f['allreduce_multi'] + b['allreduce'] + b['allreduce_multi']
+    def exchanged(lst):      # vectors exchanged: single all-reduces + members of the packed (one-level) ones
+        return sum(1 for c in lst if c.name == 'allreduce') + sum(c.members for c in lst if c.name == 'allreduce_packed')
+    calls = f['allreduce'] + f['allreduce_packed'] + b['allreduce'] + b['allreduce_packed']
     def total(lst, name):
         return sum(1 for c in lst if c.name == name) + sum(c.args[1] for c in lst if c.name == name + '_batch')
     return exchanged(plan.g.fwd), exchanged(plan.g.bwd), total(plan.g.fwd, 'slab_reduce'), total(plan.g.bwd, 'bn_bwd_coeffs'), len(outs), calls
@@ -155,4 +159,86 @@ def _plan_with_syncbn(rank, world):
 def test_add_plan_emits_one_allreduce_per_batchnorm():
     for fa, ba, sr, co, n, calls in _spawn(_plan_with_syncbn):
         assert (fa, ba, sr, co, n) == (312, 312, 312, 312, 2)
-        assert calls < 400          # the exchanges of one dependency level share a grouped collective call
+        # the exchanges of one dependency level are ONE all-reduce of a shared arena; the count cannot fall below the depth of
+        # the network in BatchNorms (~150 per direction: every exchange on the critical path waits for the one before it)
+        assert calls < 400
+
+
+def _train_step_collectives(rank, world):
+    """The FULL fused train step (forward, CE, backward, bucketed gradient all-reduce, SGD) replayed with stubbed kernels:
+    every rank must issue the identical collective sequence (deadlock safety), the SyncBN exchanges must be one per
+    dependency level, and the bucketed gradient all-reduce must equal a single all-reduce of the flat buffer."""
+    import ctypes
+    import addk.plan as P
+    import addk.train as T
+    from addk import parallel
+    from addk.modeling.ADD import ADD
+    from _util import ARCH_C2, GENOTYPE_AUTODEEPLAB, make_args
+
+    def dry_run(self, cmds, stream):             # collectives run for real (gloo); kernel launches are skipped
+        for c in cmds:
+            if c.name in ('allreduce', 'allreduce_packed', 'grad_allreduce'):
+                assert c.fn(*c.args, stream) == 0
+    P.Graph.run = dry_run
+    P.require_device = lambda x: None
+    T._plan.require_device = lambda x: None
+    P.current_stream = lambda: 0
+    torch.cuda.current_stream = lambda *a, **k: type('S', (), {'cuda_stream': 0})()
+    comm = parallel.init_sync_bn()
+    comm.log = []
+    torch.manual_seed(0)
+    m = ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4, sync_bn=True), 0).train()
+    ts = T.TrainStep(m, (2, 3, 65, 129), sync_comm=comm, use_graph=False, nstreams=2)
+    ts._sgd = lambda st: None
+    assert ts.world == world and ts.gsync is not None
+    # buckets: contiguous, disjoint, covering the flat gradient buffer
+    bk = sorted(ts.gsync.buckets)
+    assert bk[0][0] == 0 and bk[-1][1] == ts.flat_g.numel() and all(a[1] == b[0] for a, b in zip(bk, bk[1:])) and len(bk) >= 2
+    # every bucket's all-reduce sits behind the last launch that writes into it
+    names = [c.name for c in ts.g.bwd]
+    pos = [i for i, n in enumerate(names) if n == 'grad_allreduce']
+    assert len(pos) == len(bk) and pos[0] < len(names) - 1, 'first bucket must be issued before the end of the backward list'
+    base = ts.flat_g.untyped_storage().data_ptr()
+    for i in pos:
+        lo, hi = ts.g.bwd[i].wr[0][1], ts.g.bwd[i].wr[0][2]
+        later = [c.name for c in ts.g.bwd[i + 1:] if c.name != 'grad_allreduce' and any(r[0] == base and r[1] < hi and lo < r[2] for r in c.wr)]
+        assert not later, later
+    ts.flat_g.fill_(float(rank + 1))
+    ts.step()
+    tri = world * (world + 1) / 2
+    assert torch.equal(ts.flat_g, torch.full_like(ts.flat_g, tri))       # bucketed == one all-reduce of the whole buffer
+    nstats = sum(1 for k in comm.log if k[0] == 'stats')
+    return comm.log, nstats, len(bk)
+
+
+def test_train_step_collective_sequence_is_identical_on_all_ranks():
+    r = _spawn(_train_step_collectives)
+    assert r[0][0] == r[1][0] and len(r[0][0]) > 0        # same kinds, sizes and dtypes in the same order on both ranks
+    assert r[0][1] < 400                                   # SyncBN: one exchange per dependency level (312 + 312 BatchNorm calls)
+    kinds = [k[0] for k in r[0][0]]
+    assert 'grad' in kinds and kinds.index('grad') < len(kinds) - 1 - kinds[::-1].index('stats'), 'a gradient bucket overlaps the backward pass'
+
+
+def _ddp_without_syncbn(rank, world):
+    """The reference's DDP without --sync-bn: gradients are still averaged (world came from the SyncBN comm)."""
+    import addk.plan as P
+    import addk.train as T
+    from addk.modeling.ADD import ADD
+    from _util import ARCH_C2, GENOTYPE_AUTODEEPLAB, make_args
+    P.Graph.run = lambda self, cmds, stream: [c.fn(*c.args, stream) for c in cmds if c.name == 'grad_allreduce'] and None
+    P.require_device = lambda x: None
+    T._plan.require_device = lambda x: None
+    P.current_stream = lambda: 0
+    torch.cuda.current_stream = lambda *a, **k: type('S', (), {'cuda_stream': 0})()
+    m = ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4, sync_bn=False), 0).train()
+    ts = T.TrainStep(m, (2, 3, 65, 129), sync_comm=None, use_graph=False)
+    seen = {}
+    ts._sgd = lambda st: seen.setdefault('scale', 1.0 / ts.world)
+    ts.flat_g.fill_(float(rank + 1))
+    ts.step()
+    return ts.world, float(ts.flat_g.min()), float(ts.flat_g.max()), seen['scale'], sum(1 for c in ts.g.fwd if 'allreduce' in c.name)
+
+
+def test_gradients_are_averaged_without_syncbn():
+    for world, lo, hi, scale, nstat in _spawn(_ddp_without_syncbn):
+        assert world == 2 and lo == hi == 3.0 and scale == 0.5 and nstat == 0
