@@ -412,7 +412,7 @@ class Graph:
         branches per level, so the 312 finalize / 312 backward / 312 apply launches of a step — each a ~10 us latency
         chain on the critical path — shrink to one launch per level.  Commands of one level never depend on each other,
         so any order inside a level is valid; program order of the original list is kept."""
-        level = self._levels(lst)
+        level = Graph._levels(lst)
         buckets = collections.defaultdict(list)
         for i, c in enumerate(lst):
             buckets[level[i]].append(c)
