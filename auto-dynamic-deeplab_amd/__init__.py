@@ -13,10 +13,12 @@ __version__ = '0.1.0'
 
 
 def set_precision(mode):
-    """'fp32' (default: exact fp32 MFMA, the parity path) or 'bf16x3' (3-term split-bf16 MFMA, ~1.5e-5 relative per
-    product) for the dense convolution forward/data-gradient kernels.  Process-wide."""
-    _lib.check(load().addk_set_conv_precision({'fp32': 0, 'bf16x3': 1}[mode]), 'set_precision')
+    """Arithmetic of the halo-patch convolutions (wide k x k stride-1 convs, forward and data gradient): 'fp32' = exact fp32
+    MFMA; 'bf16x6' = every operand split into three bf16 terms, six product terms on the bf16 matrix pipe with fp32
+    accumulation (as accurate as the fp32 MFMA chain, 2.5x its rate); 'bf16x3' = three terms (fast mode, ~5e-7 rms per
+    dot product).  Process-wide; set it before plans are built (packed-weight buffers are sized per mode)."""
+    _lib.check(load().addk_set_conv_precision({'fp32': 0, 'bf16x3': 1, 'bf16x6': 2}[mode]), 'set_precision')
 
 
 def get_precision():
-    return ('fp32', 'bf16x3')[load().addk_get_conv_precision()]
+    return ('fp32', 'bf16x3', 'bf16x6')[load().addk_get_conv_precision()]

@@ -16,6 +16,11 @@ int addk_check_launch(const char* what);
     }                                              \
   } while (0)
 
+// arithmetic of the halo-patch convolutions when neither ADDK_MATH nor addk_set_conv_precision says otherwise (conv.hip)
+#ifndef ADDK_DEFAULT_PRECISION
+#define ADDK_DEFAULT_PRECISION 0
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -15,6 +15,7 @@
 //
 // Reference call sites: see include/addk.h (addk_conv_fwd / addk_conv_dgrad).
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -443,11 +444,17 @@ int pick_ct(int Cn, long ntiles) {
 }
 int pick_pt(long P) { return P >= 128L * 512 ? 2 : 1; }
 
-// Precision of the dense contractions: exact fp32 MFMA by default (the parity path); the 3-term split-bf16 form
-// (~1.5e-5 relative per product) is opt-in through addk_set_conv_precision(1) or ADDK_MATH=bf16x3.
+// Arithmetic of the wide k x k contractions (the halo-patch kernels of conv3.hip): 0 = exact fp32 MFMA
+// (v_mfma_f32_16x16x4_f32), 2 = split-bf16 with six product terms (fp32-equivalent accuracy at 2.5x the rate), 1 = three
+// terms (fast mode, ~5e-7 rms).  addk_set_conv_precision / ADDK_MATH=fp32|bf16x3|bf16x6.  Every other kernel is fp32.
 int g_prec = -1;
 int conv_precision() {
-  if (g_prec < 0) { const char* e = getenv("ADDK_MATH"); g_prec = (e && e[0] == 'b') ? PREC_B3 : PREC_F32; }
+  if (g_prec < 0) {
+    const char* e = getenv("ADDK_MATH");
+    g_prec = ADDK_DEFAULT_PRECISION;
+    if (e && e[0] == 'f') g_prec = 0;
+    else if (e && e[0] == 'b') g_prec = strstr(e, "x3") ? 1 : 2;
+  }
   return g_prec;
 }
 
@@ -475,11 +482,9 @@ int launch(ConvK& k, hipStream_t st, int grid_x = 0) {
   k.red32 = k.P >= 4096;
   const int ct = pick_ct(k.Cn, k.ntiles);
   dim3 grid(grid_x > 0 ? grid_x : addk_conv_rows(k.P, k.Cn), cdiv(k.Cn, 16 * ct));   // workgroups beyond ntiles only write their (zero) slab row
-  const int prec = conv_precision();
 #define ADDK_CASE(PT_, CT_) \
   if (pt == PT_ && ct == CT_) { \
-    if (prec == PREC_B3) hipLaunchKernelGGL((conv_kernel<PT_, CT_, MODE, PREC_B3>), grid, dim3(256), 0, st, k); \
-    else hipLaunchKernelGGL((conv_kernel<PT_, CT_, MODE, PREC_F32>), grid, dim3(256), 0, st, k); \
+    hipLaunchKernelGGL((conv_kernel<PT_, CT_, MODE, PREC_F32>), grid, dim3(256), 0, st, k); \
     return addk_check_launch("conv"); }
   ADDK_CASE(1, 2) ADDK_CASE(1, 3) ADDK_CASE(1, 4) ADDK_CASE(1, 5) ADDK_CASE(1, 8)
   ADDK_CASE(2, 2) ADDK_CASE(2, 3) ADDK_CASE(2, 4) ADDK_CASE(2, 5) ADDK_CASE(2, 8)
@@ -500,7 +505,7 @@ __global__ void mfma_selftest_kernel(float* out) {
 }  // namespace
 
 extern "C" int addk_set_conv_precision(int mode) {
-  if (mode != PREC_F32 && mode != PREC_B3) { addk_set_error("conv precision must be 0 (fp32) or 1 (bf16x3)"); return ADDK_ERR_INVALID; }
+  if (mode < 0 || mode > 2) { addk_set_error("conv precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)"); return ADDK_ERR_INVALID; }
   g_prec = mode;
   return ADDK_OK;
 }
@@ -539,7 +544,7 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
   }
   ADDK_REQUIRE(a->w_choff + ctot <= a->cin_total, "conv_fwd: sources exceed cin_total");
   ADDK_REQUIRE(a->ldw >= a->KH * a->KW * a->cin_total, "conv_fwd: ldw too small");
-  if (conv_precision() == PREC_F32 && pw_enabled()) {      // small pointwise shapes: register-stationary kernel (pw.hip)
+  if (pw_enabled()) {      // small pointwise shapes: register-stationary kernel (pw.hip)
     int r = addk_pw_try_fwd(a, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), stream);
     if (r <= 0) return r;
   }
@@ -569,7 +574,7 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
   ADDK_REQUIRE(a->lddy >= a->Cout && a->ldg >= a->dst.C && a->dst.ld >= a->dst.C, "conv_dgrad: short stride");
   ADDK_REQUIRE(a->w_choff + a->dst.C <= a->cin_total && a->ldw >= a->KH * a->KW * a->cin_total, "conv_dgrad: weight layout");
   ADDK_REQUIRE((a->dst.a == nullptr) == (a->dst.b == nullptr), "conv_dgrad: a/b must come together");
-  if (conv_precision() == PREC_F32 && pw_enabled()) {
+  if (pw_enabled()) {
     int r = addk_pw_try_dgrad(a, addk_conv_rows((long)a->N * a->H * a->W, a->dst.C), stream);
     if (r <= 0) return r;
   }

@@ -53,6 +53,7 @@ struct PackK {
   int cbase[C3_MAXCH];      // first K index of the chunk (fwd: absolute channel inside a tap; dgrad: co)
   int cvalid[C3_MAXCH];     // valid K entries in the chunk (<= 16)
   float* out;
+  int planes;               // 0: fp32 fragments for conv3_kernel; 2 / 3: bf16 planes (h, m[, l]) in 32-row fragment order for conv3b_kernel
 };
 
 // out[colblk][T = chunk*taps + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
@@ -62,7 +63,9 @@ __global__ void __launch_bounds__(256) c3_pack_kernel(const PackK p) { c3_pack_b
 __global__ void __launch_bounds__(256) c3_pack_batch_kernel(const PackK* __restrict__ descs) {
   c3_pack_body(descs[blockIdx.y], (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
+__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride);
 __device__ __forceinline__ void c3_pack_body(const PackK& p, long first, long stride) {
+  if (p.planes) { c3b_pack_body(p, first, stride); return; }
   const int BC = 16 * p.bct;
   const int nT = p.nchunks * p.taps;
   const long per_blk = (long)nT * p.bct * 256;
@@ -320,7 +323,313 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
   }
 }
 
+
+// ======================================================================================================================
+// Split-bf16 form of the same halo-patch convolution: every fp32 operand is written as x = h + m + l with h, m, l in bf16
+// (3 x 8 significand bits = the 24 of fp32, exactly) and a product is evaluated on the bf16 matrix pipe
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation) as the sum of its six largest bf16 x bf16 terms
+//     x*w  ~=  l*wh + h*wl + m*wm + m*wh + h*wm + h*wh          (dropped: m*wl, l*wm, l*wl  ~ 2^-26 relative)
+// Measured (scripts/bf16_split_probe.hip, K = 2048, random magnitudes over 6 octaves): max |err| / sum|a*b| = 3.0e-7, rms 5.6e-8 —
+// the same as the exact-fp32 v_mfma_f32_16x16x4_f32 chain (3.2e-7 / 6.8e-8) — at 6 x 16 = 96 matrix-pipe cycles per
+// 16x16x32 block of fp32 work instead of 256: 2.5x the fp32 MFMA rate (374 vs 149 TFLOP/s from registers).  The 3-term form
+// (h*wh + m*wh + h*wm, planes = 2) is the opt-in fast mode: 656 TFLOP/s, rms error 4.7e-7.
+//
+// Structure.  A block owns 128 pixels of one output row x (32 * WC) output channels; WAVE w owns channels [32w, 32w+32) of ALL
+// 128 pixels (four 32x32 accumulator tiles): the pixel fragments are shared through LDS (which has the bandwidth: 128 B/clk
+// per CU at 8 waves), the weight fragments are private to a wave and stream from L1/L2 (32 B/clk).  K is walked in
+// 16-channel chunks = one MFMA k-step; per chunk the KS input rows are staged ONCE: fp32 loads, lazy BatchNorm/ReLU prologue,
+// zero padding, then the split into planes — so the ~6 VALU operations per element of the split are paid once per staged
+// element, not per use (each element feeds KS*KS * 6 * WC MFMA operands).  LDS image per plane: [row][pixel][16 ch] bf16 =
+// 32 B per pixel, the two 16-byte halves of a pixel swapped when bit 3 of the pixel index is set: the ds_read_b128 of a
+// 32-pixel fragment then touches all 64 banks once per 16-lane group for every tap shift (no padding needed).
+// ======================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CB_PT = 4;                   // 32-pixel tiles per wave (128 pixels)
+constexpr int cb_pwmax(int ks, bool bigd) { return ks == 3 ? (bigd ? C3_BP + 2 * 18 : C3_BP + 2 * 2) : C3_BP + 4 * 2; }
+
+__device__ __forceinline__ unsigned bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b << 16); }
+// 4 floats -> 4 bf16 per plane (8 bytes each)
+template <int NP>
+__device__ __forceinline__ void split4(const float4 v, uint2 (&pl)[NP]) {
+  float r[4] = {v.x, v.y, v.z, v.w};
+  unsigned b[NP][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = r[e];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { b[k][e] = bf16_hi(x); x = x - bf16_f(b[k][e]); }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) pl[k] = make_uint2(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16));
+}
+
+// packed weights: out (16-byte units) [colblk][T = chunk*taps + tap][tile (wave) i][plane][lane] = 8 bf16:
+//   W(row = colblk*32*bct + i*32 + (lane & 31), tap, k = 8*(lane >> 5) + j), j = 0..7       (bct = 32-row tiles per block)
+__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride) {
+  const int BC = 32 * p.bct, NP = p.planes;
+  const int nT = p.nchunks * p.taps;
+  const long per_blk = (long)nT * p.bct * 64;
+  const long total = (long)((p.Cn + BC - 1) / BC) * per_blk;
+  uint4* out = reinterpret_cast<uint4*>(p.out);
+  for (long idx = first; idx < total; idx += stride) {
+    const int lane = (int)(idx & 63);
+    long r = idx >> 6;
+    const int i = (int)(r % p.bct); r /= p.bct;
+    const int T = (int)(r % nT); const int blk = (int)(r / nT);
+    const int chunk = T / p.taps, tap = T - chunk * p.taps;
+    const int row = blk * BC + i * 32 + (lane & 31), k0 = 8 * (lane >> 5);
+    unsigned b[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      const int kk = k0 + j;
+      if (row < p.Cn && kk < p.cvalid[chunk]) {
+        if (p.mode == MODE_FWD) v = p.w[(long)row * p.ldw + (long)tap * p.cin_total + p.cbase[chunk] + kk];
+        else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
+    }
+    uint4* o = out + (((long)blk * nT + T) * p.bct + i) * NP * 64 + lane;
+    for (int k = 0; k < NP; ++k)
+      o[k * 64] = make_uint4(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16), b[k][4] | (b[k][5] << 16), b[k][6] | (b[k][7] << 16));
+  }
+}
+
+template <int WC, int KS, int MODE, int NP, bool BIGD>
+__global__ void __launch_bounds__(64 * WC, (KS == 5 && WC <= 3) ? 1 : 2) conv3b_kernel(const C3K p) {
+  constexpr int BC = 32 * WC, NTHR = 64 * WC;
+  constexpr int TAPS = KS * KS, HK = KS / 2;
+  constexpr int PWP = cb_pwmax(KS, BIGD);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
+  constexpr int NS = (KS * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
+  static_assert(NS <= 32, "slot mask is 32 bits");
+  constexpr int PLANE = KS * PWP * 2;                             // uint4 units per plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* red = reinterpret_cast<double*>(smem);                  // [BC][2] running statistics of this block
+  uint4* Pl = reinterpret_cast<uint4*>(smem + ((BC * 16 + 15) & ~15));   // [NP][KS][PWP][2] 16-byte halves
+  uint2* Pl2 = reinterpret_cast<uint2*>(Pl);
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lp32 = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.y * BC;
+  const int d = p.dil, PW = C3_BP + (KS - 1) * d;
+  for (int i = t; i < BC * 2; i += NTHR) red[i] = 0.0;
+
+  const int q = t & 3;
+  // fragment read base per kernel column: pixel lane%32 + kw*d of patch row 0, the 16-byte half swizzled by bit 3 of the pixel
+  // (tile j adds 32 pixels: bit 3 unchanged); patch row kh and tile j are immediate offsets
+  int xb[KS];
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) { const int pj = lp32 + kw * d; xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)); }
+  const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)blockIdx.y * p.wp_blk + (long)wave * NP * 64 + lane);
+  const int nT = p.nT;
+
+  const int tpx = p.ntiles >> 3;
+  const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
+  for (int tlin = blockIdx.x; tlin < p.ntiles; tlin += gridDim.x) {
+    const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
+    const int rowid = tile / p.spr, sx = tile - rowid * p.spr;
+    const int n = rowid / p.H, oh = rowid - n * p.H;
+    const int ow0 = sx * C3_BP;
+    unsigned vmask = 0;
+    const int pbase = (n * p.H + oh - HK * d) * p.W + ow0 - HK * d;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int pix = (t + NTHR * k) >> 2;
+      const int r = pix / PWP, pj = pix - r * PWP;
+      const int ih = oh + (r - HK) * d, iw = ow0 - HK * d + pj;
+      const bool ok = r < KS && pj < PW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      vmask |= (ok ? 1u : 0u) << k;
+    }
+
+    f32x16 acc[CB_PT];
+#pragma unroll
+    for (int j = 0; j < CB_PT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    float4 ra[NS];
+    float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4();
+    bool prelu = false, pch = false;
+    auto load_patch = [&](int s_, int c0_) {      // branch-free: masked slots read the source base and are zeroed at store time
+      const addk_src S = p.src[s_];
+      const int c = c0_ + 4 * q;
+      pch = c < S.C;
+      prelu = S.relu != 0;
+      pa = make_float4(1.f, 1.f, 1.f, 1.f); pb = zero4();
+      if (S.a && pch) { pa = ld4(S.a + c); pb = ld4(S.b + c); }
+      const float* sb = S.x + (pch ? c : 0);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int pix = (t + NTHR * k) >> 2;
+        const int r = pix / PWP, pj = pix - r * PWP;
+        const int po = ((vmask >> k) & 1u) ? pbase + r * d * p.W + pj : 0;
+        ra[k] = ld4(sb + (long)po * S.ld);
+      }
+    };
+    auto store_patch = [&]() {                    // prologue, zero padding, split into planes
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        float4 v = ra[k];
+        v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
+        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const bool ok = pch && ((vmask >> k) & 1u);
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        const int pix = (t + NTHR * k) >> 2;
+        const int r = pix / PWP, pj = pix - r * PWP;
+        if (r < KS) {
+          uint2 pl[NP];
+          split4<NP>(v, pl);
+          const int slot = (r * PWP + pj) * 2 + ((q >> 1) ^ ((pj >> 3) & 1));
+#pragma unroll
+          for (int m = 0; m < NP; ++m) Pl2[(m * PLANE + slot) * 2 + (q & 1)] = pl[m];
+        }
+      }
+    };
+    // weight fragments of one tap: NP planes x 16 bytes per lane, the next tap's set is fetched while this tap's MFMAs issue
+    auto load_w = [&](int T, uint4* dst) {
+      const int Tc = T < nT ? T : nT - 1;
+      const uint4* src = wpl + (long)Tc * (WC * NP * 64);
+#pragma unroll
+      for (int m = 0; m < NP; ++m) dst[m] = src[m * 64];
+    };
+    // pixel fragment of (tap, tile j): lane reads 16 bytes of pixel (32 j + lane%32 + kw*d) in patch row kh, k half lane/32
+    auto read_x = [&](int tap, int j, uint4* x) {
+      const int kh = tap / KS, kw = tap - kh * KS;
+      const uint4* b = Pl + xb[kw];
+#pragma unroll
+      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + (kh * PWP + j * 32) * 2];
+    };
+    auto mma = [&](f32x16& c, const uint4* w, const uint4* x) {
+      auto W = [&](int m) { return __builtin_bit_cast(bf16x8, w[m]); };
+      auto X = [&](int m) { return __builtin_bit_cast(bf16x8, x[m]); };
+      if (NP == 3) {          // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(2), X(0), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(2), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(1), c, 0, 0, 0);
+      }
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(0), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(1), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(0), c, 0, 0, 0);
+    };
+
+    int s = 0, c0 = 0, T0 = 0;
+    uint4 wr[2][NP], xr[2][NP];
+    load_w(0, wr[0]);
+    load_patch(0, 0);
+    __syncthreads();                 // every wave is done with the previous tile's patch (and red[] is initialised)
+    store_patch();
+    __syncthreads();
+    while (true) {
+      int s2 = s, c2 = c0 + C3_BK;
+      if (c2 >= p.src[s].C) { c2 = 0; ++s2; }
+      const bool more = s2 < p.nsrc;
+      read_x(0, 0, xr[0]);
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        load_w(T0 + tap + 1, wr[(tap + 1) & 1]);
+        if (tap == 0 && more) load_patch(s2, c2);
+#pragma unroll
+        for (int j = 0; j < CB_PT; ++j) {
+          const int nj = (j + 1) % CB_PT, ntap = tap + (j + 1) / CB_PT;
+          if (ntap < TAPS) read_x(ntap, nj, xr[(tap * CB_PT + j + 1) & 1]);
+          mma(acc[j], wr[tap & 1], xr[(tap * CB_PT + j) & 1]);
+        }
+      }
+      T0 += TAPS;
+      if (TAPS & 1) {
+#pragma unroll
+        for (int m = 0; m < NP; ++m) wr[0][m] = wr[1][m];      // odd tap count: the set fetched during the last tap is next chunk's tap 0
+      }
+      __syncthreads();
+      if (!more) break;
+      s = s2; c0 = c2;
+      store_patch();
+      __syncthreads();
+    }
+
+    // ---- epilogue: lane holds pixel (32 j + lane%32), channels n0 + 32 wave + 8 g + 4 (lane/32) + {0..3}, g = 0..3 ----
+    const bool want_red = p.slab != nullptr;
+    float s1[4][4], s2v[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[g][e] = 0.f; s2v[g][e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < CB_PT; ++j) {
+      const int lp = j * 32 + lp32;
+      const long pp = (long)rowid * p.W + ow0 + lp;
+      const bool pin = ow0 + lp < p.W;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = n0 + wave * 32 + 8 * g + 4 * hh;
+        const int nrem = p.Cn - c;
+        if (!pin || nrem <= 0) continue;
+        float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+        if (MODE == MODE_FWD) {
+          if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+          if (p.bias_n) {
+            float4 b = ld4g(p.bias_n + (long)n * p.Cn + c, nrem, false);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          st4g(p.y + pp * p.ldy + c, v, nrem, p.vecY);
+          if (want_red) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float f = (e < nrem) ? get4(v, e) : 0.f; s1[g][e] += f; s2v[g][e] += f * f; }
+          }
+        } else {
+          float4 x = ld4g(p.dst.x + pp * p.dst.ld + c, nrem, p.vecY);
+          float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+          if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, p.vecY); bv = ld4g(p.dst.b + c, nrem, p.vecY); }
+          float4 gq;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), dz = get4(v, e);
+            const bool m = (e < nrem) && (!p.dst.relu || fmaf(ae, xe, be) > 0.f);
+            set4(gq, e, m ? dz * ae : 0.f);
+            if (want_red && m) { s1[g][e] += dz * xe; s2v[g][e] += dz; }
+          }
+          float* gp = p.y + pp * p.ldy + c;
+          if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vecY); gq.x += o.x; gq.y += o.y; gq.z += o.z; gq.w += o.w; }
+          st4g(gp, gq, nrem, p.vecY);
+        }
+      }
+    }
+    if (want_red) {          // a wave owns its 32 channels alone: butterfly over the 32 pixel lanes, one lane per half adds into red[]
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = s1[g][e], b = s2v[g][e];
+#pragma unroll
+          for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+          if (lp32 == 0) { double* r = red + (wave * 32 + 8 * g + 4 * hh + e) * 2; r[0] += (double)a; r[1] += (double)b; }
+        }
+    }
+  }
+  if (p.slab) {
+    __syncthreads();
+    if (t < BC && n0 + t < p.Cn) {
+      double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+      o[0] = red[2 * t]; o[1] = red[2 * t + 1];
+    }
+  }
+}
+
+// 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 2..5 that pads the channel count least (ties: the wider)
+int c3b_wc(int Cn) {
+  int best = 4; long bc = -1;
+  const int cands[4] = {4, 5, 3, 2};
+  for (int i = 0; i < 4; ++i) {
+    const long cols = (long)cdiv(Cn, 32 * cands[i]) * 32 * cands[i];
+    if (bc < 0 || cols < bc) { bc = cols; best = cands[i]; }
+  }
+  return best;
+}
+
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
+inline int c3_planes() { const int m = addk_get_conv_precision(); return m == 2 ? 3 : m == 1 ? 2 : 0; }   // 0: exact fp32 MFMA kernel
 // Column block (16-channel tiles per block).  128-channel blocks (2x2 waves) for the wide heads when that still
 // yields >= 512 blocks; otherwise the narrowest of 3/4/5 tiles that pads the channel count least (cells: 40 -> 3 tiles,
 // 80 and 160 -> 5 tiles; stem / small ASPP maps: 4 tiles).
@@ -336,15 +645,56 @@ int c3_bct(int Cn, long P) {
   return best;
 }
 long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
+  if (const int np = c3_planes()) {            // bf16 planes: 1 KB per (tap, 32-row tile, plane)
+    const int wc = c3b_wc(Cn);
+    return (long)cdiv(Cn, 32 * wc) * nchunks * taps * wc * np * 256;
+  }
   const int bct = c3_bct(Cn, P);
   return (long)cdiv(Cn, 16 * bct) * nchunks * taps * bct * 256;
 }
 bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn) {
   if (!c3_enabled() || KH != KW || !(KH == 3 || KH == 5) || stride != 1 || dil < 1 || dil > c3_maxdil(KH)) return false;
-  return pad == dil * (KH / 2) && OH == H && OW == W && W >= 100 && P >= 8192 && Cn >= 32 && addk_get_conv_precision() == 0;
+  return pad == dil * (KH / 2) && OH == H && OW == W && W >= 100 && P >= 8192 && Cn >= 32;
+}
+
+int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
+  const int wc = c3b_wc(k.Cn);
+  pk.bct = wc; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np;
+  k.nT = pk.nchunks * pk.taps;
+  k.wp = pk.out;
+  k.wp_blk = (long)pk.nchunks * pk.taps * wc * np * 64;          // 16-byte units per column block
+  k.spr = cdiv(k.W, C3_BP);
+  k.ntiles = k.N * k.H * k.spr;
+  k.red32 = 1;
+  if (desc_out) { *desc_out = pk; return ADDK_OK; }
+  const long total = (long)cdiv(k.Cn, 32 * wc) * k.nT * wc * 64;   // pack threads: one per (tile, lane)
+  int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
+  if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
+  const bool bigd = pk.taps == 9 && k.dil > 2;
+  const int ks = pk.taps == 9 ? 3 : 5;
+  const size_t lds = (size_t)((32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd) * 32;
+  dim3 grid(rows, cdiv(k.Cn, 32 * wc));
+  bool done = false;
+#define ADDK_C3B_(W_, K_, M_, P_, D_) { \
+    static bool attr = false; \
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, D_>), grid, dim3(64 * W_), lds, st, k); done = true; }
+#define ADDK_C3B(W_, K_, D_) \
+  if (!done && wc == W_ && ks == K_ && bigd == D_) { \
+    if (mode == MODE_FWD) { if (np == 3) ADDK_C3B_(W_, K_, MODE_FWD, 3, D_) else ADDK_C3B_(W_, K_, MODE_FWD, 2, D_) } \
+    else { if (np == 3) ADDK_C3B_(W_, K_, MODE_DGRAD, 3, D_) else ADDK_C3B_(W_, K_, MODE_DGRAD, 2, D_) } }
+  ADDK_C3B(2, 3, false) ADDK_C3B(3, 3, false) ADDK_C3B(4, 3, false) ADDK_C3B(5, 3, false)
+  ADDK_C3B(3, 3, true) ADDK_C3B(4, 3, true) ADDK_C3B(5, 3, true) ADDK_C3B(2, 3, true)
+  ADDK_C3B(2, 5, false) ADDK_C3B(3, 5, false) ADDK_C3B(4, 5, false) ADDK_C3B(5, 5, false)
+#undef ADDK_C3B
+#undef ADDK_C3B_
+  if (!done) { addk_set_error("conv3b: no instantiation for %d waves, %d taps", wc, pk.taps); return ADDK_ERR_UNSUPPORTED; }
+  return addk_check_launch("conv3b");
 }
 
 int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out = nullptr) {
+  pk.planes = 0;
+  if (const int np = c3_planes()) return c3b_launch(k, pk, mode, rows, st, packed, desc_out, np);
   const int bct = c3_bct(k.Cn, k.P);
   pk.bct = bct; pk.mode = mode; pk.Cn = k.Cn;
   k.nT = pk.nchunks * pk.taps;

@@ -445,13 +445,13 @@ int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
 // ---- batched form: mutually independent pointwise convs (one dependency level of the cell DAG) in one launch -------
 // key >= 0: the launch runs on pw_kernel with that template variant (launches with equal keys can share a batch); -1: not
 extern "C" int addk_conv_fwd_batch_key(const addk_conv_args* a) {
-  if (!a || addk_get_conv_precision() != 0 || !(addk_get_fast_paths() & ADDK_FAST_PW)) return -1;
+  if (!a || !(addk_get_fast_paths() & ADDK_FAST_PW)) return -1;
   PwK k; PwCfg c;
   if (!pw_fill_fwd(a, k) || !pw_config(k, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), c)) return -1;
   return pw_key(c, PW_FWD);
 }
 extern "C" int addk_conv_dgrad_batch_key(const addk_conv_dgrad_args* a) {
-  if (!a || addk_get_conv_precision() != 0 || !(addk_get_fast_paths() & ADDK_FAST_PW)) return -1;
+  if (!a || !(addk_get_fast_paths() & ADDK_FAST_PW)) return -1;
   PwK k; PwCfg c;
   if (!pw_fill_dgrad(a, k) || !pw_config(k, addk_conv_rows((long)a->N * a->H * a->W, a->dst.C), c)) return -1;
   return pw_key(c, PW_DGRAD);

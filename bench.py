@@ -122,7 +122,7 @@ def main():
     ap.add_argument('--F', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--math', choices=['fp32', 'bf16x3'], default='fp32', help='dense-conv arithmetic (default: exact fp32 MFMA)')
+    ap.add_argument('--math', choices=["fp32", "bf16x6", "bf16x3"], default='fp32', help='dense-conv arithmetic (default: exact fp32 MFMA)')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--force-sync', action='store_true', help='rehearse the N>1 path (RCCL SyncBN + gradient all-reduce) at world_size 1')
     a = ap.parse_args()

@@ -35,18 +35,25 @@ def lib():
     assert torch.cuda.is_available()
     import addk
     from addk import _lib as L
+    prec = L.load().addk_get_conv_precision()
     yield L
     L.load().addk_set_fast_paths(FAST_ALL)
+    L.load().addk_set_conv_precision(prec)
 
 
 def _rel(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 
 
-def _run(L, fast, shape, data):
-    """One forward + data gradient + weight gradient through the C ABI with the given fast-path mask."""
+PREC = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2}
+
+
+def _run(L, fast, shape, data, prec='fp32'):
+    """One forward + data gradient + weight gradient through the C ABI with the given fast-path mask and arithmetic of the
+    halo-patch convolutions (exact fp32 MFMA / split-bf16 with 6 or 3 product terms)."""
     lib = L.load()
     lib.addk_set_fast_paths(fast)
+    L.check(lib.addk_set_conv_precision(PREC[prec]), 'set_conv_precision')
     name, N, H, W, Cs, Cout, dil, ks = shape
     taps, pad = ks * ks, dil * (ks // 2)
     dev = data['w'].device
@@ -129,8 +136,11 @@ def _reference(shape, data):
             'dw': w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)}
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x6', 'bf16x3'])
 @pytest.mark.parametrize('shape', SHAPES, ids=[s[0] for s in SHAPES])
-def test_halo_patch_kernels_match_fp64_reference_and_generic(lib, shape):
+def test_halo_patch_kernels_match_fp64_reference_and_generic(lib, shape, prec):
+    """bf16x6 (x = h + m + l in bf16, six product terms on the bf16 matrix pipe) is held to the SAME 2e-5 bound as the exact
+    fp32 MFMA kernel; the 3-term fast mode to 2e-4."""
     name, N, H, W, Cs, Cout, dil, ks = shape
     dev = torch.device('cuda:0')
     gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
@@ -139,17 +149,23 @@ def test_halo_patch_kernels_match_fp64_reference_and_generic(lib, shape):
     data = {'x': [rnd(P, c) for c in Cs], 'a': [rnd(c) for c in Cs], 'b': [0.3 * rnd(c) for c in Cs],
             'w': 0.1 * rnd(Cout, ks * ks * sum(Cs)), 'dy': rnd(P, Cout)}
     ref = _reference(shape, data)
-    fast = _run(lib, FAST_ALL, shape, data)
+    fast = _run(lib, FAST_ALL, shape, data, prec)
     slow = _run(lib, 0, shape, data)
-    bad = []
+    tol = 2e-4 if prec == 'bf16x3' else TOL
+    bad, log = [], []
     for tag, got in (('fast', fast), ('generic', slow)):
         errs = {'y': _rel(got['y'], ref['y']), 'stats': _rel(got['stats'], ref['stats']), 'dw': _rel(got['dw'], ref['dw'])}
         for i in range(len(Cs)):
             errs['g%d' % i] = _rel(got['g'][i], ref['g'][i])
             errs['dab%d' % i] = _rel(got['dab'][i], ref['dab'][i])
-        bad += ['%s/%s %.2e' % (tag, k, v) for k, v in errs.items() if not v <= TOL]
-    assert not bad, 'beyond %.0e of the fp64 reference: %s' % (TOL, ', '.join(bad))
-    assert _rel(fast['y'], slow['y']) <= 1e-5 and _rel(fast['dw'], slow['dw']) <= 1e-5
+        bad += ['%s/%s %.2e' % (tag, k, v) for k, v in errs.items() if not v <= (tol if tag == 'fast' else TOL)]
+        log.append('%s[%s] %s: %s' % (name, prec, tag, ' '.join('%s %.1e' % kv for kv in errs.items())))
+    import os
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/halo_kernel_errors.txt', 'a') as f:
+        f.write('\n'.join(log) + '\n')
+    assert not bad, 'beyond %.0e of the fp64 reference: %s' % (tol, ', '.join(bad))
+    assert _rel(fast['y'], slow['y']) <= (1e-4 if prec == 'bf16x3' else 1e-5) and _rel(fast['dw'], slow['dw']) <= 1e-5
 
 
 DW_SHAPES = [
