@@ -399,7 +399,7 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
 }
 
 template <int WC, int KS, int MODE, int NP, bool BIGD>
-__global__ void __launch_bounds__(64 * WC, (KS == 5 && WC <= 3) ? 1 : 2) conv3b_kernel(const C3K p) {
+__global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
   constexpr int BC = 32 * WC, NTHR = 64 * WC;
   constexpr int TAPS = KS * KS, HK = KS / 2;
   constexpr int PWP = cb_pwmax(KS, BIGD);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
@@ -514,9 +514,13 @@ __global__ void __launch_bounds__(64 * WC, (KS == 5 && WC <= 3) ? 1 : 2) conv3b_
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(0), c, 0, 0, 0);
     };
 
+    // Software pipeline, pinned with sched_barrier (left alone, the compiler sinks every prefetch down to its first use and the
+    // wave then waits out a full L2 round trip per tap): weight fragments are fetched TWO taps ahead into a ring of three
+    // register sets, pixel fragments one 32-pixel tile ahead, and the next chunk's patch is loaded to registers during tap 0.
     int s = 0, c0 = 0, T0 = 0;
-    uint4 wr[2][NP], xr[2][NP];
+    uint4 wr[3][NP], xr[2][NP];
     load_w(0, wr[0]);
+    load_w(1, wr[1]);
     load_patch(0, 0);
     __syncthreads();                 // every wave is done with the previous tile's patch (and red[] is initialised)
     store_patch();
@@ -528,19 +532,24 @@ __global__ void __launch_bounds__(64 * WC, (KS == 5 && WC <= 3) ? 1 : 2) conv3b_
       read_x(0, 0, xr[0]);
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
-        load_w(T0 + tap + 1, wr[(tap + 1) & 1]);
+        load_w(T0 + tap + 2, wr[(tap + 2) % 3]);
         if (tap == 0 && more) load_patch(s2, c2);
 #pragma unroll
         for (int j = 0; j < CB_PT; ++j) {
           const int nj = (j + 1) % CB_PT, ntap = tap + (j + 1) / CB_PT;
-          if (ntap < TAPS) read_x(ntap, nj, xr[(tap * CB_PT + j + 1) & 1]);
-          mma(acc[j], wr[tap & 1], xr[(tap * CB_PT + j) & 1]);
+          if (ntap < TAPS) read_x(ntap, nj, xr[(j + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(acc[j], wr[tap % 3], xr[j & 1]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       T0 += TAPS;
-      if (TAPS & 1) {
+      if (TAPS % 3) {                // the two sets fetched ahead sit in ring slots TAPS%3 and (TAPS+1)%3: rotate them to 0 and 1
+        uint4 t0[NP], t1[NP];
 #pragma unroll
-        for (int m = 0; m < NP; ++m) wr[0][m] = wr[1][m];      // odd tap count: the set fetched during the last tap is next chunk's tap 0
+        for (int m = 0; m < NP; ++m) { t0[m] = wr[TAPS % 3][m]; t1[m] = wr[(TAPS + 1) % 3][m]; }
+#pragma unroll
+        for (int m = 0; m < NP; ++m) { wr[0][m] = t0[m]; wr[1][m] = t1[m]; }
       }
       __syncthreads();
       if (!more) break;
@@ -617,11 +626,12 @@ __global__ void __launch_bounds__(64 * WC, (KS == 5 && WC <= 3) ? 1 : 2) conv3b_
   }
 }
 
-// 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 2..5 that pads the channel count least (ties: the wider)
+// 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 3..5 that pads the channel count least (ties: the wider)
 int c3b_wc(int Cn) {
+  if (Cn <= 64) return 2;                 // 2-wave blocks stage 13+ slots per thread (register spills): only where nothing wider fits
   int best = 4; long bc = -1;
-  const int cands[4] = {4, 5, 3, 2};
-  for (int i = 0; i < 4; ++i) {
+  const int cands[3] = {5, 4, 3};
+  for (int i = 0; i < 3; ++i) {
     const long cols = (long)cdiv(Cn, 32 * cands[i]) * 32 * cands[i];
     if (bc < 0 || cols < bc) { bc = cols; best = cands[i]; }
   }

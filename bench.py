@@ -7,7 +7,19 @@
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  Synthetic data (N(0,1) images, uniform labels with 5 % ignore), random-init
-weights of the named architecture, fp32 storage and arithmetic (dense contractions on the fp32 matrix cores).
+weights of the named architecture (kaiming-scaled normals keyed on parameter names, so the CPU oracle gets the SAME
+weights and the first-step loss can be asserted against it), fp32 storage; the wide k x k contractions run in the
+arithmetic `--math` names (library default otherwise; bf16x6 = fp32 operands as three bf16 terms, six product terms, fp32
+accumulation — as accurate as the fp32 MFMA chain).
+
+Besides the contract's fields the line carries, measured in this run on rank 0 at N=1:
+  roofline           dominant kernel (decoder 3x3) AND `segment`: the north-star "ASPP + cell forward" segment, eval and
+                     train mode, as fractions of the HBM roofline (SURVEY §8(d) algorithmic bytes) and of the MFMA peak
+  step_frac_mfma     whole-step algorithmic FLOP/s over the fp32 matrix peak
+  per_exit_ms        config 4: EDM-gated dynamic inference, early / final exit, 1024x2048 and 1025x2049, and the mean latency
+                     at 0 / 50 / 100 % early exits
+  drop_in            the same step through the reference's own call pattern (model(x); loss.backward(); torch.optim.SGD.step())
+  cpu_baseline       the CPU oracle on the same inputs (bounded sample), whose first-step loss the GPU loss is asserted against
 """
 import argparse
 import json
@@ -26,7 +38,13 @@ import torch         # noqa: E402
 NETWORK_ARCH = [1, 2, 2, 2, 3, 2, 2, 1, 1, 1, 1, 2]      # train.py:75-79 (searched-dense, C=2)
 C_INDEX = [5]
 PEAK_MFMA_F32_TFLOPS = 157.3                              # MI355X_MICROARCH.md: fp32 matrix peak (spec)
+PEAK_MFMA_BF16_TFLOPS = 2500.0                            # dense bf16 peak (spec)
 PEAK_HBM_GBS = 8000.0
+WEIGHT_SEED = 1001
+# SURVEY §8(d), per image, fp32, 1024x2048: inference algorithmic bytes / training-forward extra / forward conv FLOPs per segment
+ALG_GB = {'stem': 0.630, 'cell': 1.275 + 0.144 + 0.598 + 0.271 + 0.880, 'low': 0.033, 'aspp': 0.069, 'decoder': 0.358}
+TRAIN_EXTRA_GB = {'stem': 0.671, 'cell': 2.098, 'low': 0.013, 'aspp': 0.168, 'decoder': 0.268}
+GFLOP = {'stem': 59.8, 'cell': 120.75, 'low': 0.63, 'aspp': 104.7, 'decoder': 169.75}
 
 
 def make_args(F=20, B=5, sync_bn=False):
@@ -42,11 +60,18 @@ def synthetic_batch(n, h, w, seed, device):
     return x.to(device), t.to(device)
 
 
-def cpu_baseline(genotype, n, h, w):
+def init_weights(model):
+    """Random init of the architecture, keyed on parameter names (tests/_util.fill_params): conv ~ N(0, 2/fan_in) as
+    kaiming_normal_ gives, BN gamma ~ 1, beta ~ 0 with a small spread.  Identical in the oracle child."""
+    from _util import fill_params
+    return fill_params(model, WEIGHT_SEED)
+
+
+def cpu_baseline(n, h, w):
     """The CPU oracle (PyTorch-CPU restatement pinned to the reference by tests/golden) timed on this box's host
-    cores on the same workload: one full fwd+bwd+SGD step at bs=n (a bounded sample: the reference needs
-    ~14 s per step on 8 cores).  Runs in a child process with a time limit; if the full-size step does not finish
-    the sample is shrunk to a quarter-size image and scaled by pixel count (said so in `sample`)."""
+    cores on the same workload: full fwd+bwd+SGD steps at bs=n (a bounded sample: the reference needs ~14 s per step on 8
+    cores).  Runs in a child process with a time limit; if the full-size step does not finish the sample is shrunk to a
+    quarter-size image and scaled by pixel count (said so in `sample`)."""
     import subprocess
     for hh, ww, limit in ((h, w, 150), (h // 2, w // 2, 100), (h // 4, w // 4, 60)):
         try:
@@ -58,6 +83,7 @@ def cpu_baseline(genotype, n, h, w):
                 if (hh, ww) != (h, w):
                     d['value'] *= (hh * ww) / float(h * w)
                     d['sample'] += ' (scaled by pixel count to %dx%d)' % (h, w)
+                    d.pop('first_step_loss', None)
                 return d
         except subprocess.TimeoutExpired:
             sys.stderr.write('[bench] cpu baseline at %dx%d exceeded %ds\n' % (hh, ww, limit))
@@ -67,14 +93,15 @@ def cpu_baseline(genotype, n, h, w):
 
 def _cpu_baseline_child(genotype, n, h, w):
     import oracle
-    torch.manual_seed(1)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
     cores = max(1, min(cores, 16))          # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(cores)
     m = oracle.ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(), 0)
+    init_weights(m)
     m.train()
     opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True)
     x, t = synthetic_batch(n, h, w, 1, 'cpu')
+    losses = []
 
     def step():
         ys = m(x)
@@ -82,15 +109,16 @@ def _cpu_baseline_child(genotype, n, h, w):
         opt.zero_grad()
         loss.backward()
         opt.step()
+        losses.append(float(loss))
     t0 = time.perf_counter()
-    step()                                   # untimed warm-up (allocator, oneDNN primitive caches)
+    step()                                   # untimed warm-up (allocator, oneDNN primitive caches); its loss is step 0's
     warm = time.perf_counter() - t0
     k = max(2, min(5, int(16.0 / max(warm, 1e-3))))      # ~10-30 s of timed CPU work
     t0 = time.perf_counter()
     for _ in range(k):
         step()
     dt = (time.perf_counter() - t0) / k
-    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port', 'first_step_loss': losses[0], 'second_step_loss': losses[1],
             'sample': '%d steps fwd+bwd+SGD after 1 warm-up step, bs=%d %dx%d, torch-CPU oracle, %.1f s per step' % (k, n, h, w, dt)}
 
 
@@ -111,24 +139,143 @@ def time_launch(cmd, reps=20):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def _events_ms(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def segment_roofline(model, x, mode, reps=8):
+    """North-star segment: the forward launch list of `model` in `mode` ('eval' | 'train'), timed per tagged segment with HIP
+    events on the launch stream (single stream: true per-segment durations), plus the whole forward as the model runs it
+    (level-ordered, batched, two streams).  Fractions: SURVEY §8(d) algorithmic bytes / 8 TB/s and conv FLOPs / fp32 matrix peak."""
+    import addk.plan as P
+    dev = x.device
+    n = x.shape[0]
+    model.train(mode == 'train')
+    g = P.Graph(dev, mode == 'train', False, None)
+    act, inref = g.input_nchw(x)
+    inref.bind(x)
+    model.emit(g, act)
+    g.finalize()
+    st = torch.cuda.current_stream().cuda_stream
+    g.run(g.fwd, st); g.run(g.fwd, st)
+    runs, cur = [], None
+    for i, c in enumerate(g.fwd):
+        if cur is None or c.tag != cur[0]:
+            cur = [c.tag, i, i + 1]; runs.append(cur)
+        else:
+            cur[2] = i + 1
+    tot = {}
+    for tag, i0, i1 in runs:
+        tot[tag] = tot.get(tag, 0.0) + _events_ms(lambda: g.run(g.fwd[i0:i1], st), reps)
+    whole = _events_ms(lambda: g.run(g.fwd, st), reps)
+    nl = len(g.fwd)
+    del g
+    g2 = P.Graph(dev, mode == 'train', False, None)
+    act2, inref2 = g2.input_nchw(x)
+    inref2.bind(x)
+    model.emit(g2, act2)
+    g2.reorder = True
+    g2.finalize(2)
+    for _ in range(2):
+        g2.run_parallel(g2.fwd, None)
+    whole2 = _events_ms(lambda: g2.run_parallel(g2.fwd, None), reps)
+    extra = TRAIN_EXTRA_GB if mode == 'train' else dict.fromkeys(ALG_GB, 0.0)
+    ms = tot.get('cell', 0.0) + tot.get('aspp', 0.0)
+    gb = n * (ALG_GB['cell'] + ALG_GB['aspp'] + extra['cell'] + extra['aspp'])
+    gf = n * (GFLOP['cell'] + GFLOP['aspp'])
+    out = {'mode': mode, 'aspp_plus_cell_ms': ms, 'alg_GB': gb, 'achieved_GBps': gb / ms * 1e3, 'frac_hbm': gb / ms * 1e3 / PEAK_HBM_GBS,
+           'alg_GFLOP': gf, 'achieved_TFLOPs': gf / ms, 'frac_mfma_f32': gf / ms / PEAK_MFMA_F32_TFLOPS,
+           'forward_ms_single_stream': whole, 'forward_ms_two_streams_batched': whole2, 'launches': nl, 'launches_batched': len(g2.fwd),
+           'segments_ms': {k: round(v, 4) for k, v in tot.items() if k}}
+    del g2
+    torch.cuda.empty_cache()
+    return out
+
+
+def per_exit_latency(model, dev, reps=12):
+    """Config 4 (eval.py:195-230): EDM-gated dynamic inference at bs=1; per-exit latency as the reference measures it
+    (synchronize + perf_counter around the whole call), at both shapes, and the mean at 0 / 50 / 100 % early exits."""
+    from addk.modeling.ADD import EDM
+    from _util import fill_params
+    edm = EDM()
+    fill_params(edm, 701)
+    edm.to(dev).eval()
+    model.eval()
+    out = {}
+    with torch.no_grad():
+        for h, w in ((1024, 2048), (1025, 2049)):
+            x = torch.randn(1, 3, h, w, device=dev)
+            res = {}
+            for name, thr in (('early', 1e9), ('final', -1e9)):
+                for _ in range(4):
+                    model.dynamic_inference(x, threshold=thr, confidence='edm', edm=edm)
+                ts = [model.dynamic_inference(x, threshold=thr, confidence='edm', edm=edm)[2] for _ in range(reps)]
+                res[name + '_exit_ms'] = 1e3 * float(np.median(ts))
+            e, f = res['early_exit_ms'], res['final_exit_ms']
+            res['mean_ms_at_early_exit_fraction'] = {'0%': f, '50%': 0.5 * (e + f), '100%': e}
+            res['fps_at_early_exit_fraction'] = {'0%': 1e3 / f, '50%': 2e3 / (e + f), '100%': 1e3 / e}
+            out['%dx%d' % (h, w)] = res
+            plans = model._plans()
+            for k in [k for k in plans if k[0] == 'dyn']:
+                del plans[k]
+            torch.cuda.empty_cache()
+    return out
+
+
+def drop_in_step(model, x, t, steps=5):
+    """The reference's own call pattern (train.py:227-240) on the addk modules: forward through nn.Module.__call__, the
+    drop-in CrossEntropyLoss per exit, autograd backward, torch.optim.SGD.  No TrainStep, no whole-step graph."""
+    from addk.loss import CrossEntropyLoss
+    model.train()
+    crit = CrossEntropyLoss(ignore_index=255)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True)
+
+    def step():
+        ys = model(x)
+        loss = sum(crit(y, t) for y in ys) / len(ys)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'steps': steps,
+            'what': 'outputs = model(image); loss = mean_i CE(outputs[i], target); loss.backward(); torch.optim.SGD.step()'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=2)
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--F', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the segment roofline / per-exit latency / drop-in measurements')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--math', choices=["fp32", "bf16x6", "bf16x3"], default='fp32', help='dense-conv arithmetic (default: exact fp32 MFMA)')
+    ap.add_argument('--math', choices=['fp32', 'bf16x6', 'bf16x3'], default=None,
+                    help='arithmetic of the wide k x k contractions (default: the library default, see addk.get_precision())')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--force-sync', action='store_true', help='rehearse the N>1 path (RCCL SyncBN + gradient all-reduce) at world_size 1')
     a = ap.parse_args()
+    genotype = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
     if a.cpu_baseline_child:
-        g = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
-        print(json.dumps(_cpu_baseline_child(g, a.batch, a.height, a.width)))
+        print(json.dumps(_cpu_baseline_child(genotype, a.batch, a.height, a.width)))
         return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -141,7 +288,9 @@ def main():
     from addk.modeling.ADD import ADD
     from addk.train import TrainStep
     from addk import parallel
-    addk.set_precision(a.math)
+    if a.math:
+        addk.set_precision(a.math)
+    math = addk.get_precision()
     comm = None
     if world > 1 or a.force_sync:
         import torch.distributed as dist
@@ -150,9 +299,9 @@ def main():
             os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend='nccl', init_method='env://')
         comm = parallel.init_sync_bn(force=a.force_sync)
-    genotype = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
-    torch.manual_seed(1)
-    model = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=comm is not None), 0).to(dev)
+    model = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=comm is not None), 0)
+    init_weights(model)
+    model.to(dev)
     parallel.broadcast_params(model)
     n, h, w = a.batch, a.height, a.width
     ts = TrainStep(model, (n, 3, h, w), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm,
@@ -165,8 +314,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    losses = []
+    for i in range(a.warmup):
         ts.step()
+        if i < 2:
+            losses.append(float(ts.loss.item()))
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -184,37 +336,62 @@ def main():
     ms = dt / a.steps * 1e3
     value = world * n * a.steps / dt
 
-    # roofline of the dominant kernel: the fp32-MFMA conv; its heaviest launch (decoder 3x3 304->256), which runs on the
-    # halo-patch kernel conv3_kernel (its weight-packing pre-pass, ~5 us, is inside the timed launch)
+    # roofline of the dominant kernel: the heaviest dense-conv launch (decoder 3x3 304->256) on the halo-patch kernel
     convs = [m for m in ts.g.meta if m['kind'] == 'conv_fwd']
     top = max(convs, key=lambda m: m['flops'])
     tk = time_launch(top['cmd'])
     fwd_flops = sum(m['flops'] for m in convs)
-    # HBM-side traffic of that launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), which cannot run
-    # inside this process: the committed measurement of the same kernel and shape is reported when present
-    traffic = None
     halo = bool(top.get('halo'))
-    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_decoder_conv3.json' if halo else 'r01_pmc_traffic_decoder_conv.json')
-    if a.math == 'fp32' and (n, h, w, a.F) == (2, 1024, 2048, 20) and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get('traffic_bytes_per_launch')
-    roof = {'bound': 'mfma', 'achieved': top['flops'] / tk / 1e12, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': top['flops'] / tk / 1e12 / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic,
-            'kernel': ('conv3_kernel<BCT=8,FWD>' if halo else 'conv_kernel<PT=2,CT=8,FWD>') + ' (v_mfma_f32_16x16x4_f32)', 'launch_ms': tk * 1e3,
+    terms = {'fp32': 1, 'bf16x6': 6, 'bf16x3': 3}[math] if halo else 1
+    if terms == 1:
+        peak, kern = PEAK_MFMA_F32_TFLOPS, ('conv3_kernel' if halo else 'conv_kernel') + ' (v_mfma_f32_16x16x4_f32)'
+        peak_note = 'fp32 matrix peak'
+    else:
+        peak = PEAK_MFMA_BF16_TFLOPS / terms
+        kern = 'conv3b_kernel (v_mfma_f32_32x32x16_bf16, %d bf16 product terms per fp32 product)' % terms
+        peak_note = 'dense bf16 MFMA peak %.0f TFLOP/s / %d matrix instructions per fp32 multiply-add' % (PEAK_MFMA_BF16_TFLOPS, terms)
+    ach = top['flops'] / tk / 1e12
+    roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            'traffic_note': 'PMC passes cannot run inside this process; per-launch FETCH/WRITE bytes of this kernel are in profiles/ (separate rocprofv3 --pmc runs)',
+            'peak_note': peak_note, 'executed_matrix_TFLOPs': ach * terms, 'frac_of_fp32_matrix_peak': ach / PEAK_MFMA_F32_TFLOPS,
+            'kernel': kern, 'launch_ms': tk * 1e3,
             'launch_shape_NHWCinCoutKSD': list(top['shape']), 'algorithmic_gflop_per_launch': top['flops'] / 1e9,
             'algorithmic_bytes_per_launch': top['bytes']}
+    step_tflops = 3 * fwd_flops / (dt / a.steps) / 1e12
     out = {'metric': 'Cityscapes 1024x2048 images/sec fwd+bwd @ bs=2/GPU', 'value': value, 'unit': 'images/sec',
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.math == 'fp32' else 'f32 storage, split-bf16 (3-term) MFMA products, f32 accumulate', 'data': 'synthetic',
+           'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32' if math == 'fp32' else 'f32 storage and accumulation; k x k contractions as %s split-bf16 MFMA products' % math,
+           'data': 'synthetic',
            'config': {'workload': 'ADD F=%d searched_arch/autodeeplab C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, h, w, n),
                       'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': comm is not None,
-                      'hip_graph': bool(ts.graph is not None)},
-           'loss': loss,
+                      'hip_graph': bool(ts.graph is not None), 'math': math},
+           'loss': loss, 'first_step_losses': losses,
            'step_algorithmic_tflop': 3 * fwd_flops / 1e12,
-           'step_tflops_per_gpu': 3 * fwd_flops / (dt / a.steps) / 1e12,
+           'step_tflops_per_gpu': step_tflops, 'step_frac_mfma': step_tflops / PEAK_MFMA_F32_TFLOPS,
            'plan_device_gb': ts.nbytes / 1e9,
            'roofline': roof}
+    extras = world == 1 and not a.no_extras and comm is None and (n, h, w, a.F) == (2, 1024, 2048, 20)
+    if extras:
+        del ts
+        torch.cuda.empty_cache()
+        with torch.no_grad():
+            seg = {m: segment_roofline(model, x, m) for m in ('eval', 'train')}
+        roof['segment'] = {'name': 'ASPP + cell forward, 1024x2048 bs=2 (BASELINE north_star: >= 0.60 of the HBM roofline)',
+                           'eval': seg['eval'], 'train': seg['train'], 'bound': 'hbm', 'peak_GBps': PEAK_HBM_GBS,
+                           'frac': seg['eval']['frac_hbm']}
+        out['per_exit_ms'] = per_exit_latency(model, dev)
+        out['drop_in'] = drop_in_step(model, x, t)
     if not a.no_cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(genotype, n, h, w)
+        cb = cpu_baseline(n, h, w)
+        out['cpu_baseline'] = cb
+        ref = cb.get('first_step_loss')
+        if ref is not None and losses:
+            rel = abs(losses[0] - ref) / abs(ref)
+            out['first_step_loss_vs_cpu_oracle'] = {'gpu': losses[0], 'cpu_oracle': ref, 'rel_diff': rel}
+            if len(losses) > 1 and cb.get('second_step_loss') is not None:
+                out['first_step_loss_vs_cpu_oracle']['second_step'] = {'gpu': losses[1], 'cpu_oracle': cb['second_step_loss']}
+            assert rel <= 1e-3, 'first-step loss %.7f differs from the CPU oracle %.7f on the same inputs (rel %.2e)' % (losses[0], ref, rel)
     print(json.dumps(out), flush=True)
     if comm is not None:
         torch.distributed.destroy_process_group()
