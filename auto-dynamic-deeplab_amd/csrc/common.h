@@ -18,7 +18,7 @@ int addk_check_launch(const char* what);
 
 // arithmetic of the halo-patch convolutions when neither ADDK_MATH nor addk_set_conv_precision says otherwise (conv.hip)
 #ifndef ADDK_DEFAULT_PRECISION
-#define ADDK_DEFAULT_PRECISION 0
+#define ADDK_DEFAULT_PRECISION 2
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

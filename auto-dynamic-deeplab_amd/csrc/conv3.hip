@@ -639,7 +639,14 @@ int c3b_wc(int Cn) {
 }
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
-inline int c3_planes() { const int m = addk_get_conv_precision(); return m == 2 ? 3 : m == 1 ? 2 : 0; }   // 0: exact fp32 MFMA kernel
+// bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  The 5x5 convs with <= 64 output
+// channels (cells' dil_conv_5x5 at level 1) stay on the fp32 kernel: 2-wave blocks of the split kernel stage 22 slots per thread
+// and spill (measured 113 vs 88 us at 40 channels, 125x253).
+inline int c3_planes(int Cn, int taps) {
+  const int m = addk_get_conv_precision();
+  if (m == 0 || (taps == 25 && Cn <= 64)) return 0;
+  return m == 2 ? 3 : 2;
+}
 // Column block (16-channel tiles per block).  128-channel blocks (2x2 waves) for the wide heads when that still
 // yields >= 512 blocks; otherwise the narrowest of 3/4/5 tiles that pads the channel count least (cells: 40 -> 3 tiles,
 // 80 and 160 -> 5 tiles; stem / small ASPP maps: 4 tiles).
@@ -655,7 +662,7 @@ int c3_bct(int Cn, long P) {
   return best;
 }
 long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
-  if (const int np = c3_planes()) {            // bf16 planes: 1 KB per (tap, 32-row tile, plane)
+  if (const int np = c3_planes(Cn, taps)) {            // bf16 planes: 1 KB per (tap, 32-row tile, plane)
     const int wc = c3b_wc(Cn);
     return (long)cdiv(Cn, 32 * wc) * nchunks * taps * wc * np * 256;
   }
@@ -704,7 +711,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
 
 int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out = nullptr) {
   pk.planes = 0;
-  if (const int np = c3_planes()) return c3b_launch(k, pk, mode, rows, st, packed, desc_out, np);
+  if (const int np = c3_planes(k.Cn, pk.taps)) return c3b_launch(k, pk, mode, rows, st, packed, desc_out, np);
   const int bct = c3_bct(k.Cn, k.P);
   pk.bct = bct; pk.mode = mode; pk.Cn = k.Cn;
   k.nT = pk.nchunks * pk.taps;
