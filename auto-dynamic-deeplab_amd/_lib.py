@@ -38,6 +38,12 @@ class ConvWgradArgs(C.Structure):
                 ('ldw', i32), ('cin_total', i32), ('w_choff', i32), ('accumulate', i32), ('ws', vp), ('ws_floats', i64)]
 
 
+class SepArgs(C.Structure):
+    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('Cout', i32), ('ldw', i32), ('dw_w', vp), ('pw_w', vp),
+                ('y', vp), ('ldy', i32), ('ldt', i32), ('t', vp), ('stats', vp), ('stats_ld', i32), ('nterm', i32), ('ea', vp), ('eb', vp),
+                ('term', Src * MAX_TERMS)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32), ('KH', i32), ('KW', i32),
                 ('stride', i32), ('pad', i32), ('dil', i32), ('w', vp), ('y', vp), ('ldy', i32)]
@@ -130,6 +136,11 @@ _SIGS = {
     'addk_conv_wgrad_config': (i32, [C.POINTER(ConvWgradArgs), C.POINTER(i32)]),
     'addk_conv_wgrad_batch_prepare': (i64, [C.POINTER(ConvWgradArgs), i32, vp, i64, C.POINTER(i64)]),
     'addk_conv_wgrad_batch_run': (i32, [vp, C.POINTER(i64), vp]),
+    'addk_sep_fwd_supported': (i32, [C.POINTER(SepArgs)]),
+    'addk_sep_fwd': (i32, [C.POINTER(SepArgs), vp]),
+    'addk_sep_fwd_batch_key': (i32, [C.POINTER(SepArgs)]),
+    'addk_sep_fwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),
+    'addk_sep_batch_run': (i32, [vp, vp, vp]),
     'addk_dw_fwd': (i32, [C.POINTER(DwArgs), vp]),
     'addk_dw_bwd': (i32, [C.POINTER(DwBwdArgs), vp]),
     'addk_dw_rows': (i32, [i64, i32]),

@@ -28,6 +28,11 @@ struct PwK {
   addk_src dst; int accumulate;          // dgrad epilogue
   int P; int ntiles16; int rows;       // rows: slab rows the caller allocated (>= gx; the extra rows are zero-filled)
   int gx, gy;                          // grid of this launch (a batched launch runs several descriptors on one larger grid)
+  // fused SepConv half (SEP = 3 / 5): depthwise K x K in front of the pointwise conv, computed while the B fragment is built
+  const float* dww; int H, W;          // depthwise weights [C][K*K]; image geometry (stride 1, dilation 1, pad K/2)
+  float* t; int ldt;                   // optional copy of the depthwise output (training: the backward pass reads it)
+  const float* ea; const float* eb;    // inference epilogue: y = ea*acc + eb + sum of terms
+  int nterm; addk_src term[ADDK_MAX_TERMS];
 };
 
 // These launches are latency chains (kernel arguments -> weight panel -> one or two pixel tiles -> store -> statistics)
@@ -35,8 +40,12 @@ struct PwK {
 // is kept under 128 (KG=3) / 168 (KG=5) registers for 4 / 3 waves per SIMD: no prefetch buffer (occupancy hides the
 // latency) and, for maps of >= 4096 pixels, per-lane statistics in fp32 (a lane sums at most a handful of values; the
 // cross-lane / cross-wave / cross-block sums stay fp64).
-template <int CT, int KG, int MODE, bool RED32>     // CT column tiles of 16, KG groups of 16 reduction channels
-__device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2]) {
+// SEP > 0 (forward only): the B operand is not x but depthwise_SEPxSEP(relu?(a*x+b)) — every lane builds its fragment
+// (pixel li, channels 16g + 4kq + {0..3}) from the SEP*SEP neighbouring pixels, all loads unconditional and independent (L1/L2 hits:
+// neighbouring lanes share them), zero padding after the prologue as in the reference; tap weights sit in LDS as [tap][channel].
+// No barrier in the main loop and no round trip of the depthwise output through HBM (operations.py:51-53: ReLU, dw, pw in one launch).
+template <int CT, int KG, int MODE, bool RED32, int SEP = 0>     // CT column tiles of 16, KG groups of 16 reduction channels
+__device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2], const float* dwl = nullptr) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.y * (CT * 16);
@@ -45,23 +54,26 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2])
   // Every load below is unconditional (masked lanes read a safe address and are zeroed afterwards) so that the whole
   // panel, the prologue coefficients and the first pixel tile are ONE round trip to memory, not a chain of them.
   float4 wf[CT][KG];
+  auto load_panel = [&]() {
 #pragma unroll
-  for (int i = 0; i < CT; ++i)
+    for (int i = 0; i < CT; ++i)
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      const int n = n0 + i * 16 + li, k = 16 * g + 4 * kq;
-      const bool ok = n < p.Cn && k < p.K;          // K % 4 == 0: a quad is valid as a whole
-      float4 v;
-      if (MODE == PW_FWD) {
-        v = ld4(ok ? p.w + (long)n * p.ldw + p.w_off + k : p.w);
-      } else {
-        const float* b = ok ? p.w + (long)k * p.ldw + p.w_off + n : p.w;
-        const long st = ok ? p.ldw : 0;
-        v = make_float4(b[0], b[st], b[2 * st], b[3 * st]);
+      for (int g = 0; g < KG; ++g) {
+        const int n = n0 + i * 16 + li, k = 16 * g + 4 * kq;
+        const bool ok = n < p.Cn && k < p.K;          // K % 4 == 0: a quad is valid as a whole
+        float4 v;
+        if (MODE == PW_FWD) {
+          v = ld4(ok ? p.w + (long)n * p.ldw + p.w_off + k : p.w);
+        } else {
+          const float* b = ok ? p.w + (long)k * p.ldw + p.w_off + n : p.w;
+          const long st = ok ? p.ldw : 0;
+          v = make_float4(b[0], b[st], b[2 * st], b[3 * st]);
+        }
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        wf[i][g] = v;
       }
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      wf[i][g] = v;
-    }
+  };
+  if (!SEP) load_panel();        // fused form: the panel is fetched after the depthwise phase (its registers are needed there)
   // lazy prologue coefficients of this lane's k slots
   const bool relu = p.src.relu != 0;
   const bool pro = relu || p.src.a != nullptr;
@@ -98,10 +110,45 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2])
       x[g] = v;
     }
   };
-  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles16; tile += wstride) {
-    load_tile(tile, xf);
+  auto load_tile_sep = [&](int tile, float4 (&x)[KG]) {
+    constexpr int HK = SEP / 2;
     const int pp = tile * 16 + li;
-    if (pro) {
+    const bool pin = pp < p.P;
+    const int hw = p.H * p.W;
+    const int n = pp / hw, rem = pp - n * hw;
+    const int oh = rem / p.W, ow = rem - oh * p.W;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) x[g] = zero4();
+#pragma unroll 1
+    for (int kh = 0; kh < SEP; ++kh)              // one patch row (SEP x KG independent 16-byte loads) in flight at a time
+#pragma unroll
+      for (int kw = 0; kw < SEP; ++kw) {
+        const int ih = oh - HK + kh, iw = ow - HK + kw;
+        const bool sp = pin && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const long off = sp ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+          const int k = 16 * g + 4 * kq;
+          const bool ok = sp && k < p.K;
+          float4 v = ld4(p.src.x + (ok ? off + k : 0));
+          if (pro) {
+            v.x = fmaf(pa[g].x, v.x, pb[g].x); v.y = fmaf(pa[g].y, v.y, pb[g].y); v.z = fmaf(pa[g].z, v.z, pb[g].z); v.w = fmaf(pa[g].w, v.w, pb[g].w);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          }
+          v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+          const float4 w4 = *reinterpret_cast<const float4*>(dwl + (kh * SEP + kw) * (KG * 16) + k);
+          x[g].x = fmaf(w4.x, v.x, x[g].x); x[g].y = fmaf(w4.y, v.y, x[g].y); x[g].z = fmaf(w4.z, v.z, x[g].z); x[g].w = fmaf(w4.w, v.w, x[g].w);
+        }
+      }
+    if (p.t && pin) {
+#pragma unroll
+      for (int g = 0; g < KG; ++g) { const int k = 16 * g + 4 * kq; if (k < p.K) st4(p.t + (long)pp * p.ldt + k, x[g]); }
+    }
+  };
+  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles16; tile += wstride) {
+    if (SEP) { load_tile_sep(tile, xf); if (KG <= 3) load_panel(); } else load_tile(tile, xf);
+    const int pp = tile * 16 + li;
+    if (pro && !SEP) {
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
         float4 v = xf[g];
@@ -117,11 +164,21 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2])
     for (int i = 0; i < CT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
+      if (SEP && KG > 3) {          // wide fused form: the weight fragments of one group at a time (L1 hits), not the whole 25-quad panel
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          const int n = n0 + i * 16 + li, k = 16 * g + 4 * kq;
+          const bool ok = n < p.Cn && k < p.K;
+          float4 v = ld4(ok ? p.w + (long)n * p.ldw + p.w_off + k : p.w);
+          v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+          wf[i][0] = v;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < CT; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(wf[i][g], e), get4(xf[g], e), acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(wf[i][(SEP && KG > 3) ? 0 : g], e), get4(xf[g], e), acc[i], 0, 0, 0);
     }
     // ---- epilogue: lane holds channels n0 + i*16 + kq*4 + {0..3} of pixel pp ----
     if (pp < p.P) {
@@ -133,6 +190,17 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2])
         float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         if (MODE == PW_FWD) {
           if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+          if (SEP) {            // inference epilogue: own frozen BatchNorm, then the other branches of the cell block
+            if (p.ea) {
+              const float4 ea = ld4g(p.ea + c, nrem, true), eb = ld4g(p.eb + c, nrem, true);
+              v.x = fmaf(ea.x, v.x, eb.x); v.y = fmaf(ea.y, v.y, eb.y); v.z = fmaf(ea.z, v.z, eb.z); v.w = fmaf(ea.w, v.w, eb.w);
+            }
+            for (int ti = 0; ti < p.nterm; ++ti) {
+              const addk_src& T = p.term[ti];
+              const float4 u = prologue4(ld4g(T.x + (long)pp * T.ld + c, nrem, true), T.a, T.b, c, nrem, T.relu != 0, true);
+              v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+          }
           st4g(p.y + (long)pp * p.ldy + c, v, nrem, true);
           if (p.slab) {
 #pragma unroll
@@ -186,6 +254,27 @@ __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p)
   __shared__ double red[4][CT * 16][2];
   pw_body<CT, KG, MODE, RED32>(p, red);
 }
+template <int CT, int KG, bool RED32, int SEP>
+__device__ __forceinline__ void sep_block(const PwK& p) {
+  __shared__ double red[4][CT * 16][2];
+  __shared__ __attribute__((aligned(16))) float dwl[SEP * SEP * KG * 16];      // depthwise tap weights [tap][channel], zero beyond K
+  for (int i = threadIdx.x; i < SEP * SEP * KG * 16; i += 256) {
+    const int tp = i / (KG * 16), c = i - tp * (KG * 16);
+    dwl[i] = c < p.K ? p.dww[(long)c * (SEP * SEP) + tp] : 0.f;
+  }
+  __syncthreads();
+  pw_body<CT, KG, PW_FWD, RED32, SEP>(p, red, dwl);
+}
+template <int CT, int KG, bool RED32, int SEP>
+__global__ void __launch_bounds__(256, 2) sep_kernel(const PwK p) { sep_block<CT, KG, RED32, SEP>(p); }
+// the fused halves of one dependency level (the parallel branches of a cell) in ONE launch: block (x, 0, z) runs descriptor z
+template <int CT, int KG, bool RED32, int SEP>
+__global__ void __launch_bounds__(256, 2) sep_batch_kernel(const PwK* __restrict__ tab) {
+  const PwK& p = tab[blockIdx.z];          // by reference: a local copy with its runtime-indexed term[] would live in scratch
+  if ((int)blockIdx.x >= p.gx) return;
+  sep_block<CT, KG, RED32, SEP>(p);
+}
+
 // several independent pointwise convs of one dependency level in ONE launch: block (x, y, z) runs descriptor z
 template <int CT, int KG, int MODE, bool RED32>
 __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_batch_kernel(const PwK* __restrict__ tab) {
@@ -397,6 +486,46 @@ bool pw_fill_dgrad(const addk_conv_dgrad_args* a, PwK& k) {
 }
 inline int pw_key(const PwCfg& c, int mode) { return (mode << 12) | (c.ct << 8) | (c.kg << 4) | c.red32; }
 
+// ---- fused SepConv half ----
+bool sep_fill(const addk_sep_args* a, PwK& k, PwCfg& c) {
+  if (!a || !(a->K == 3 || a->K == 5) || a->N <= 0 || a->H <= 0 || a->W <= 0) return false;
+  const addk_src& s = a->src;
+  const int kg = cdiv(s.C, 16);
+  if (!(kg == 3 || kg == 5) || a->Cout != s.C || !s.x || !src_vec_ok(s) || !a->dw_w || !a->pw_w || !a->y) return false;
+  if (!aligned16(a->y) || a->ldy % 4 || a->ldy < a->Cout || !aligned16(a->pw_w) || a->ldw % 4 || a->ldw < s.C) return false;
+  if (a->t && (!aligned16(a->t) || a->ldt % 4 || a->ldt < s.C)) return false;
+  if (a->nterm < 0 || a->nterm > ADDK_MAX_TERMS || (a->ea == nullptr) != (a->eb == nullptr)) return false;
+  if ((a->nterm > 0 || a->ea) && a->stats) return false;               // the sum epilogue is an inference form
+  if (a->ea && (!aligned16(a->ea) || !aligned16(a->eb))) return false;
+  for (int i = 0; i < a->nterm; ++i) if (!a->term[i].x || a->term[i].C != a->Cout || !src_vec_ok(a->term[i])) return false;
+  k = PwK{};
+  k.src = s; k.K = s.C; k.Cn = a->Cout; k.w = a->pw_w; k.ldw = a->ldw; k.w_off = 0;
+  k.y = a->y; k.ldy = a->ldy; k.bias = nullptr;
+  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.P = a->N * a->H * a->W; k.ntiles16 = cdiv(k.P, 16);
+  k.dww = a->dw_w; k.H = a->H; k.W = a->W; k.t = a->t; k.ldt = a->ldt; k.ea = a->ea; k.eb = a->eb; k.nterm = a->nterm;
+  for (int i = 0; i < a->nterm; ++i) k.term[i] = a->term[i];
+  const int rows = addk_conv_rows(k.P, a->Cout);
+  c.kg = kg; c.ct = kg; c.red32 = 1;          // one block covers every output channel: the depthwise part is computed once; per-lane statistics in fp32 (a lane sums a handful of values), fp64 across lanes and blocks
+  k.rows = rows;
+  c.gx = rows; if (c.gx > cdiv(k.ntiles16, 4)) c.gx = cdiv(k.ntiles16, 4); if (c.gx < 1) c.gx = 1;
+  c.gy = 1; k.gx = c.gx; k.gy = 1;
+  return true;
+}
+inline int sep_key(const PwCfg& c, int K) { return (K << 16) | (c.kg << 4) | c.red32; }
+template <bool BATCH>
+int sep_dispatch(int kg, int K, int red32, dim3 grid, hipStream_t st, const PwK* one, const PwK* tab) {
+#define ADDK_SEP(KG_, K_, R_) \
+  if (kg == KG_ && K == K_ && (red32 != 0) == R_) { \
+    if (BATCH) hipLaunchKernelGGL((sep_batch_kernel<KG_, KG_, R_, K_>), grid, dim3(256), 0, st, tab); \
+    else hipLaunchKernelGGL((sep_kernel<KG_, KG_, R_, K_>), grid, dim3(256), 0, st, *one); \
+    return addk_check_launch("sep_fwd"); }
+  ADDK_SEP(3, 3, true) ADDK_SEP(3, 5, true) ADDK_SEP(5, 3, true) ADDK_SEP(5, 5, true)
+#undef ADDK_SEP
+  addk_set_error("sep_fwd: no instantiation");
+  return ADDK_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 // Returns 0 when the launch was taken, 1 when the shape is not covered (caller falls back), <0 on error.
@@ -490,4 +619,43 @@ extern "C" int addk_conv_batch_run(const void* dev_blob, const int64_t* meta, vo
   const PwK* tab = reinterpret_cast<const PwK*>(dev_blob);
   if (mode == PW_FWD) return pw_batch_launch<PW_FWD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
   return pw_batch_launch<PW_DGRAD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
+}
+
+// ---- fused SepConv half: C ABI ---------------------------------------------------------------------------------------
+extern "C" int addk_sep_fwd_supported(const addk_sep_args* a) {
+  PwK k; PwCfg c;
+  return (addk_get_fast_paths() & ADDK_FAST_PW) && sep_fill(a, k, c) ? 1 : 0;
+}
+extern "C" int addk_sep_fwd(const addk_sep_args* a, void* stream) {
+  PwK k; PwCfg c;
+  ADDK_REQUIRE(sep_fill(a, k, c), "sep_fwd: shape not covered by the fused kernel (K in {3,5}, C == Cout in (32,48] or (64,80], aligned)");
+  return sep_dispatch<false>(c.kg, a->K, c.red32, dim3(c.gx, 1), (hipStream_t)stream, &k, nullptr);
+}
+// batched form (one dependency level): key >= 0 groups launches that share a kernel variant
+extern "C" int addk_sep_fwd_batch_key(const addk_sep_args* a) {
+  PwK k; PwCfg c;
+  if (!(addk_get_fast_paths() & ADDK_FAST_PW) || !sep_fill(a, k, c)) return -1;
+  return sep_key(c, a->K);
+}
+extern "C" int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  if (!a || n <= 0 || !meta) { addk_set_error("sep_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
+  const int64_t total = (int64_t)n * sizeof(PwK);
+  if (host_blob && blob_bytes < total) { addk_set_error("sep_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
+  int key0 = -1, gx = 0;
+  for (int i = 0; i < n; ++i) {
+    PwK k; PwCfg c;
+    if (!sep_fill(&a[i], k, c)) { addk_set_error("sep_batch_prepare: launch %d is not covered", i); return ADDK_ERR_INVALID; }
+    const int key = sep_key(c, a[i].K);
+    if (i == 0) key0 = key;
+    if (key != key0) { addk_set_error("sep_batch_prepare: mixed kernel variants"); return ADDK_ERR_INVALID; }
+    if (c.gx > gx) gx = c.gx;
+    if (host_blob) reinterpret_cast<PwK*>(host_blob)[i] = k;
+  }
+  meta[0] = key0; meta[1] = n; meta[2] = gx; meta[3] = 1;
+  return total;
+}
+extern "C" int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
+  ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "sep_batch_run: bad args");
+  const int key = (int)meta[0], K = key >> 16, kg = (key >> 4) & 15, red32 = key & 1;
+  return sep_dispatch<true>(kg, K, red32, dim3((unsigned)meta[2], 1, (unsigned)meta[1]), (hipStream_t)stream, nullptr, reinterpret_cast<const PwK*>(dev_blob));
 }

@@ -35,16 +35,31 @@ def emit_blocks(g, ops, cell_arch, B, states, C_out):
     concat = g.tensor(s1.N, s1.H, s1.W, B * C_out)
     offset = used = 0
     n0 = len(states)
+    from .operations import SepConv
+    fuse_sum = not g.training and not g.want_grad        # inference: the closing SepConv of a block writes the branch sum itself
     for b in range(B):
-        terms = []
+        todo = []
         for j, h in enumerate(states):
             if offset + j in active:
-                terms.append(ops[used].emit(g, h))
+                todo.append((ops[used], h))               # the binding is positional (Q1); the emission order inside a block is free
+                if getattr(g, 'bindings', None) is not None:
+                    g.bindings.append((used, offset + j))
                 used += 1
         slot = concat.chan(b * C_out, C_out)
-        if not terms or all(t.zero for t in terms):
-            raise NotImplementedError('a cell block without any non-zero branch')
-        states.append(g.affine_sum(terms, out=slot))
+        closer = None
+        if fuse_sum and len(todo) > 1:
+            seps = [i for i, (op, _) in enumerate(todo) if isinstance(op, SepConv)]
+            if seps:
+                closer = todo.pop(seps[-1])
+        terms = [op.emit(g, h) for op, h in todo]
+        if closer is not None and not all(t.zero for t in terms):
+            states.append(closer[0].emit(g, closer[1], sum_terms=terms, out=slot))
+        else:
+            if closer is not None:
+                terms.append(closer[0].emit(g, closer[1]))
+            if not terms or all(t.zero for t in terms):
+                raise NotImplementedError('a cell block without any non-zero branch')
+            states.append(g.affine_sum(terms, out=slot))
         offset += len(states) - 1
     assert len(states) - n0 == B
     return Act(concat, None, False, g.want_grad)

@@ -64,11 +64,11 @@ class SepConv(AddkModule):
             BatchNorm(C_out, eps=eps, momentum=momentum, affine=affine))
         assert C_in == C_out, 'the path only instantiates depthwise SepConv with C_in == C_out (operations.py:12-13)'
 
-    def emit(self, g, x):
-        t = g.dwconv(x, self.op[1], relu_in=True)
-        y = g.conv_bn([t], self.op[2], self.op[3], relu_in=False)
-        t = g.dwconv(y, self.op[5], relu_in=True)
-        return g.conv_bn([t], self.op[6], self.op[7], relu_in=False)
+    def emit(self, g, x, sum_terms=None, out=None):
+        """Each half is one fused launch (plan.Graph.sep_half).  `sum_terms` / `out` (inference): this op closes a cell block —
+        its second half adds the other branches and writes the block sum (ADD.py:108) itself."""
+        y = g.sep_half(x, self.op[1], self.op[2], self.op[3])
+        return g.sep_half(y, self.op[5], self.op[6], self.op[7], sum_terms=sum_terms, out=out)
 
 
 class Identity(AddkModule):

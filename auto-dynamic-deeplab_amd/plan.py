@@ -361,6 +361,7 @@ class Graph:
                 'slab_reduce': ('addk_slab_reduce_batch', lambda p: p.C), 'bn_bwd_coeffs': ('addk_bn_bwd_coeffs_batch', lambda p: p.C),
                 'conv_fwd': ('addk_conv_fwd_batch_prepare', 'addk_conv_batch_run'), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', 'addk_conv_batch_run'),
                 'dw_fwd': ('addk_dw_fwd_batch_prepare', 'addk_dw_batch_run'), 'dw_bwd': ('addk_dw_bwd_batch_prepare', 'addk_dw_batch_run'),
+                'sep_fwd': ('addk_sep_fwd_batch_prepare', 'addk_sep_batch_run'),
                 'allreduce': (None, None)}
 
     @staticmethod
@@ -641,8 +642,9 @@ class Graph:
 
     # ---------------- ops ----------------
     def conv(self, srcs, weight, Cout, k, stride=1, pad=0, dil=1, relu_in=False, bias=None, bias_n=None,
-             out=None, stats=None, stats_ld=0, out_hw=None, w_choff=0, cin_total=None):
-        """Dense conv over virtually concatenated `srcs` (list of Act).  Returns the raw output TRef."""
+             out=None, stats=None, stats_ld=0, out_hw=None, w_choff=0, cin_total=None, fwd=True):
+        """Dense conv over virtually concatenated `srcs` (list of Act).  Returns the raw output TRef.  fwd=False registers only
+        the backward pass (the forward launch is part of a fused command, sep_half)."""
         lib = self.lib
         a0 = srcs[0]
         N, H, W = a0.N, a0.H, a0.W
@@ -660,36 +662,37 @@ class Graph:
         wptr = self.param(weight)
         ldw = k * k * cin_total
         assert weight.numel() == Cout * ldw, 'weight %s does not match Cout=%d k=%d cin=%d' % (tuple(weight.shape), Cout, k, cin_total)
-        ar = L.ConvArgs()
-        for i, s in enumerate(srcs):
-            assert (s.N, s.H, s.W) == (N, H, W), 'virtual concat needs equal spatial size'
-            ar.src[i] = self.src(s, relu_in)
-        ar.nsrc = len(srcs)
-        ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
-        ar.KH = ar.KW = k
-        ar.stride, ar.pad, ar.dil, ar.Cout = stride, pad, dil, Cout
-        ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = ldw, cin_total, w_choff, out.ld
-        ar.w, ar.y = wptr, out.ptr
-        ar.bias = self.param(bias) if bias is not None else None
-        ar.bias_n = bias_n.ptr if bias_n is not None else None
-        ar.stats = stats.ptr if stats is not None else None
-        ar.stats_ld = stats_ld
-        wpk = None
-        npk = int(lib.addk_conv_fwd_pack_floats(C.byref(ar)))       # > 0: wide 3x3 stride-1 conv, halo-patch kernel (conv3.hip)
-        if npk > 0:
-            wpk = self.buf(npk)
-            ar.wpack, ar.wpack_floats = wpk.ptr, npk
-            self._hoist_pack(lib.addk_conv_fwd_pack_desc, ar, weight, wpk, create=True)
-        self.keep.append(ar)
-        cf = self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
-                       rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
-        bk = int(lib.addk_conv_fwd_batch_key(C.byref(ar)))
-        if bk >= 0:
-            cf.payload, cf.bkey = ar, bk
-        self.meta.append(dict(kind='conv_fwd', cmd=cf, flops=2.0 * N * OH * OW * Cout * k * k * csum,
-                              bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
-                              shape=(N, H, W, csum, Cout, k, stride, dil), halo=npk > 0))
-
+        if fwd:
+            ar = L.ConvArgs()
+            for i, s in enumerate(srcs):
+                assert (s.N, s.H, s.W) == (N, H, W), 'virtual concat needs equal spatial size'
+                ar.src[i] = self.src(s, relu_in)
+            ar.nsrc = len(srcs)
+            ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
+            ar.KH = ar.KW = k
+            ar.stride, ar.pad, ar.dil, ar.Cout = stride, pad, dil, Cout
+            ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = ldw, cin_total, w_choff, out.ld
+            ar.w, ar.y = wptr, out.ptr
+            ar.bias = self.param(bias) if bias is not None else None
+            ar.bias_n = bias_n.ptr if bias_n is not None else None
+            ar.stats = stats.ptr if stats is not None else None
+            ar.stats_ld = stats_ld
+            wpk = None
+            npk = int(lib.addk_conv_fwd_pack_floats(C.byref(ar)))       # > 0: wide 3x3 stride-1 conv, halo-patch kernel (conv3.hip)
+            if npk > 0:
+                wpk = self.buf(npk)
+                ar.wpack, ar.wpack_floats = wpk.ptr, npk
+                self._hoist_pack(lib.addk_conv_fwd_pack_desc, ar, weight, wpk, create=True)
+            self.keep.append(ar)
+            cf = self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
+                           rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
+            bk = int(lib.addk_conv_fwd_batch_key(C.byref(ar)))
+            if bk >= 0:
+                cf.payload, cf.bkey = ar, bk
+            self.meta.append(dict(kind='conv_fwd', cmd=cf, flops=2.0 * N * OH * OW * Cout * k * k * csum,
+                                  bytes=4.0 * (N * H * W * csum + N * OH * OW * Cout + Cout * k * k * csum),
+                                  shape=(N, H, W, csum, Cout, k, stride, dil), halo=npk > 0))
+    
         if self.want_grad:
             srcs_l = list(srcs)
 
@@ -894,8 +897,8 @@ class Graph:
         raw = self.conv(srcs, conv_mod.weight, Cout, k, stride, pad, dil, relu_in, out=out, stats=slab, **kw)
         return self.bn(raw, bn_mod, slab, rows or 0, post_relu)
 
-    def dwconv(self, src, conv_mod, relu_in):
-        """Depthwise conv; returns a materialised Act."""
+    def dwconv(self, src, conv_mod, relu_in, fwd=True):
+        """Depthwise conv; returns a materialised Act.  fwd=False: only the output buffer and the backward pass (sep_half)."""
         lib = self.lib
         k = conv_mod.kernel_size[0]
         stride, pad, dil = conv_mod.stride[0], conv_mod.padding[0], conv_mod.dilation[0]
@@ -909,10 +912,11 @@ class Graph:
         ar.N, ar.H, ar.W, ar.OH, ar.OW, ar.KH, ar.KW, ar.stride, ar.pad, ar.dil = N, H, W, OH, OW, k, k, stride, pad, dil
         ar.w, ar.y, ar.ldy = wptr, out.ptr, out.ld
         self.keep.append(ar)
-        cdw = self._add(self.fwd, 'dw_fwd', lib.addk_dw_fwd, C.byref(ar), rd=self.lz(src) + [conv_mod.weight], wr=[out])
-        bk = int(lib.addk_dw_fwd_batch_key(C.byref(ar)))
-        if bk >= 0:
-            cdw.payload, cdw.bkey = ar, bk
+        if fwd:
+            cdw = self._add(self.fwd, 'dw_fwd', lib.addk_dw_fwd, C.byref(ar), rd=self.lz(src) + [conv_mod.weight], wr=[out])
+            bk = int(lib.addk_dw_fwd_batch_key(C.byref(ar)))
+            if bk >= 0:
+                cdw.payload, cdw.bkey = ar, bk
         act = Act(out, None, False, self.want_grad)
         if self.want_grad:
             def emit_bwd():
@@ -950,6 +954,62 @@ class Graph:
                     cdb.payload, cdb.bkey = ba, bk
             self._bwd_emitters.append(emit_bwd)
         return act
+
+    def sep_half(self, src, dw_mod, pw_mod, bn_mod, sum_terms=None, out=None):
+        """One half of SepConv (operations.py:51-54 / 55-58): ReLU -> depthwise k x k -> pointwise 1x1 -> BN (lazy), as ONE
+        launch where the fused kernel covers the shape (addk_sep_fwd: the depthwise output stays on chip; in training it is
+        also written out because the backward pass reads it).  Inference only: `sum_terms` (other branches of the cell
+        block) makes the epilogue apply this op's frozen BatchNorm and write the block sum (ADD.py:108) into `out`."""
+        lib = self.lib
+        k = dw_mod.kernel_size[0]
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        Cout = pw_mod.out_channels
+        training = self.training and bn_mod.training
+        ar = L.SepArgs()
+        ar.src = self.src(src, True)
+        ar.N, ar.H, ar.W, ar.K, ar.Cout, ar.ldw = N, H, W, k, Cout, Cc
+        ar.dw_w, ar.pw_w = self.param(dw_mod.weight), self.param(pw_mod.weight)
+        fused = (os.environ.get('ADDK_FUSE_SEP', '1') == '1' and dw_mod.stride[0] == 1 and dw_mod.dilation[0] == 1
+                 and dw_mod.padding[0] == k // 2 and pw_mod.kernel_size[0] == 1 and (sum_terms is None or not (training or self.want_grad)))
+        if fused:
+            raw = out if out is not None else self.tensor(N, H, W, Cout)
+            ar.y, ar.ldy = raw.ptr, raw.ld
+            fused = bool(lib.addk_sep_fwd_supported(C.byref(ar)))
+        if not fused:
+            t = self.dwconv(src, dw_mod, relu_in=True)
+            act = self.conv_bn([t], pw_mod, bn_mod, relu_in=False)
+            return act if sum_terms is None else self.affine_sum(list(sum_terms) + [act], out=out)
+        t = self.dwconv(src, dw_mod, relu_in=True, fwd=False) if self.want_grad else None
+        slab = rows = None
+        if training:
+            slab, rows = self.stats_slab(N * H * W, Cout)
+        if t is not None:
+            self.conv([t], pw_mod.weight, Cout, 1, out=raw, stats=slab, fwd=False)       # backward of the pointwise half
+            ar.t, ar.ldt = t.raw.ptr, t.raw.ld
+        ar.stats = slab.ptr if slab is not None else None
+        ar.stats_ld = 0
+        rd = self.lz(src) + [dw_mod.weight, pw_mod.weight]
+        if sum_terms is not None:
+            # inference: y = a*acc + b (this op's frozen BatchNorm) + the other branches, written straight into the block's slot
+            st = self.bn(raw, bn_mod, None, 0).bn
+            terms = [tm for tm in sum_terms if not tm.zero]
+            assert len(terms) <= L.MAX_TERMS and out is not None
+            ar.ea, ar.eb, ar.nterm = st.a.ptr, st.b.ptr, len(terms)
+            for i, tm in enumerate(terms):
+                assert (tm.N, tm.H, tm.W, tm.C) == (N, H, W, Cout), 'branch shapes differ'
+                ar.term[i] = self.src(tm)
+                rd += self.lz(tm)
+            ar.y, ar.ldy = out.ptr, out.ld
+            rd += [st.a, st.b]
+            raw = out
+        self.keep.append(ar)
+        c = self._add(self.fwd, 'sep_fwd', lib.addk_sep_fwd, C.byref(ar), rd=rd, wr=[raw, slab, t.raw if t is not None else None])
+        bk = int(lib.addk_sep_fwd_batch_key(C.byref(ar)))
+        if bk >= 0:
+            c.payload, c.bkey = ar, bk
+        if sum_terms is not None:
+            return Act(raw, None, False, False)
+        return self.bn(raw, bn_mod, slab, rows or 0)
 
     def affine_sum(self, terms, out=None, relu_out=False):
         """Materialise sum_i relu_i?(a_i*x_i+b_i) (optionally ReLU'd) into `out`."""

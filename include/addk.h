@@ -173,6 +173,36 @@ int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, int32_t n, 
 int addk_conv_wgrad_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused SepConv half (reference modeling/operations.py:51-53 and :55-57): ReLU / lazy BatchNorm prologue -> depthwise
+ * K x K (stride 1, dilation 1, 'same' padding) -> pointwise 1x1 on the matrix cores -> BatchNorm statistics, ONE launch:
+ * the depthwise output never makes a round trip through HBM.  In training `t` receives the depthwise output (the
+ * backward pass reads it: pointwise weight gradient, depthwise backward); in inference t = NULL and the epilogue can
+ * apply the op's own (frozen) BatchNorm and add the other branches of the cell block (ADD.py:108):
+ *     y = ea[c]*acc + eb[c] + sum_i relu_i?(a_i*term_i + b_i)        (ea == NULL: plain y = acc)
+ * Covered shapes: K in {3,5}, C == Cout in (32, 48] or (64, 80], 16-byte aligned tensors; addk_sep_fwd_supported says so.
+ * ------------------------------------------------------------------------------------- */
+typedef struct addk_sep_args {
+  addk_src src;                     /* lazy input of the depthwise conv (x, a, b, relu) */
+  int32_t N, H, W;                  /* output size == input size */
+  int32_t K;                        /* depthwise kernel size (3 or 5) */
+  int32_t Cout; int32_t ldw;        /* pointwise: Cout x src.C weights, row stride ldw */
+  const float* dw_w;                /* depthwise weights [src.C][K*K] */
+  const float* pw_w;
+  float* y; int32_t ldy;
+  int32_t ldt; float* t;            /* depthwise output [P][ldt] or NULL */
+  void* stats; int32_t stats_ld;    /* fp64 (sum, sumsq) partial slab [rows][stats_ld][2] or NULL; rows = addk_conv_rows(P, Cout) */
+  int32_t nterm;                    /* inference epilogue: number of extra terms (0..ADDK_MAX_TERMS) */
+  const float* ea; const float* eb; /* inference epilogue: own affine (both NULL = none) */
+  addk_src term[ADDK_MAX_TERMS];
+} addk_sep_args;
+int addk_sep_fwd_supported(const addk_sep_args* a);      /* 1: the fused kernel covers this launch */
+int addk_sep_fwd(const addk_sep_args* a, void* stream);
+/* table-driven batch of the fused halves of one dependency level (same protocol as addk_conv_fwd_batch_prepare / addk_conv_batch_run) */
+int addk_sep_fwd_batch_key(const addk_sep_args* a);
+int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Depthwise k x k convolution (groups == C), stride 1 or 2, pad k/2*dil: the depthwise
  * halves of SepConv (operations.py:52,56).  w is [C][KH*KW] (torch [C,1,KH,KW]).
  * ------------------------------------------------------------------------------------- */

@@ -306,3 +306,76 @@ def test_register_streaming_wgrad_matches_fp64_reference(lib, name, N, H, W, Ci,
         torch.cuda.synchronize()
         outs[fast] = dw
         assert _rel(dw, ref) <= TOL, 'mask %d: %.2e' % (fast, _rel(dw, ref))
+
+
+SEP_SHAPES = [
+    # name,        N,  H,   W,  C, k
+    ('sep3_c40',   2, 61, 125, 40, 3),      # level-1 cells (F=20): 3 channel groups, odd map
+    ('sep5_c40',   1, 70, 125, 40, 5),
+    ('sep3_c80',   2, 33,  65, 80, 3),      # level-2 cells: 5 channel groups
+    ('sep5_c80',   2, 63, 127, 80, 5),
+    ('sep5_small', 1,  9,  11, 48, 5),      # map smaller than a tile row, every pixel touches the border
+]
+
+
+@pytest.mark.parametrize('shape', SEP_SHAPES, ids=[s[0] for s in SEP_SHAPES])
+def test_fused_sepconv_half_matches_fp64_reference(lib, shape):
+    """addk_sep_fwd (ReLU/lazy-BN prologue -> depthwise k x k -> pointwise 1x1 -> statistics in ONE launch) through the C ABI
+    against an fp64 PyTorch evaluation of the same half of SepConv (operations.py:51-54): training form (raw output, fp64
+    (sum, sumsq) slab, depthwise output written for the backward pass) and the inference form whose epilogue applies the
+    op's frozen BatchNorm and adds the other branches of the cell block (ADD.py:108)."""
+    L = lib
+    lb = L.load()
+    lb.addk_set_fast_paths(FAST_ALL)
+    name, N, H, W, Cc, k = shape
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    P = N * H * W
+    x, a, b = rnd(P, Cc), rnd(Cc), 0.3 * rnd(Cc)
+    wdw, wpw = 0.3 * rnd(Cc, k * k), 0.2 * rnd(Cc, Cc)
+    st = torch.cuda.current_stream().cuda_stream
+    # fp64 reference
+    xr = x.double().view(N, H, W, Cc).permute(0, 3, 1, 2)
+    z = F.relu(a.double().view(1, -1, 1, 1) * xr + b.double().view(1, -1, 1, 1))
+    t_ref = F.conv2d(z, wdw.double().view(Cc, 1, k, k), padding=k // 2, groups=Cc)
+    y_ref = F.conv2d(t_ref, wpw.double().view(Cc, Cc, 1, 1))
+    flat = lambda v: v.permute(0, 2, 3, 1).reshape(P, Cc)
+    ar = L.SepArgs()
+    ar.src.x, ar.src.a, ar.src.b, ar.src.ld, ar.src.C, ar.src.relu = x.data_ptr(), a.data_ptr(), b.data_ptr(), Cc, Cc, 1
+    ar.N, ar.H, ar.W, ar.K, ar.Cout, ar.ldw = N, H, W, k, Cc, Cc
+    ar.dw_w, ar.pw_w = wdw.data_ptr(), wpw.data_ptr()
+    y, t = torch.empty(P, Cc, device=dev), torch.empty(P, Cc, device=dev)
+    rows = lb.addk_conv_rows(P, Cc)
+    slab = torch.full((rows, Cc, 2), float('nan'), device=dev, dtype=torch.float64)
+    ar.y, ar.ldy, ar.t, ar.ldt, ar.stats, ar.stats_ld = y.data_ptr(), Cc, t.data_ptr(), Cc, slab.data_ptr(), Cc
+    assert lb.addk_sep_fwd_supported(C.byref(ar)) == 1
+    L.check(lb.addk_sep_fwd(C.byref(ar), st), 'sep_fwd')
+    torch.cuda.synchronize()
+    yl = flat(y_ref)
+    errs = {'t': _rel(t, flat(t_ref)), 'y': _rel(y, yl), 'stats': _rel(slab.sum(0), torch.stack([yl.sum(0), (yl * yl).sum(0)], 1))}
+    # inference form: y = ea*acc + eb + relu(a1*u1 + b1) + u2
+    ea, eb = 1 + 0.2 * rnd(Cc), 0.2 * rnd(Cc)
+    u1, a1, b1, u2 = rnd(P, Cc), rnd(Cc), 0.3 * rnd(Cc), rnd(P, Cc)
+    ar.t, ar.stats = None, None
+    ar.ea, ar.eb, ar.nterm = ea.data_ptr(), eb.data_ptr(), 2
+    ar.term[0].x, ar.term[0].a, ar.term[0].b, ar.term[0].ld, ar.term[0].C, ar.term[0].relu = u1.data_ptr(), a1.data_ptr(), b1.data_ptr(), Cc, Cc, 1
+    ar.term[1].x, ar.term[1].ld, ar.term[1].C, ar.term[1].relu = u2.data_ptr(), Cc, Cc, 0
+    y2 = torch.empty(P, Cc, device=dev)
+    ar.y = y2.data_ptr()
+    assert lb.addk_sep_fwd_supported(C.byref(ar)) == 1
+    L.check(lb.addk_sep_fwd(C.byref(ar), st), 'sep_fwd (inference epilogue)')
+    torch.cuda.synchronize()
+    ref2 = ea.double() * yl + eb.double() + F.relu(a1.double() * u1.double() + b1.double()) + u2.double()
+    errs['y_sum'] = _rel(y2, ref2)
+    # and against the two unfused launches on the same buffers
+    da = L.DwArgs()
+    da.src = ar.src
+    da.N, da.H, da.W, da.OH, da.OW, da.KH, da.KW, da.stride, da.pad, da.dil = N, H, W, H, W, k, k, 1, k // 2, 1
+    t2 = torch.empty(P, Cc, device=dev)
+    da.w, da.y, da.ldy = wdw.data_ptr(), t2.data_ptr(), Cc
+    L.check(lb.addk_dw_fwd(C.byref(da), st), 'dw_fwd')
+    torch.cuda.synchronize()
+    errs['t_vs_unfused'] = _rel(t, t2)
+    bad = ['%s %.2e' % kv for kv in errs.items() if not kv[1] <= TOL]
+    assert not bad, '%s beyond %.0e: %s' % (name, TOL, ', '.join(bad))

@@ -116,14 +116,27 @@ def test_positional_op_binding_q1(dry):
     m = _add(4)
     c = m.cells[0]
     assert isinstance(c._ops[8], DilConv) and isinstance(c._ops[9], SepConv)
-    order = []
-    for k, op in enumerate(c._ops):
-        orig = op.emit
-        op.emit = (lambda g, h, k=k, orig=orig: (order.append(k), orig(g, h))[1])
-    m.eval()
-    with torch.no_grad():
-        m(torch.randn(1, 3, 33, 65))
-    assert order == list(range(10))      # consumed strictly in genotype-row order
+    import addk.plan as P
+    seen = []
+    orig_init = P.Graph.__init__
+
+    def init(self, *a, **k):
+        orig_init(self, *a, **k)
+        self.bindings = seen                 # emit_blocks records (genotype row, branch index) pairs here
+    P.Graph.__init__ = init
+    try:
+        for mode in ('eval', 'train'):
+            del seen[:]
+            m.train(mode == 'train')
+            with torch.set_grad_enabled(mode == 'train'):
+                m(torch.randn(2, 3, 33, 65))
+            per_cell = seen[:10]
+            # row k of the genotype is bound to the k-th ACTIVE branch in ascending branch order, whatever order the launches of a
+            # block are emitted in (inference emits a block's closing SepConv last: it writes the branch sum itself)
+            assert per_cell == list(zip(range(10), sorted(int(v) for v in GENOTYPE_AUTODEEPLAB[:, 0]))), (mode, per_cell)
+            assert (8, 18) in per_cell and (9, 19) in per_cell
+    finally:
+        P.Graph.__init__ = orig_init
 
 
 def test_dynamic_plan_segments(dry):
