@@ -116,6 +116,7 @@ _SIGS = {
     'addk_conv_fwd': (i32, [C.POINTER(ConvArgs), vp]),
     'addk_conv_rows': (i32, [i64, i32]),
     'addk_set_conv_precision': (i32, [i32]),
+    'addk_set_split_min_channels': (i32, [i32]),
     'addk_get_conv_precision': (i32, []),
     'addk_conv_dgrad': (i32, [C.POINTER(ConvDgradArgs), vp]),
     'addk_set_fast_paths': (i32, [i32]),

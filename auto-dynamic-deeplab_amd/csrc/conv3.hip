@@ -54,6 +54,7 @@ struct PackK {
   int cvalid[C3_MAXCH];     // valid K entries in the chunk (<= 16)
   float* out;
   int planes;               // 0: fp32 fragments for conv3_kernel; 2 / 3: bf16 planes (h, m[, l]) in 32-row fragment order for conv3b_kernel
+  int dil_odd;              // conv3b: odd dilation -> taps with odd (kh + kw) carry a minus sign (checkerboard accumulation, see conv3b_kernel)
 };
 
 // out[colblk][T = chunk*taps + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
@@ -380,6 +381,8 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
     const int T = (int)(r % nT); const int blk = (int)(r / nT);
     const int chunk = T / p.taps, tap = T - chunk * p.taps;
     const int row = blk * BC + i * 32 + (lane & 31), k0 = 8 * (lane >> 5);
+    const int ks = p.taps == 9 ? 3 : 5;
+    const bool flip = p.dil_odd && (((tap / ks) + (tap % ks)) & 1);      // (-1)^((kh+kw) d): the tap's share of the checkerboard sign
     unsigned b[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -389,6 +392,7 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
         if (p.mode == MODE_FWD) v = p.w[(long)row * p.ldw + (long)tap * p.cin_total + p.cbase[chunk] + kk];
         else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
       }
+      if (flip) v = -v;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
     }
@@ -424,6 +428,13 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
   for (int kw = 0; kw < KS; ++kw) { const int pj = lp32 + kw * d; xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)); }
   const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)blockIdx.y * p.wp_blk + (long)wave * NP * 64 + lane);
   const int nT = p.nT;
+  unsigned pmask = 0;                         // bit k: parity of (r*d + pj) of this thread's patch slot k (checkerboard sign, below)
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int pix = (t + NTHR * k) >> 2;
+    const int r = pix / PWP, pj = pix - r * PWP;
+    pmask |= (unsigned)((r * d + pj) & 1) << k;
+  }
 
   const int tpx = p.ntiles >> 3;
   const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
@@ -434,6 +445,7 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
     const int ow0 = sx * C3_BP;
     unsigned vmask = 0;
     const int pbase = (n * p.H + oh - HK * d) * p.W + ow0 - HK * d;
+    const unsigned par0 = (unsigned)(oh + ow0);                 // parity of (ih + iw) of patch element (r, pj) = par0 + r*d + pj (the -2 HK d is even)
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const int pix = (t + NTHR * k) >> 2;
@@ -474,8 +486,10 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
         float4 v = ra[k];
         v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
         if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        // zero padding and the checkerboard sign in one factor: 0 outside the image, -1 for input pixels of odd (ih + iw), else +1
         const bool ok = pch && ((vmask >> k) & 1u);
-        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
+        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
         const int pix = (t + NTHR * k) >> 2;
         const int r = pix / PWP, pj = pix - r * PWP;
         if (r < KS) {
@@ -501,6 +515,16 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
 #pragma unroll
       for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + (kh * PWP + j * 32) * 2];
     };
+    // The accumulation inside the bf16 MFMA is not symmetric: what falls below its internal guard bits is floored, not rounded, so
+    // a result sits, on average, 0.17 rms errors BELOW the exact sum whatever the sign of the data (scripts/bf16_bias_probe.hip:
+    // mean error -2e-7 at |sum| ~ 1 for K = 2304; same for 32x32x16 and 16x16x32 and any term order; the fp32 MFMA shows
+    // none).  Per element that is below the rounding noise, but it is COHERENT: neighbouring pixels all err the same way, and
+    // the layers behind (3x3 windows, sums over 10^5-10^6 pixels) respond to such a DC shift far more than to white noise
+    // (whole-network frozen-BN gradients at 2x512x1024: 2.5x the error of the exact-fp32 kernels).  The kernel therefore
+    // computes a CHECKERBOARD of signs: output pixel (oh, ow) is accumulated as (-1)^(oh+ow) * y.  Input pixels of odd
+    // (ih + iw) are negated when they are staged (sign bits of the bf16 planes: exact), which puts (-1)^(oh+ow) * (-1)^((kh+kw) d)
+    // on the operand of tap (kh, kw); the second factor is uniform per tap and is baked into the packed weights; the epilogue undoes the
+    // pixel's sign.  The floor bias then alternates from pixel to pixel and averages out in every window and every sum.
     auto mma = [&](f32x16& c, const uint4* w, const uint4* x) {
       auto W = [&](int m) { return __builtin_bit_cast(bf16x8, w[m]); };
       auto X = [&](int m) { return __builtin_bit_cast(bf16x8, x[m]); };
@@ -512,16 +536,6 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(0), c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(1), c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(0), c, 0, 0, 0);
-    };
-    // The accumulation inside the bf16 MFMA is not symmetric: its result sits, on average, 0.17 rms errors BELOW the exact sum
-    // whatever the sign of the data (scripts/bf16_bias_probe.hip: mean error -2e-7 at |sum| ~ 1, same for 32x32x16 and 16x16x32,
-    // any term order; the fp32 MFMA shows none).  Per element that is below the rounding noise, but it is coherent, and sums
-    // over 10^5-10^6 pixels (BatchNorm statistics, (dA,dB), weight gradients) would collect it.  The odd 32-pixel tiles
-    // therefore run on NEGATED weights (sign bits flipped: exact) and are negated back in the epilogue: their bias points the
-    // other way and the per-channel sums over pixels see none.
-    auto negate = [&](const uint4* w, uint4* wn) {
-#pragma unroll
-      for (int m = 0; m < NP; ++m) wn[m] = make_uint4(w[m].x ^ 0x80008000u, w[m].y ^ 0x80008000u, w[m].z ^ 0x80008000u, w[m].w ^ 0x80008000u);
     };
 
     // Software pipeline, pinned with sched_barrier (left alone, the compiler sinks every prefetch down to its first use and the
@@ -544,14 +558,12 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
       for (int tap = 0; tap < TAPS; ++tap) {
         load_w(T0 + tap + 2, wr[(tap + 2) % 3]);
         if (tap == 0 && more) load_patch(s2, c2);
-        uint4 wn[NP];
-        negate(wr[tap % 3], wn);
 #pragma unroll
         for (int j = 0; j < CB_PT; ++j) {
           const int nj = (j + 1) % CB_PT, ntap = tap + (j + 1) / CB_PT;
           if (ntap < TAPS) read_x(ntap, nj, xr[(j + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
-          mma(acc[j], (j & 1) ? wn : wr[tap % 3], xr[j & 1]);
+          mma(acc[j], wr[tap % 3], xr[j & 1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -588,7 +600,7 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
         const int nrem = p.Cn - c;
         if (!pin || nrem <= 0) continue;
         float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-        if (j & 1) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // odd tiles were accumulated on negated weights
+        if ((par0 + (unsigned)lp32) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
         if (MODE == MODE_FWD) {
           if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
           if (p.bias_n) {
@@ -652,12 +664,18 @@ int c3b_wc(int Cn) {
 }
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
-// bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  The 5x5 convs with <= 64 output
-// channels (cells' dil_conv_5x5 at level 1) stay on the fp32 kernel: 2-wave blocks of the split kernel stage 22 slots per thread
-// and spill (measured 113 vs 88 us at 40 channels, 125x253).
+// bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  Launches with <= 64 output
+// channels (stem1, the cells' 40-channel dilated convs) stay on the fp32 kernel: the 2-wave blocks of the split kernel stage
+// 13-22 slots per thread and spill (5x5 at 40 channels: 113 vs 88 us), and in the whole-network frozen-BatchNorm gradient test
+// at 2x512x1024 they — not the wide variants — doubled the distance to the fp64 oracle (median 4.7e-4 vs 2.5e-4 with the fp32
+// kernels; with them excluded 2.5e-4, and the decoder / ASPP / late-cell gradients are 2-6x CLOSER to fp64 than on fp32 MFMA).
+// ADDK_C3B_MINC moves the threshold (experiments).
+int g_c3b_minc = -1;
 inline int c3_planes(int Cn, int taps) {
   const int m = addk_get_conv_precision();
-  if (m == 0 || (taps == 25 && Cn <= 64)) return 0;
+  (void)taps;
+  if (g_c3b_minc < 0) { const char* e = getenv("ADDK_C3B_MINC"); g_c3b_minc = e ? atoi(e) : 65; }
+  if (m == 0 || Cn < g_c3b_minc) return 0;
   return m == 2 ? 3 : 2;
 }
 // Column block (16-channel tiles per block).  128-channel blocks (2x2 waves) for the wide heads when that still
@@ -689,7 +707,7 @@ bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, 
 
 int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
   const int wc = c3b_wc(k.Cn);
-  pk.bct = wc; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np;
+  pk.bct = wc; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = k.dil & 1;
   k.nT = pk.nchunks * pk.taps;
   k.wp = pk.out;
   k.wp_blk = (long)pk.nchunks * pk.taps * wc * np * 64;          // 16-byte units per column block
@@ -723,7 +741,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
 }
 
 int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out = nullptr) {
-  pk.planes = 0;
+  pk.planes = 0; pk.dil_odd = 0;
   if (const int np = c3_planes(k.Cn, pk.taps)) return c3b_launch(k, pk, mode, rows, st, packed, desc_out, np);
   const int bct = c3_bct(k.Cn, k.P);
   pk.bct = bct; pk.mode = mode; pk.Cn = k.Cn;
@@ -821,6 +839,7 @@ static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK
   return c3_launch(k, pk, MODE_DGRAD, rows, (hipStream_t)stream, a->wpack_ready != 0, desc_out);
 }
 
+extern "C" int addk_set_split_min_channels(int c) { g_c3b_minc = c < 0 ? 65 : c; return ADDK_OK; }
 int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) { return c3_fwd(a, rows, stream, nullptr); }
 int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) { return c3_dgrad(a, rows, stream, nullptr); }
 

@@ -969,7 +969,7 @@ class Graph:
         ar.src = self.src(src, True)
         ar.N, ar.H, ar.W, ar.K, ar.Cout, ar.ldw = N, H, W, k, Cout, Cc
         ar.dw_w, ar.pw_w = self.param(dw_mod.weight), self.param(pw_mod.weight)
-        fused = (os.environ.get('ADDK_FUSE_SEP', '1') == '1' and dw_mod.stride[0] == 1 and dw_mod.dilation[0] == 1
+        fused = (os.environ.get('ADDK_FUSE_SEP', '0') == '1' and dw_mod.stride[0] == 1 and dw_mod.dilation[0] == 1
                  and dw_mod.padding[0] == k // 2 and pw_mod.kernel_size[0] == 1 and (sum_terms is None or not (training or self.want_grad)))
         if fused:
             raw = out if out is not None else self.tensor(N, H, W, Cout)

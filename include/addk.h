@@ -95,10 +95,18 @@ typedef struct addk_conv_args {
 int addk_conv_fwd(const addk_conv_args* a, void* stream);
 /* floats of `wpack` this launch can use; 0 = the halo-patch kernel does not cover the shape */
 int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a);
-/* Arithmetic of the dense contractions (fwd and dgrad): 0 = exact fp32 products on v_mfma_f32_16x16x4_f32 (default,
- * the parity path); 1 = split-bf16: x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with
- * fp32 accumulation (~1.5e-5 relative per product).  Process-wide; also ADDK_MATH=bf16x3 in the environment. */
+/* Arithmetic of the wide k x k stride-1 contractions (the halo-patch kernels, forward and data gradient):
+ *   0 = exact fp32 products on v_mfma_f32_16x16x4_f32;
+ *   2 = split-bf16, six terms (default): every fp32 operand is x = h + m + l with h, m, l in bf16 (3 x 8 bits = fp32's 24, exact)
+ *       and a product is the sum of its six largest bf16 x bf16 terms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation —
+ *       as accurate as the fp32 MFMA chain (rms 5.6e-8 vs 6.8e-8 of sum|a*b| at K = 2048) at 2.5x its rate;
+ *   1 = three terms (h*h, h*m, m*h): fast mode, rms ~5e-7.
+ * Every other kernel computes in fp32.  Process-wide; set before plans are built (packed-weight buffers are sized per mode).
+ * Environment: ADDK_MATH=fp32|bf16x6|bf16x3. */
 int addk_set_conv_precision(int mode);
+/* Split-bf16 modes: launches with fewer output channels than this stay on the exact fp32 kernel (default 65, see conv3.hip;
+ * tests lower it to reach the narrow variants).  c < 0 restores the default. */
+int addk_set_split_min_channels(int c);
 /* Specialised kernels that may replace the generic ones (all on by default; results agree to fp32 rounding).  The mask is
  * process-wide and is meant for tests and A/B timing; the environment (ADDK_PW=0, ADDK_C3=0, ADDK_WGRAD_H3=0, ADDK_DWTILE=0, ADDK_WGRAD_RS=0) sets the
  * initial value. */

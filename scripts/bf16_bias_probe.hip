@@ -12,10 +12,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x; float r = x - (float)h; m = (__bf16)r; r = r - (float)m; l = (__bf16)r;
 }
-// C[32][32] = A[32][K] * B[K][32]; mode 0: fp32 16x16x4 (4 tiles), 1: bf16x6 32x32x16, 2: bf16x6 16x16x32 (4 tiles), 3: bf16x6 32x32x16 big terms first
+// C[32][32] = A[32][K] * B[K][32]; mode 0: fp32 16x16x4 (4 tiles), 1: bf16x6 32x32x16, 2: bf16x6 16x16x32 (4 tiles), 3: bf16x6 32x32x16 big terms first,
+// 4: bf16x6 32x32x16 with the three small terms summed among themselves first and joined by rounded fp32 adds (what conv3b_kernel does)
 __global__ void k(const float* A, const float* B, float* C, int K, int mode) {
   const int lane = threadIdx.x;
-  if (mode == 1 || mode == 3) {
+  if (mode == 1 || mode == 3 || mode == 4) {
     const int r = lane & 31, h = lane >> 5;
     f32x16 acc; for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int k0 = 0; k0 < K; k0 += 16) {
@@ -25,7 +26,16 @@ __global__ void k(const float* A, const float* B, float* C, int K, int mode) {
         split3(A[r * K + k0 + 8 * h + j], x, y, z); ah[j] = x; am[j] = y; al[j] = z;
         split3(B[(k0 + 8 * h + j) * 32 + r], x, y, z); bh[j] = x; bm[j] = y; bl[j] = z;
       }
-      if (mode == 1) {
+      if (mode == 4) {
+        f32x16 z; for (int e = 0; e < 16; ++e) z[e] = 0.f;
+        f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, z, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, t, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        for (int e = 0; e < 16; ++e) acc[e] += t[e];
+      } else if (mode == 1) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
@@ -72,10 +82,10 @@ int main() {
   const int K = 2304, R = 16;        // R independent problems -> 16384 samples
   float *dA, *dB, *dC;
   hipMalloc(&dA, 32 * K * 4); hipMalloc(&dB, K * 32 * 4); hipMalloc(&dC, 1024 * 4);
-  const char* names[4] = {"fp32 mfma 16x16x4", "bf16x6 32x32x16 small-first", "bf16x6 16x16x32 small-first", "bf16x6 32x32x16 big-first"};
+  const char* names[5] = {"fp32 mfma 16x16x4", "bf16x6 32x32x16 small-first", "bf16x6 16x16x32 small-first", "bf16x6 32x32x16 big-first", "bf16x6 small terms apart"};
   for (int sgn = 0; sgn < 2; ++sgn) {
     printf(sgn ? "--- all-positive operands (no cancellation)\n" : "--- signed operands\n");
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
       double se = 0, se2 = 0, sref = 0; long n = 0;
       srand(7);
       for (int rep = 0; rep < R; ++rep) {

@@ -39,6 +39,7 @@ def lib():
     yield L
     L.load().addk_set_fast_paths(FAST_ALL)
     L.load().addk_set_conv_precision(prec)
+    L.load().addk_set_split_min_channels(-1)
 
 
 def _rel(a, b):
@@ -54,6 +55,7 @@ def _run(L, fast, shape, data, prec='fp32'):
     lib = L.load()
     lib.addk_set_fast_paths(fast)
     L.check(lib.addk_set_conv_precision(PREC[prec]), 'set_conv_precision')
+    lib.addk_set_split_min_channels(0)          # reach the narrow (<= 64 channel) variants of the split kernel too
     name, N, H, W, Cs, Cout, dil, ks = shape
     taps, pad = ks * ks, dil * (ks // 2)
     dev = data['w'].device
