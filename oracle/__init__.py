@@ -19,5 +19,5 @@ from .net import (  # noqa: F401
     PRIMITIVES, OPS, ReLUConvBN, DilConv, SepConv, Identity, Zero,
     FactorizedReduce, DoubleFactorizedReduce, ASPP_train, Decoder, Cell, ADD,
     EDM, Cell_baseline, Baselin_Model, normalized_shannon_entropy,
-    confidence_max, global_batch_norm, Evaluator, cross_entropy_mean_exits,
+    confidence_max, global_batch_norm, Evaluator, cross_entropy_mean_exits, class_weights_from_labels,
 )

@@ -629,3 +629,15 @@ class Evaluator:
         freq = cm.sum(dim=1) / cm.sum()
         iu = d / (cm.sum(dim=1) + cm.sum(dim=0) - d)
         return (freq[freq > 0] * iu[freq > 0]).sum()
+
+
+def class_weights_from_labels(label_batches, num_classes):
+    """utils/calculate_weights.py:6-29 restated with numpy: labels outside [0, num_classes) are dropped, the class
+    histogram z is accumulated over the batches, weight_c = 1 / ln(1.02 + z_c / sum(z))."""
+    import numpy as np
+    z = np.zeros((num_classes,))
+    for y in label_batches:
+        y = np.asarray(y)
+        mask = (y >= 0) & (y < num_classes)
+        z += np.bincount(y[mask].astype(np.uint8), minlength=num_classes)
+    return np.array([1 / np.log(1.02 + f / z.sum()) for f in z])
