@@ -137,6 +137,10 @@ _SIGS = {
     'addk_conv_wgrad_config': (i32, [C.POINTER(ConvWgradArgs), C.POINTER(i32)]),
     'addk_conv_wgrad_batch_prepare': (i64, [C.POINTER(ConvWgradArgs), i32, vp, i64, C.POINTER(i64)]),
     'addk_conv_wgrad_batch_run': (i32, [vp, C.POINTER(i64), vp]),
+    'addk_lut_u8': (i32, [vp, vp, i64, vp, vp]),
+    'addk_resample_u8': (i32, [vp, i32, i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
+    'addk_nearest_u8': (i32, [vp, i32, i32, vp, i32, i32, vp, vp, i32, vp]),
+    'addk_finish_sample': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'addk_sep_fwd_supported': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_fwd': (i32, [C.POINTER(SepArgs), vp]),
     'addk_sep_fwd_batch_key': (i32, [C.POINTER(SepArgs)]),

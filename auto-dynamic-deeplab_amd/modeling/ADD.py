@@ -333,5 +333,6 @@ class EDM(AddkModule):
         return v
 
     def forward(self, x):
+        x = x.squeeze(1)                      # ADD.py:516: train_edm.py feeds [bs, 1, 400, h, w] (features stored per batch of 1)
         out = self.run_plan(self.emit, (x,))
         return out.reshape(out.shape[0], -1)

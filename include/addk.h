@@ -413,6 +413,25 @@ int addk_entropy_sum(const float* logits_nchw, int32_t N, int32_t C, int64_t HW,
 int addk_argmax_nchw(const float* logits, int32_t N, int32_t C, int64_t HW, int64_t* out, void* stream);
 int addk_confusion(const int64_t* gt, const int64_t* pred, int64_t n, int32_t num_class, int64_t* cm, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * GPU input pipeline: Cityscapes sample preparation from DECODED 8-bit planes (reference
+ * dataloaders/datasets/cityscapes.py:64-91 encode_segmap; dataloaders/custom_transforms.py:238-286 train_preprocess,
+ * :322-347 full_image_eval_preprocess).  Bit-exact with the reference's PIL calls: the resampling tables are built on the
+ * host with PIL's own arithmetic (addk/data.py) and the kernels apply them in PIL's fixed point.
+ * ------------------------------------------------------------------------------------- */
+int addk_lut_u8(const uint8_t* in, uint8_t* out, int64_t n, const uint8_t* lut256, void* stream);
+/* one pass of the antialiased 8-bit resize (interleaved C channels): out = clip8(((1<<21) + sum_k in*coef[k]) >> 22);
+ * bounds[2*o] = first source index, bounds[2*o+1] = tap count of output index o; coef is [out extent][ksize] int32.
+ * vertical = 0: along x (mirror = 1 reads the row right-to-left: the random flip); vertical = 1: along y. */
+int addk_resample_u8(const uint8_t* in, int32_t IH, int32_t IW, uint8_t* out, int32_t OH, int32_t OW, int32_t C, const int32_t* bounds,
+                     const int32_t* coef, int32_t ksize, int32_t vertical, int32_t mirror, void* stream);
+/* NEAREST resize of a label plane through source-index tables (xtab[OW], ytab[OH]) */
+int addk_nearest_u8(const uint8_t* in, int32_t IH, int32_t IW, uint8_t* out, int32_t OH, int32_t OW, const int32_t* xtab, const int32_t* ytab,
+                    int32_t mirror, void* stream);
+/* ToTensor + Normalize + pad (image 0, label 255) + crop at (i0, j0): HWC u8 -> CHW float [3][CH][CW], labels -> int64 [CH][CW] (lbl/out_lbl may be NULL) */
+int addk_finish_sample(const uint8_t* img, const uint8_t* lbl, int32_t IH, int32_t IW, int32_t i0, int32_t j0, int32_t CH, int32_t CW,
+                       const float* mean3, const float* std3, float* out_img, int64_t* out_lbl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -476,6 +476,7 @@ class EDM(nn.Module):
                                  nn.ReLU(), nn.Linear(32, 1))
 
     def forward(self, x):
+        x = x.squeeze(1)                                  # ADD.py:516
         x = F.relu(self.conv(F.relu(x)))
         return self.edm(x.mean(dim=(2, 3)))
 
