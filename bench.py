@@ -278,6 +278,12 @@ def main():
         print(json.dumps(_cpu_baseline_child(genotype, a.batch, a.height, a.width)))
         return
 
+    # exactly ONE line on stdout: RCCL prints a version banner to stdout when a communicator is created, so the process's
+    # stdout is pointed at stderr for the whole run and the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(out_fd, 'w')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -392,7 +398,8 @@ def main():
             if len(losses) > 1 and cb.get('second_step_loss') is not None:
                 out['first_step_loss_vs_cpu_oracle']['second_step'] = {'gpu': losses[1], 'cpu_oracle': cb['second_step_loss']}
             assert rel <= 1e-3, 'first-step loss %.7f differs from the CPU oracle %.7f on the same inputs (rel %.2e)' % (losses[0], ref, rel)
-    print(json.dumps(out), flush=True)
+    json_out.write(json.dumps(out) + '\n')
+    json_out.flush()
     if comm is not None:
         torch.distributed.destroy_process_group()
 

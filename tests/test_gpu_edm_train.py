@@ -22,13 +22,13 @@ def test_edm_data_and_training_match_the_oracle():
     mo.eval()
     images = [rand_tensor(300 + i, 'edm_img', (1, 3, 65, 129)) for i in range(4)]
     feats, ents = make_edm_data(ma, [{'image': im} for im in images], device=dev)
-    assert tuple(feats.shape) == (4, 1, 400, 9, 17) and tuple(ents.shape) == (4,)
     fo, eo = [], []
     with torch.no_grad():
         for im in images:
             out, f = mo.get_feature(im)
             fo.append(f); eo.append(oracle.normalized_shannon_entropy(out))
     fo = torch.stack(fo)
+    assert tuple(feats.shape) == tuple(fo.shape) and feats.shape[:3] == (4, 1, 400) and tuple(ents.shape) == (4,)
     assert rel_err(feats, fo) <= 1e-3
     assert np.allclose(ents.cpu().numpy(), np.array(eo, dtype=np.float32), rtol=1e-4, atol=1e-6)
     # two Adam steps, reference form: L1Loss()(edm(feature) [bs,1], entropy [bs]) broadcasts to [bs,bs]
