@@ -467,6 +467,207 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
     }
 }
 
+// Split-bf16 form of wgrad_h3_kernel (same work decomposition, same partial-tile layout, same epilogue): dy and the
+// activations are written as h + m + l in bf16 (exact) and a product is the sum of its six largest bf16 x bf16 terms on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (conv3.hip: as accurate as the fp32 MFMA chain at 2.5x its rate).
+// The MFMA's K axis is the PIXEL index here, while both operands arrive pixel-major ([pixel][channel] rows from NHWC
+// memory): the staged LDS images stay pixel-major — per 16-channel tile [pixel][16 ch] bf16, 32-byte rows, 8-byte writes —
+// and the fragments are fetched with the hardware transposing read ds_read_b64_tr_b16 (a 16-lane group reads a
+// 4-pixel x 16-channel block and every lane receives ITS channel's four pixels): two reads give a lane the 8 consecutive
+// pixels of its channel that the 16x16x32 operand wants, for dy and for every tap-shifted window of the activation rows
+// alike (any pixel shift is a row offset: always aligned).  A pixel's row sits at 32*p with the two 128-byte halves of
+// every 8-pixel block swapped when bit 3 of p is set: the two groups of a half-wave (pixels p..p+3 and p+8..p+11) then hit
+// disjoint banks for every shift (scripts/tr_read_probe.hip checks the lane map and the operand on the device).
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) wg_s16x4 wg_lds_s16x4;
+__device__ __forceinline__ unsigned wg_bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float wg_bf16_f(unsigned b) { return __uint_as_float(b << 16); }
+template <int NP>
+__device__ __forceinline__ void wg_split4(const float4 v, uint2 (&pl)[NP]) {
+  float r[4] = {v.x, v.y, v.z, v.w};
+  unsigned b[NP][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = r[e];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { b[k][e] = wg_bf16_hi(x); x = x - wg_bf16_f(b[k][e]); }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) pl[k] = make_uint2(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16));
+}
+// byte offset of pixel row p inside a [pixel][16 ch] bf16 tile image
+__device__ __forceinline__ int wg_prow(int p) { return (p << 5) ^ (((p >> 3) & 1) << 7); }
+
+template <int NT, bool BATCH, int NP>
+__global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
+  if (BATCH) {
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK& p = BATCH ? ops[op] : pv;
+  constexpr int BCO = 64 * NT, YT = BCO / 16, YQ = BCO / 4, YRS = 256 / YQ;
+  constexpr int NYJ = H3_KP / YRS;
+  constexpr int NZJ = (3 * H3_ZW * 4 + 255) / 256;
+  constexpr int ZWP = 104;                                        // patch row pitch in pixels (>= 64 + 2*18, multiple of 8: the swizzle works on 8-pixel blocks)
+  constexpr int YIMG = H3_KP * 32, ZROW = ZWP * 32;               // bytes per dy tile image / per activation patch row (one plane)
+  constexpr int YPL = YT * YIMG, ZPL = 3 * ZROW;                  // bytes per plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  unsigned char* Yb = wsm;                                        // [NP][YT][64 px][16 co]
+  unsigned char* Zb = wsm + NP * YPL;                             // [NP][3 rows][ZWP px][16 ci]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
+  const int co0 = yt * BCO, c0 = zt * 16;
+  const int d = p.dil, ZW = H3_KP + 2 * d;
+  const int spr = (p.OW + H3_KP - 1) / H3_KP;
+  const int nseg = p.N * p.OH * spr;
+  const int sbeg = blk_y * p.chunkP;
+  int send = sbeg + p.chunkP; if (send > nseg) send = nseg;
+
+  const int yq = t & (YQ - 1), yrow0 = t / YQ;
+  const int co = co0 + 4 * yq;
+  const bool co_ok = co < p.Cout;
+  const int zq = t & 3, zc = c0 + 4 * zq, nremz = p.src.C - zc;
+  float4 za = make_float4(1.f, 1.f, 1.f, 1.f), zb = zero4();
+  if (p.src.a && nremz > 0) { za = ld4g(p.src.a + zc, nremz, p.vecZ); zb = ld4g(p.src.b + zc, nremz, p.vecZ); }
+  const bool zrelu = p.src.relu != 0;
+  // transposed-read lane geometry: lane 16g + 4q + pp supplies (pixel row q of the block, channels 4pp..4pp+3)
+  const int tq = li >> 2, tp = li & 3;
+  const int lrow = 8 * kq + tq;                                   // this lane's pixel row inside a 32-pixel k-step (first read; second +4)
+
+  f32x4 acc[NT][9];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ry[NYJ], rz[NZJ];
+  unsigned ymask = 0, zmask = 0;
+  auto load_step = [&](int seg) {
+    const int rowid = seg / spr, sx = seg - rowid * spr;
+    const int n = rowid / p.OH, oh = rowid - n * p.OH;
+    const int ow0 = sx * H3_KP;
+    const long pp0 = (long)rowid * p.OW + ow0;
+    const float* yb = p.dy + pp0 * p.lddy + co;
+    ymask = 0; zmask = 0;
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      const int row = yrow0 + k * YRS;
+      const bool ok = co_ok && ow0 + row < p.OW;
+      ry[k] = ld4(ok ? yb + (long)row * p.lddy : p.dy);
+      ymask |= (ok ? 1u : 0u) << k;
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      const int pix = (t + 256 * k) >> 2;
+      const int zr = pix / ZW, zj = pix - zr * ZW;
+      const int ih = oh + (zr - 1) * d, iw = ow0 - d + zj;
+      const bool ok = zr < 3 && nremz > 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rz[k] = ld4(ok ? p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + zc : p.src.x);
+      zmask |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      float4 v = ry[k];
+      const bool ok = (ymask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      uint2 pl[NP];
+      wg_split4<NP>(v, pl);
+      const int off = (yq >> 2) * YIMG + wg_prow(yrow0 + k * YRS) + 8 * (yq & 3);
+#pragma unroll
+      for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(Yb + m * YPL + off) = pl[m];
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      float4 v = rz[k];
+      v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
+      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const bool ok = (zmask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      const int pix = (t + 256 * k) >> 2;
+      const int zr = pix / ZW, zj = pix - zr * ZW;
+      if (zr < 3) {
+        uint2 pl[NP];
+        wg_split4<NP>(v, pl);
+        const int off = zr * ZROW + wg_prow(zj) + 8 * zq;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(Zb + m * ZPL + off) = pl[m];
+      }
+    }
+  };
+  // fragment of one 32-pixel k-step: 8 consecutive pixels of this lane's channel = two transposed reads, per plane
+  auto rd = [&](const unsigned char* base, int plane_bytes, int pix0, wg_bf16x8* f) {
+    const int o0 = wg_prow(pix0 + lrow) + 8 * tp, o1 = wg_prow(pix0 + lrow + 4) + 8 * tp;
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o0));
+      const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o1));
+      wg_bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = __builtin_bit_cast(__bf16, lo[e]); v[4 + e] = __builtin_bit_cast(__bf16, hi[e]); }
+      f[m] = v;
+    }
+  };
+  auto mma = [&](f32x4& c, const wg_bf16x8* y, const wg_bf16x8* z) {
+    if (NP == 3) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[2], z[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[0], z[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[1], z[1], c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[1], z[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[0], z[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[0], z[0], c, 0, 0, 0);
+  };
+
+  if (sbeg < send) {
+    load_step(sbeg);
+    store_step();
+    __syncthreads();
+    for (int seg = sbeg; seg < send; ++seg) {
+      const bool more = seg + 1 < send;
+      if (more) load_step(seg + 1);
+#pragma unroll
+      for (int ks = 0; ks < H3_KP / 32; ++ks) {
+        wg_bf16x8 yf[NT][NP];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rd(Yb + (wave * NT + i) * YIMG, YPL, ks * 32, yf[i]);
+        wg_bf16x8 zf[2][NP];
+        rd(Zb, ZPL, ks * 32, zf[0]);                              // tap 0: patch row 0, shift 0
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (tap + 1 < 9) rd(Zb + ((tap + 1) / 3) * ZROW, ZPL, ks * 32 + ((tap + 1) % 3) * d, zf[(tap + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NT; ++i) mma(acc[i][tap], yf[i], zf[tap & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      if (more) { store_step(); __syncthreads(); }
+    }
+  }
+  const int C = p.src.C;
+  float* wsb = p.ws + (long)blk_y * p.Cout * 9 * C;
+  const int c = c0 + li;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cow = co0 + (wave * NT + i) * 16 + kq * 4 + r;
+      if (cow < p.Cout && c < C) {
+        float* o = wsb + (long)cow * 9 * C + c;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) o[tap * C] = acc[i][tap][r];
+      }
+    }
+}
+inline bool wgrad_split_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
+constexpr size_t wg_h3b_lds(int nt, int np) { return (size_t)np * ((64 * nt / 16) * H3_KP * 32 + 3 * 104 * 32); }
+
 // Halo-patch weight gradient of the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5: 40/80/160 channels,
 // dilation <= 2).  Same staging as wgrad_h3_kernel — per 64-pixel row segment dy [64][16*CT] and the KS activation rows
 // [KS][64+(KS-1)d][16] go to LDS once and every tap reads its shifted window — but the accumulators are split the other
@@ -1034,8 +1235,20 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_RS(3, 3) ADDK_RS(3, 4) ADDK_RS(4, 3) ADDK_RS(4, 4)
 #undef ADDK_RS
+  // wide 3x3 (decoder, ASPP: 128-channel blocks) in a split-bf16 mode: the transposed-read kernel; the 64-channel blocks
+  // (stem1) stay on fp32, as the narrow launches of the forward / data-gradient kernels do (conv3.hip, c3_planes)
+  const int wg_np = addk_get_conv_precision() == 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;
+#define ADDK_H3B_(B_, P_) { \
+    static bool attr = false; \
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<2, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    hipLaunchKernelGGL((wgrad_h3b_kernel<2, B_, P_>), grid, dim3(256), wg_h3b_lds(2, P_), st, k, ops, work); done = true; }
+  if (kind == 5 && cty == 8 && wg_np && wgrad_split_enabled()) {
+    if (ops) { if (wg_np == 3) ADDK_H3B_(true, 3) else ADDK_H3B_(true, 2) }
+    else { if (wg_np == 3) ADDK_H3B_(false, 3) else ADDK_H3B_(false, 2) }
+  }
+#undef ADDK_H3B_
 #define ADDK_H3(NT_) \
-  if (kind == 5 && cty == 4 * NT_) { \
+  if (!done && kind == 5 && cty == 4 * NT_) { \
     if (ops) hipLaunchKernelGGL((wgrad_h3_kernel<NT_, true>), grid, dim3(256), 0, st, k, ops, work); \
     else hipLaunchKernelGGL((wgrad_h3_kernel<NT_, false>), grid, dim3(256), 0, st, k, ops, work); \
     done = true; }
