@@ -606,10 +606,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
     for (int m = 0; m < NP; ++m) {
       const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o0));
       const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o1));
-      wg_bf16x8 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = __builtin_bit_cast(__bf16, lo[e]); v[4 + e] = __builtin_bit_cast(__bf16, hi[e]); }
-      f[m] = v;
+      // whole-register reinterpretation: building the fragment element by element from the two results is miscompiled by
+      // hipcc 7.2 (it drops the upper dword of each 64-bit result: scripts/tr_read_probe.hip)
+      struct { wg_s16x4 a, b; } pr = {lo, hi};
+      f[m] = __builtin_bit_cast(wg_bf16x8, pr);
     }
   };
   auto mma = [&](f32x4& c, const wg_bf16x8* y, const wg_bf16x8* z) {

@@ -31,9 +31,10 @@ __global__ void mfma_kernel(const unsigned short* A, const unsigned short* B, fl
   auto frag = [&](const unsigned short* img) {
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&img[(8 * g + q) * 16 + 4 * p]);
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&img[(8 * g + 4 + q) * 16 + 4 * p]);
-    bf16x8 f;
-    for (int e = 0; e < 4; ++e) { f[e] = __builtin_bit_cast(__bf16, lo[e]); f[4 + e] = __builtin_bit_cast(__bf16, hi[e]); }
-    return f;
+    // NB: assembling the fragment element by element (f[e] = bit_cast<bf16>(lo[e]) ...) is miscompiled by hipcc 7.2 — it keeps only
+    // the low dword of each 64-bit result; reinterpret the register pair as a whole instead
+    struct { s16x4 a, b; } pr = {lo, hi};
+    return __builtin_bit_cast(bf16x8, pr);
   };
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(sa), frag(sb), acc, 0, 0, 0);
