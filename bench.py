@@ -265,6 +265,7 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--F', type=int, default=20)
+    ap.add_argument('--genotype', default='autodeeplab/genotype', help="cell genotype under searched_arch/ (config 5: --F 40 --genotype 40_5e_38_lr/genotype_1)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the segment roofline / per-exit latency / drop-in measurements')
     ap.add_argument('--no-graph', action='store_true')
@@ -273,7 +274,7 @@ def main():
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--force-sync', action='store_true', help='rehearse the N>1 path (RCCL SyncBN + gradient all-reduce) at world_size 1')
     a = ap.parse_args()
-    genotype = np.load(os.path.join(ROOT, 'searched_arch', 'autodeeplab', 'genotype.npy'))
+    genotype = np.load(os.path.join(ROOT, 'searched_arch', a.genotype + '.npy'))
     if a.cpu_baseline_child:
         print(json.dumps(_cpu_baseline_child(genotype, a.batch, a.height, a.width)))
         return
@@ -357,8 +358,17 @@ def main():
         kern = 'conv3b_kernel (v_mfma_f32_32x32x16_bf16, %d bf16 product terms per fp32 product)' % terms
         peak_note = 'dense bf16 MFMA peak %.0f TFLOP/s / %d matrix instructions per fp32 multiply-add' % (PEAK_MFMA_BF16_TFLOPS, terms)
     ach = top['flops'] / tk / 1e12
-    roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-            'traffic_note': 'PMC passes cannot run inside this process; per-launch FETCH/WRITE bytes of this kernel are in profiles/ (separate rocprofv3 --pmc runs)',
+    # HBM-side traffic of that launch: PMC passes cannot run inside this process; the committed rocprofv3 --pmc measurement of the
+    # same kernel and shape (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes: scripts/refresh_profiles_r02.sh) is quoted, labelled
+    traffic, tsrc = None, None
+    tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_decoder_conv3b.json')
+    if halo and math == 'bf16x6' and (n, h, w, a.F, a.genotype) == (2, 1024, 2048, 20, 'autodeeplab/genotype') and os.path.exists(tpath):
+        try:
+            traffic, tsrc = json.load(open(tpath)).get('traffic_bytes_per_launch'), 'profiles/r02_pmc_traffic_decoder_conv3b.json (not measured in this run)'
+        except Exception:
+            pass
+    roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
+            'traffic_source': tsrc,
             'peak_note': peak_note, 'executed_matrix_TFLOPs': ach * terms, 'frac_of_fp32_matrix_peak': ach / PEAK_MFMA_F32_TFLOPS,
             'kernel': kern, 'launch_ms': tk * 1e3,
             'launch_shape_NHWCinCoutKSD': list(top['shape']), 'algorithmic_gflop_per_launch': top['flops'] / 1e9,
@@ -369,7 +379,7 @@ def main():
            'scaling': 'weak', 'vs_baseline': None,
            'dtype': 'f32' if math == 'fp32' else 'f32 storage and accumulation; k x k contractions as %s split-bf16 MFMA products' % math,
            'data': 'synthetic',
-           'config': {'workload': 'ADD F=%d searched_arch/autodeeplab C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, h, w, n),
+           'config': {'workload': 'ADD F=%d searched_arch/%s C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, a.genotype, h, w, n),
                       'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': comm is not None,
                       'hip_graph': bool(ts.graph is not None), 'math': math},
            'loss': loss, 'first_step_losses': losses,
@@ -377,7 +387,8 @@ def main():
            'step_tflops_per_gpu': step_tflops, 'step_frac_mfma': step_tflops / PEAK_MFMA_F32_TFLOPS,
            'plan_device_gb': ts.nbytes / 1e9,
            'roofline': roof}
-    extras = world == 1 and not a.no_extras and comm is None and (n, h, w, a.F) == (2, 1024, 2048, 20)
+    default_cfg = (n, h, w, a.F, a.genotype) == (2, 1024, 2048, 20, 'autodeeplab/genotype')
+    extras = world == 1 and not a.no_extras and comm is None and default_cfg
     if extras:
         del ts
         torch.cuda.empty_cache()
@@ -388,7 +399,7 @@ def main():
                            'frac': seg['eval']['frac_hbm']}
         out['per_exit_ms'] = per_exit_latency(model, dev)
         out['drop_in'] = drop_in_step(model, x, t)
-    if not a.no_cpu_baseline and world == 1:
+    if not a.no_cpu_baseline and world == 1 and default_cfg:
         cb = cpu_baseline(n, h, w)
         out['cpu_baseline'] = cb
         ref = cb.get('first_step_loss')

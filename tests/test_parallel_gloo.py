@@ -242,3 +242,19 @@ def _ddp_without_syncbn(rank, world):
 def test_gradients_are_averaged_without_syncbn():
     for world, lo, hi, scale, nstat in _spawn(_ddp_without_syncbn):
         assert world == 2 and lo == hi == 3.0 and scale == 0.5 and nstat == 0
+
+
+def test_shard_indices_equal_torch_distributed_sampler():
+    """parallel.shard_indices reproduces torch.utils.data.DistributedSampler (dataloaders/__init__.py:33: default shuffle=True,
+    seed 0, never set_epoch) for every rank, incl. the wrap-around padding, other epochs/seeds and shuffle=False."""
+    from torch.utils.data import DistributedSampler
+    from addk import parallel
+    for n, world in ((10, 4), (2975, 8), (7, 3), (16, 16), (5, 8)):
+        ds = list(range(n))
+        for rank in range(world):
+            for kw in (dict(), dict(shuffle=False), dict(seed=3)):
+                s = DistributedSampler(ds, num_replicas=world, rank=rank, **kw)
+                assert list(s) == parallel.shard_indices(n, rank, world, **kw), (n, world, rank, kw)
+            s = DistributedSampler(ds, num_replicas=world, rank=rank)
+            s.set_epoch(5)
+            assert list(s) == parallel.shard_indices(n, rank, world, epoch=5)
