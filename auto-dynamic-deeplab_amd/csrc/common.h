@@ -31,26 +31,46 @@ static inline bool src_vec_ok(const addk_src& s) {
   return aligned16(s.x) && (s.ld % 4 == 0) && (s.C % 4 == 0) && (!s.a || aligned16(s.a)) && (!s.b || aligned16(s.b));
 }
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Pointers that reach a kernel through a descriptor TABLE in device memory (the batched launches) carry no address-space
+// information: the compiler emits flat_load / flat_store for them, which count on lgkmcnt together with the LDS traffic
+// (every wait for a fragment read then also waits for the global loads in flight) and probe the apertures.  gptr() states
+// that a pointer is global memory; ld4 / st4 (and everything built on them) are GLOBAL accesses — LDS staging uses
+// lds_ld4 / lds_st4.
+// gfloat* / gdouble*: explicitly-global views for the scalar accesses.
+template <class T> __device__ __forceinline__ T* gptr(T* p) { return (T*)(__attribute__((address_space(1))) T*)p; }
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) double gdouble;
+typedef float addk_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p) {
+  const addk_f32x4 v = *(const __attribute__((address_space(1))) addk_f32x4*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) {
+  const addk_f32x4 t = {v.x, v.y, v.z, v.w};
+  *(__attribute__((address_space(1))) addk_f32x4*)p = t;
+}
+__device__ __forceinline__ float4 lds_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void lds_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // guarded 4-element load: elements with index >= n read as 0
 __device__ __forceinline__ float4 ld4g(const float* p, int n, bool vec) {
   if (vec && n >= 4) return ld4(p);
   float4 v = zero4();
-  if (n > 0) v.x = p[0];
-  if (n > 1) v.y = p[1];
-  if (n > 2) v.z = p[2];
-  if (n > 3) v.w = p[3];
+  const gfloat* g = (const gfloat*)p;
+  if (n > 0) v.x = g[0];
+  if (n > 1) v.y = g[1];
+  if (n > 2) v.z = g[2];
+  if (n > 3) v.w = g[3];
   return v;
 }
 __device__ __forceinline__ void st4g(float* p, float4 v, int n, bool vec) {
   if (vec && n >= 4) { st4(p, v); return; }
-  if (n > 0) p[0] = v.x;
-  if (n > 1) p[1] = v.y;
-  if (n > 2) p[2] = v.z;
-  if (n > 3) p[3] = v.w;
+  gfloat* g = (gfloat*)p;
+  if (n > 0) g[0] = v.x;
+  if (n > 1) g[1] = v.y;
+  if (n > 2) g[2] = v.z;
+  if (n > 3) g[3] = v.w;
 }
 
 // lazy prologue z = relu?(a*x+b) on 4 channels; lanes >= n stay 0

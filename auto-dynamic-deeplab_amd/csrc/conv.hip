@@ -254,12 +254,12 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
         return;
       }
 #pragma unroll
-      for (int j = 0; j < NAJ; ++j) st4(&As[(ar + 32 * j) * BKP + 4 * aq], ra[j]);
+      for (int j = 0; j < NAJ; ++j) lds_st4(&As[(ar + 32 * j) * BKP + 4 * aq], ra[j]);
       if (MODE == MODE_FWD) {
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
           int slot = t + 256 * j, row = slot >> 3, q = slot & 7;
-          if (row < BC) st4(&Bs[row * BKP + 4 * q], rb[j]);
+          if (row < BC) lds_st4(&Bs[row * BKP + 4 * q], rb[j]);
         }
       } else {
 #pragma unroll

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
         const bool ok = pch && ((vmask >> k) & 1u);
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
         const int r = geo[k] & 7, pj = geo[k] >> 3;
-        if (r < KS) st4(&Ps[(r * C3_PWMAX + pj) * C3_RS + 4 * q], v);
+        if (r < KS) lds_st4(&Ps[(r * C3_PWMAX + pj) * C3_RS + 4 * q], v);
       }
     };
 

@@ -110,14 +110,14 @@ __device__ __forceinline__ void dw_fwd_tile_body(const DwT& t, float* sm) {
       v.x = fmaf(av.x, v.x, bv.x); v.y = fmaf(av.y, v.y, bv.y); v.z = fmaf(av.z, v.z, bv.z); v.w = fmaf(av.w, v.w, bv.w);
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      st4(&patch[pix * C4b + 4 * q], v);
+      lds_st4(&patch[pix * C4b + 4 * q], v);
     }
   }
   __syncthreads();
   if (!cact) return;
   float4 wr[KS * KS];
 #pragma unroll
-  for (int tp = 0; tp < KS * KS; ++tp) wr[tp] = ld4(&wl[tp * C4b + 4 * q]);
+  for (int tp = 0; tp < KS * KS; ++tp) wr[tp] = lds_ld4(&wl[tp * C4b + 4 * q]);
   const int nout = t.TH * DW_TW;
   for (int o = pl; o < nout; o += npl) {
     const int orow = o / DW_TW, ocol = o - orow * DW_TW;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void dw_fwd_tile_body(const DwT& t, float* sm) {
     for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
       for (int kw = 0; kw < KS; ++kw) {
-        const float4 v = ld4(pb + ((kh * p.dil) * t.PW + kw * p.dil) * C4b);
+        const float4 v = lds_ld4(pb + ((kh * p.dil) * t.PW + kw * p.dil) * C4b);
         const float4 w = wr[kh * KS + kw];
         acc.x = fmaf(w.x, v.x, acc.x); acc.y = fmaf(w.y, v.y, acc.y); acc.z = fmaf(w.z, v.z, acc.z); acc.w = fmaf(w.w, v.w, acc.w);
       }
@@ -292,7 +292,7 @@ __device__ __forceinline__ void dw_bwd_tile_body(const DwT& t, float* sm) {
         const bool ok = cact && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
         float4 v = ld4(yb + (ok ? ((long)(n * p.OH + oh) * p.OW + ow) * p.lddy : 0));
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-        st4(&patch[pix * C4b + 4 * q], v);
+        lds_st4(&patch[pix * C4b + 4 * q], v);
       }
     }
     __syncthreads();
@@ -314,8 +314,8 @@ __device__ __forceinline__ void dw_bwd_tile_body(const DwT& t, float* sm) {
 #pragma unroll
           for (int kw = 0; kw < KS; ++kw) {
             const int tp = kh * KS + kw;
-            const float4 d = ld4(pb + (((KS - 1 - kh) * p.dil) * t.PW + (KS - 1 - kw) * p.dil) * C4b);
-            const float4 w = ld4(&wl[tp * C4b + 4 * q]);
+            const float4 d = lds_ld4(pb + (((KS - 1 - kh) * p.dil) * t.PW + (KS - 1 - kw) * p.dil) * C4b);
+            const float4 w = lds_ld4(&wl[tp * C4b + 4 * q]);
             dz.x = fmaf(w.x, d.x, dz.x); dz.y = fmaf(w.y, d.y, dz.y); dz.z = fmaf(w.z, d.z, dz.z); dz.w = fmaf(w.w, d.w, dz.w);
             dwacc[tp].x = fmaf(d.x, z.x, dwacc[tp].x); dwacc[tp].y = fmaf(d.y, z.y, dwacc[tp].y);
             dwacc[tp].z = fmaf(d.z, z.z, dwacc[tp].z); dwacc[tp].w = fmaf(d.w, z.w, dwacc[tp].w);
@@ -399,6 +399,8 @@ __global__ void __launch_bounds__(256) dw_wreduce_batch_kernel(const addk_dw_wre
   // elements; the wave-per-element form strides its lanes over the rows, 64 cache lines per load), fixed-order combine in LDS
   __shared__ float part[4][64];
   const addk_dw_wreduce_item it = items[blockIdx.y];
+  const gfloat* ws = (const gfloat*)it.ws;
+  gfloat* dwo = (gfloat*)it.dw;
   const int e = threadIdx.x & 63, rg = threadIdx.x >> 6;
   for (int i0 = blockIdx.x * 64; i0 < it.n; i0 += max_blocks_per_item * 64) {
     const int i = i0 + e;
@@ -406,16 +408,16 @@ __global__ void __launch_bounds__(256) dw_wreduce_batch_kernel(const addk_dw_wre
     if (i < it.n) {
       int r = rg;
       for (; r + 12 < it.rows; r += 16) {
-        s0 += it.ws[(long)r * it.n + i]; s1 += it.ws[(long)(r + 4) * it.n + i];
-        s2 += it.ws[(long)(r + 8) * it.n + i]; s3 += it.ws[(long)(r + 12) * it.n + i];
+        s0 += ws[(long)r * it.n + i]; s1 += ws[(long)(r + 4) * it.n + i];
+        s2 += ws[(long)(r + 8) * it.n + i]; s3 += ws[(long)(r + 12) * it.n + i];
       }
-      for (; r < it.rows; r += 4) s0 += it.ws[(long)r * it.n + i];
+      for (; r < it.rows; r += 4) s0 += ws[(long)r * it.n + i];
     }
     part[rg][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && i < it.n) {
       const float s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-      it.dw[i] = it.accumulate ? it.dw[i] + s : s;
+      dwo[i] = it.accumulate ? dwo[i] + s : s;
     }
     __syncthreads();
   }

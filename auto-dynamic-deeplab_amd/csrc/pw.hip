@@ -65,7 +65,7 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
         if (MODE == PW_FWD) {
           v = ld4(ok ? p.w + (long)n * p.ldw + p.w_off + k : p.w);
         } else {
-          const float* b = ok ? p.w + (long)k * p.ldw + p.w_off + n : p.w;
+          const gfloat* b = (const gfloat*)(ok ? p.w + (long)k * p.ldw + p.w_off + n : p.w);
           const long st = ok ? p.ldw : 0;
           v = make_float4(b[0], b[st], b[2 * st], b[3 * st]);
         }
@@ -238,11 +238,11 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
       }
     __syncthreads();
     if (t < CT * 16 && n0 + t < p.Cn) {
-      double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+      gdouble* o = (gdouble*)p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
       o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
       o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
       for (int r = blockIdx.x + p.gx; r < p.rows; r += p.gx) {     // rows no workgroup owns
-        double* z = p.slab + ((long)r * p.slab_ld + n0 + t) * 2;
+        gdouble* z = (gdouble*)p.slab + ((long)r * p.slab_ld + n0 + t) * 2;
         z[0] = 0.0; z[1] = 0.0;
       }
     }
@@ -260,7 +260,7 @@ __device__ __forceinline__ void sep_block(const PwK& p) {
   __shared__ __attribute__((aligned(16))) float dwl[SEP * SEP * KG * 16];      // depthwise tap weights [tap][channel], zero beyond K
   for (int i = threadIdx.x; i < SEP * SEP * KG * 16; i += 256) {
     const int tp = i / (KG * 16), c = i - tp * (KG * 16);
-    dwl[i] = c < p.K ? p.dww[(long)c * (SEP * SEP) + tp] : 0.f;
+    dwl[i] = c < p.K ? ((const gfloat*)p.dww)[(long)c * (SEP * SEP) + tp] : 0.f;
   }
   __syncthreads();
   pw_body<CT, KG, PW_FWD, RED32, SEP>(p, red, dwl);
@@ -400,11 +400,11 @@ __global__ void __launch_bounds__(256, 3) pwk_kernel(const PwkK p) {
       }
     __syncthreads();
     if (t < CT * 16 && n0 + t < p.Cn) {
-      double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+      gdouble* o = (gdouble*)p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
       o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
       o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
       for (int r = blockIdx.x + p.gx; r < p.rows; r += p.gx) {
-        double* z = p.slab + ((long)r * p.slab_ld + n0 + t) * 2;
+        gdouble* z = (gdouble*)p.slab + ((long)r * p.slab_ld + n0 + t) * 2;
         z[0] = 0.0; z[1] = 0.0;
       }
     }

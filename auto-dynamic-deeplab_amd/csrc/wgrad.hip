@@ -23,6 +23,16 @@ struct WgK {
   float* dw; int ldw, cin_total, w_choff, accumulate;
 };
 
+// Descriptor of this block's convolution, BY VALUE (scalar registers, loaded once): either the kernel argument or the
+// batch table's entry with its pointers declared global (common.h, gptr).
+template <bool BATCH>
+__device__ __forceinline__ WgK wg_desc(const WgK& pv, const WgK* __restrict__ ops, int op) {
+  if (!BATCH) return pv;
+  WgK k = ops[op];
+  k.dy = gptr(k.dy); k.src.x = gptr(k.src.x); k.src.a = gptr(k.src.a); k.src.b = gptr(k.src.b); k.ws = gptr(k.ws); k.dw = gptr(k.dw);
+  return k;
+}
+
 constexpr int KP = 64;
 constexpr int ldpad(int bc) { return (bc % 32 == 16) ? bc : bc + 16; }
 
@@ -35,7 +45,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK pv, const WgK* __r
     const int4 wk = work[blockIdx.x];
     op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
   }
-  const WgK& p = BATCH ? ops[op] : pv;
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
   constexpr int BCY = 16 * CTY, BCZ = 16 * CTZ;
   constexpr int LY = ldpad(BCY), LZ = ldpad(BCZ);
   constexpr int NYJ = (KP * BCY / 4 + 255) / 256;
@@ -108,7 +118,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK pv, const WgK* __r
 #pragma unroll
     for (int j = 0; j < NYJ; ++j) {
       int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
-      if (row < KP) st4(&Ys[row * LY + 4 * q], ry[j]);
+      if (row < KP) lds_st4(&Ys[row * LY + 4 * q], ry[j]);
     }
 #pragma unroll
     for (int j = 0; j < NZJ; ++j) {
@@ -121,7 +131,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK pv, const WgK* __r
         if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
       }
-      if (row < KP) st4(&Zs[row * LZ + 4 * q], v);
+      if (row < KP) lds_st4(&Zs[row * LZ + 4 * q], v);
     }
   };
 
@@ -168,7 +178,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK pv, const WgK* __r
   }
   // workspace layout: [split][co][tap][c] over the real (unpadded) extents
   const int C = p.src.C;
-  float* wsb = p.ws + (long)blk_y * p.Cout * p.taps * C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * p.taps * C;
   for (int idx = t; idx < TILE; idx += 256) {
     int r = idx / BCZ, cc = idx - r * BCZ;
     int co = co0 + r, c = c0 + cc;
@@ -187,7 +197,7 @@ __global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK pv, const WgK* 
     const int4 wk = work[blockIdx.x];
     op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
   }
-  const WgK& p = BATCH ? ops[op] : pv;
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
   constexpr int BCY = 32 * TY, BCZ = 32 * TZ;
   constexpr int LY = ldpad(BCY), LZ = ldpad(BCZ);
   constexpr int NYJ = (KP * BCY / 4 + 255) / 256;
@@ -255,7 +265,7 @@ __global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK pv, const WgK* 
 #pragma unroll
     for (int j = 0; j < NYJ; ++j) {
       int slot = t + 256 * j, row = slot / (BCY / 4), q = slot - row * (BCY / 4);
-      if (row < KP) st4(&Ys[row * LY + 4 * q], ry[j]);
+      if (row < KP) lds_st4(&Ys[row * LY + 4 * q], ry[j]);
     }
 #pragma unroll
     for (int j = 0; j < NZJ; ++j) {
@@ -268,7 +278,7 @@ __global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK pv, const WgK* 
         if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (nrem < 4) { if (nrem < 2) v.y = 0.f; if (nrem < 3) v.z = 0.f; v.w = 0.f; }
       }
-      if (row < KP) st4(&Zs[row * LZ + 4 * q], v);
+      if (row < KP) lds_st4(&Zs[row * LZ + 4 * q], v);
     }
   };
 
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(256) wgrad_os_kernel(const WgK pv, const WgK* 
     }
   }
   const int C = p.src.C;
-  float* wsb = p.ws + (long)blk_y * p.Cout * p.taps * C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * p.taps * C;
 #pragma unroll
   for (int i = 0; i < TY; ++i)
 #pragma unroll
@@ -327,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
     const int4 wk = work[blockIdx.x];
     op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
   }
-  const WgK& p = BATCH ? ops[op] : pv;
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
   constexpr int BCO = 64 * NT, LY = BCO + 16, YQ = BCO / 4, YRS = 256 / YQ;
   constexpr int NYJ = H3_KP / YRS;
   constexpr int NZJ = (3 * H3_ZW * 4 + 255) / 256;
@@ -399,7 +409,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
       float4 v = ry[k];
       const bool ok = (ymask >> k) & 1u;
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      st4(&Ys[(yrow0 + k * YRS) * LY + 4 * yq], v);
+      lds_st4(&Ys[(yrow0 + k * YRS) * LY + 4 * yq], v);
     }
 #pragma unroll
     for (int k = 0; k < NZJ; ++k) {
@@ -408,7 +418,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
       if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       const bool ok = (zmask >> k) & 1u;
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      if (zr[k] < 3) st4(&Zs[(zr[k] * H3_ZW + zj[k]) * 16 + 4 * zq], v);
+      if (zr[k] < 3) lds_st4(&Zs[(zr[k] * H3_ZW + zj[k]) * 16 + 4 * zq], v);
     }
   };
 
@@ -452,7 +462,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
     }
   }
   const int C = p.src.C;
-  float* wsb = p.ws + (long)blk_y * p.Cout * 9 * C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * 9 * C;
   const int c = c0 + li;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
@@ -460,7 +470,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3_kernel(const WgK pv, const Wg
     for (int r = 0; r < 4; ++r) {
       const int cow = co0 + (wave * NT + i) * 16 + kq * 4 + r;
       if (cow < p.Cout && c < C) {
-        float* o = wsb + (long)cow * 9 * C + c;
+        gfloat* o = wsb + (long)cow * 9 * C + c;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) o[tap * C] = acc[i][tap][r];
       }
@@ -483,18 +493,25 @@ typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) wg_s16x4 wg_lds_s16x4;
 __device__ __forceinline__ unsigned wg_bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float wg_bf16_f(unsigned b) { return __uint_as_float(b << 16); }
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> one packed bf16 pair (round to nearest even): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned wg_cvt2(float a, float b) {
+  const wg_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_bf16x2));
+}
 template <int NP>
 __device__ __forceinline__ void wg_split4(const float4 v, uint2 (&pl)[NP]) {
-  float r[4] = {v.x, v.y, v.z, v.w};
-  unsigned b[NP][4];
+  float a = v.x, b = v.y, c = v.z, d = v.w;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float x = r[e];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) { b[k][e] = wg_bf16_hi(x); x = x - wg_bf16_f(b[k][e]); }
+  for (int k = 0; k < NP; ++k) {
+    const unsigned p0 = wg_cvt2(a, b), p1 = wg_cvt2(c, d);
+    pl[k] = make_uint2(p0, p1);
+    if (k + 1 < NP) {
+      a -= __uint_as_float(p0 << 16); b -= __uint_as_float(p0 & 0xffff0000u);
+      c -= __uint_as_float(p1 << 16); d -= __uint_as_float(p1 & 0xffff0000u);
+    }
   }
-#pragma unroll
-  for (int k = 0; k < NP; ++k) pl[k] = make_uint2(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16));
 }
 // byte offset of pixel row p inside a [pixel][16 ch] bf16 tile image
 __device__ __forceinline__ int wg_prow(int p) { return (p << 5) ^ (((p >> 3) & 1) << 7); }
@@ -506,12 +523,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
     const int4 wk = work[blockIdx.x];
     op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
   }
-  const WgK& p = BATCH ? ops[op] : pv;
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
   constexpr int BCO = 64 * NT, YT = BCO / 16, YQ = BCO / 4, YRS = 256 / YQ;
   constexpr int NYJ = H3_KP / YRS;
   constexpr int NZJ = (3 * H3_ZW * 4 + 255) / 256;
   constexpr int ZWP = 104;                                        // patch row pitch in pixels (>= 64 + 2*18, multiple of 8: the swizzle works on 8-pixel blocks)
-  constexpr int YIMG = H3_KP * 32, ZROW = ZWP * 32;               // bytes per dy tile image / per activation patch row (one plane)
+  // bytes per dy tile image / per activation patch row (one plane).  The tile images are 32 bytes apart from a multiple of
+  // the 256-byte bank period: the 8 tiles x 4 channel quads a half-wave stores for one pixel row then cover all 64 banks once
+  constexpr int YIMG = H3_KP * 32 + 32, ZROW = ZWP * 32;
   constexpr int YPL = YT * YIMG, ZPL = 3 * ZROW;                  // bytes per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   unsigned char* Yb = wsm;                                        // [NP][YT][64 px][16 co]
@@ -612,15 +631,12 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
       f[m] = __builtin_bit_cast(wg_bf16x8, pr);
     }
   };
-  auto mma = [&](f32x4& c, const wg_bf16x8* y, const wg_bf16x8* z) {
-    if (NP == 3) {
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[2], z[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[0], z[2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[1], z[1], c, 0, 0, 0);
-    }
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[1], z[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[0], z[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[0], z[0], c, 0, 0, 0);
+  // one tap: the product terms smallest first, the NT accumulator chains interleaved term by term
+  auto mma = [&](f32x4 (&c)[NT][9], int tap, const wg_bf16x8 (&y)[NT][NP], const wg_bf16x8* z) {
+#define WG_TERM(YI, ZI) _Pragma("unroll") for (int i = 0; i < NT; ++i) c[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i][YI], z[ZI], c[i][tap], 0, 0, 0);
+    if (NP == 3) { WG_TERM(2, 0) WG_TERM(0, 2) WG_TERM(1, 1) }
+    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0)
+#undef WG_TERM
   };
 
   if (sbeg < send) {
@@ -641,8 +657,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
         for (int tap = 0; tap < 9; ++tap) {
           if (tap + 1 < 9) rd(Zb + ((tap + 1) / 3) * ZROW, ZPL, ks * 32 + ((tap + 1) % 3) * d, zf[(tap + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < NT; ++i) mma(acc[i][tap], yf[i], zf[tap & 1]);
+          mma(acc, tap, yf, zf[tap & 1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -651,7 +666,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
     }
   }
   const int C = p.src.C;
-  float* wsb = p.ws + (long)blk_y * p.Cout * 9 * C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * 9 * C;
   const int c = c0 + li;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
@@ -659,14 +674,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
     for (int r = 0; r < 4; ++r) {
       const int cow = co0 + (wave * NT + i) * 16 + kq * 4 + r;
       if (cow < p.Cout && c < C) {
-        float* o = wsb + (long)cow * 9 * C + c;
+        gfloat* o = wsb + (long)cow * 9 * C + c;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) o[tap * C] = acc[i][tap][r];
       }
     }
 }
 inline bool wgrad_split_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
-constexpr size_t wg_h3b_lds(int nt, int np) { return (size_t)np * ((64 * nt / 16) * H3_KP * 32 + 3 * 104 * 32); }
+constexpr size_t wg_h3b_lds(int nt, int np) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + 3 * 104 * 32); }
 
 // Halo-patch weight gradient of the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5: 40/80/160 channels,
 // dilation <= 2).  Same staging as wgrad_h3_kernel — per 64-pixel row segment dy [64][16*CT] and the KS activation rows
@@ -683,7 +698,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_hk_kernel(const WgK pv, const Wg
     const int4 wk = work[blockIdx.x];
     op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
   }
-  const WgK& p = BATCH ? ops[op] : pv;
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
   constexpr int TAPS = KS * KS, TPW = (TAPS + 3) / 4, HK = KS / 2;
   constexpr int BCO = 16 * CT, LY = BCO, YQ = BCO / 4;            // 48 and 80 are = 16 mod 32: conflict-free fragment reads
   constexpr int NYJ = (H3_KP * YQ + 255) / 256;
@@ -755,7 +770,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_hk_kernel(const WgK pv, const Wg
       float4 v = ry[k];
       const bool ok = (ymask >> k) & 1u;
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      if (yrow[k] < H3_KP) st4(&Ys[yrow[k] * LY + 4 * yqv[k]], v);
+      if (yrow[k] < H3_KP) lds_st4(&Ys[yrow[k] * LY + 4 * yqv[k]], v);
     }
 #pragma unroll
     for (int k = 0; k < NZJ; ++k) {
@@ -764,7 +779,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_hk_kernel(const WgK pv, const Wg
       if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       const bool ok = (zmask >> k) & 1u;
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      if (zr[k] < KS) st4(&Zs[(zr[k] * HK_ZW + zj[k]) * 16 + 4 * zq], v);
+      if (zr[k] < KS) lds_st4(&Zs[(zr[k] * HK_ZW + zj[k]) * 16 + 4 * zq], v);
     }
   };
 
@@ -807,7 +822,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_hk_kernel(const WgK pv, const Wg
     }
   }
   const int C = p.src.C;
-  float* wsb = p.ws + (long)blk_y * p.Cout * TAPS * C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * TAPS * C;
   const int c = c0 + li;
 #pragma unroll
   for (int i = 0; i < CT; ++i)
@@ -815,7 +830,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_hk_kernel(const WgK pv, const Wg
     for (int r = 0; r < 4; ++r) {
       const int cow = co0 + i * 16 + kq * 4 + r;
       if (cow < p.Cout && c < C) {
-        float* o = wsb + (long)cow * TAPS * C + c;
+        gfloat* o = wsb + (long)cow * TAPS * C + c;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
           const int tap = wave * TPW + j;
@@ -846,8 +861,9 @@ __device__ __forceinline__ RsFrag<LAY> rs_load(const float* base, int li, bool o
     const float4 x = ld4(base + (ok4 ? 4 * li : 0));
     f.v[0] = ok4 ? x.x : 0.f; f.v[1] = ok4 ? x.y : 0.f; f.v[2] = ok4 ? x.z : 0.f; f.v[3 % LAY] = ok4 ? x.w : 0.f;
   } else {
-    const float2 x = *reinterpret_cast<const float2*>(base + (ok2 ? 2 * li : 0));
-    const float y = base[ok1 ? 32 + li : 0];
+    typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+    const rs_f32x2 x = *(const __attribute__((address_space(1))) rs_f32x2*)(base + (ok2 ? 2 * li : 0));
+    const float y = ((const gfloat*)base)[ok1 ? 32 + li : 0];
     f.v[0] = ok2 ? x.x : 0.f; f.v[1] = ok2 ? x.y : 0.f; f.v[2] = ok1 ? y : 0.f;
   }
   return f;
@@ -862,7 +878,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
     const int4 wk = work[blockIdx.x];
     op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
   }
-  const WgK p = BATCH ? ops[op] : pv;          // by value: the descriptor lives in scalar registers
+  const WgK p = wg_desc<BATCH>(pv, ops, op);          // by value: the descriptor lives in scalar registers
   __shared__ float tile[RS_T][RS_T + 1];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
   int bx = blk_x;
@@ -948,7 +964,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
     }
     __syncthreads();
   }
-  float* wsb = p.ws + (long)blk_y * p.Cout * p.taps * C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * p.taps * C;
   for (int idx = t; idx < RS_T * RS_T; idx += 256) {
     const int r = idx / RS_T, cc = idx - r * RS_T;
     if (r < ncy && cc < ncz) wsb[((long)(co0 + r) * p.taps + tap) * C + c0 + cc] = tile[r][cc];
@@ -994,8 +1010,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_wave_kernel(const float* ws,
 __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const WgK* __restrict__ ops, const int4* __restrict__ rwork) {
   __shared__ float part[4][64];
   const int4 wk = rwork[blockIdx.x];
-  const WgK p = ops[wk.x];
+  const WgK p = wg_desc<true>(ops[0], ops, __builtin_amdgcn_readfirstlane(wk.x));
   const int C = p.src.C;
+  const gfloat* ws = (const gfloat*)p.ws;
   const long n = (long)p.Cout * p.taps * C;
   long i; float s;
   bool writer;
@@ -1006,9 +1023,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const WgK* __re
     if (i < n) {
       int k = rg;
       for (; k + 12 < p.splits; k += 16) {
-        s0 += p.ws[(long)k * n + i]; s1 += p.ws[(long)(k + 4) * n + i]; s2 += p.ws[(long)(k + 8) * n + i]; s3 += p.ws[(long)(k + 12) * n + i];
+        s0 += ws[(long)k * n + i]; s1 += ws[(long)(k + 4) * n + i]; s2 += ws[(long)(k + 8) * n + i]; s3 += ws[(long)(k + 12) * n + i];
       }
-      for (; k < p.splits; k += 4) s0 += p.ws[(long)k * n + i];
+      for (; k < p.splits; k += 4) s0 += ws[(long)k * n + i];
     }
     part[rg][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -1020,15 +1037,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const WgK* __re
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
     for (; k + 3 < p.splits; k += 4) {
-      s0 += p.ws[(long)k * n + i]; s1 += p.ws[(long)(k + 1) * n + i]; s2 += p.ws[(long)(k + 2) * n + i]; s3 += p.ws[(long)(k + 3) * n + i];
+      s0 += ws[(long)k * n + i]; s1 += ws[(long)(k + 1) * n + i]; s2 += ws[(long)(k + 2) * n + i]; s3 += ws[(long)(k + 3) * n + i];
     }
-    for (; k < p.splits; ++k) s0 += p.ws[(long)k * n + i];
+    for (; k < p.splits; ++k) s0 += ws[(long)k * n + i];
     s = (s0 + s1) + (s2 + s3);
     writer = true;
   }
   if (writer) {
     int c = (int)(i % C); long r = i / C; int tap = (int)(r % p.taps); int co = (int)(r / p.taps);
-    float* d = p.dw + (long)co * p.ldw + (long)tap * p.cin_total + p.w_choff + c;
+    gfloat* d = (gfloat*)p.dw + (long)co * p.ldw + (long)tap * p.cin_total + p.w_choff + c;
     *d = p.accumulate ? *d + s : s;
   }
 }
