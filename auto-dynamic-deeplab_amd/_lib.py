@@ -44,6 +44,12 @@ class SepArgs(C.Structure):
                 ('term', Src * MAX_TERMS)]
 
 
+class CeUpsampleArgs(C.Structure):
+    _fields_ = [('logits', vp), ('ld', i32), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('OH', i32), ('OW', i32),
+                ('target', vp), ('class_w', vp), ('ignore_index', i32), ('wsum', vp), ('scale', f32), ('loss_out', vp),
+                ('g', vp), ('ldg', i32), ('accumulate', i32), ('ws', vp)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32), ('KH', i32), ('KW', i32),
                 ('stride', i32), ('pad', i32), ('dil', i32), ('w', vp), ('y', vp), ('ldy', i32)]
@@ -182,6 +188,9 @@ _SIGS = {
     'addk_ce_count': (i32, [vp, i64, vp, i32, i32, vp, vp, vp]),
     'addk_ce_fwd_bwd': (i32, [vp, vp, i32, i32, i64, vp, i32, vp, f32, vp, vp, vp, vp]),
     'addk_ce_ws_floats': (i64, [i32, i64]),
+    'addk_ce_upsample_supported': (i32, [i32, i32, i32, i32, i32, i32]),
+    'addk_ce_upsample_ws_floats': (i64, [i32, i32, i32]),
+    'addk_ce_upsample_fwd_bwd': (i32, [C.POINTER(CeUpsampleArgs), vp]),
     'addk_sgd_step': (i32, [vp, vp, vp, i64, vp, f32, f32, i32, i32, f32, vp]),
     'addk_fill': (i32, [vp, i64, f32, vp]),
     'addk_entropy_sum': (i32, [vp, i32, i32, i64, vp, vp, vp]),

@@ -726,7 +726,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   bool done = false;
 #define ADDK_C3B_(W_, K_, M_, P_, D_) { \
     static bool attr = false; \
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
     hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, D_>), grid, dim3(64 * W_), lds, st, k); done = true; }
 #define ADDK_C3B(W_, K_, D_) \
   if (!done && wc == W_ && ks == K_ && bigd == D_) { \

@@ -123,6 +123,167 @@ __global__ void confusion_kernel(const int64_t* gt, const int64_t* pred, long n,
   }
 }
 
+
+// ---- fused logits up-sampling + cross-entropy, forward and backward (decoder.py:28 + train.py:70,231) -------------------
+// The training step never needs the full-resolution logits: loss and gradient are computed straight from the low-resolution
+// NHWC logits.  F.interpolate(mode='bilinear', align_corners=False) index arithmetic as in resize.hip (ATen's
+// area_pixel_compute_source_index in fp32).  A high-resolution pixel (Y, X) reads the low-resolution rows h0(Y), h0+1 and
+// columns w0(X), w0+1; it is OWNED by (h0, w0): thread (r, xl) of a block walks the pixels of row Y = first_row(h) + r whose
+// w0 is its column, computes each pixel's softmax ONCE and accumulates the pixel's gradient into A0 (column w0) and A1
+// (column w0 + 1).  A1 moves to the right neighbour lane, the 16 rows of the band are reduced through LDS in a fixed order
+// with the row weights, and the part that belongs to row h + 1 is carried in registers to the next band: a gather with no
+// atomics and no second pass over the 1.3 GB/exit of full-resolution logits and gradients the three-kernel form wrote and re-read.
+// A block owns 15 output columns x HB output rows; it re-walks one band above (for the carry) and one column to the left
+// (for A1): (HB+1)/HB * 16/15 redundant softmax work, counted once in the loss (own bands, xl >= 1).
+struct CeUpK {
+  const float* x; int ld; int N, H, W, OH, OW;
+  const int64_t* target; const float* cw; int ignore;
+  const float* wsum; float scale;
+  float* g; int ldg; int accumulate;
+  float* ws; int HB;
+};
+
+__device__ __forceinline__ void ce_src_index(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+__host__ __device__ __forceinline__ int ce_idx0(int dst, float scale, int in) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  int i0 = (int)s;
+  return i0 > in - 1 ? in - 1 : i0;
+}
+// smallest output index whose i0 is >= i (i0 is monotone in the output index)
+__host__ __device__ __forceinline__ int ce_first_out(int i, float scale, int in, int out) {
+  if (i <= 0) return 0;
+  int g = (int)(((float)i + 0.5f) / scale - 0.5f);
+  if (g < 0) g = 0;
+  if (g > out) g = out;
+  while (g > 0 && ce_idx0(g - 1, scale, in) >= i) --g;
+  while (g < out && ce_idx0(g, scale, in) < i) ++g;
+  return g;
+}
+
+constexpr int CEU_R = 16, CEU_X = 16;      // rows of a band / lanes per row (15 output columns + the left neighbour)
+
+template <int CC>
+__global__ void __launch_bounds__(256) ce_up_kernel(const CeUpK p) {
+  __shared__ float S0[CEU_R * CEU_X * CC], S1[CEU_R * CEU_X * CC];
+  __shared__ float shs[4];
+  const int t = threadIdx.x, xl = t & (CEU_X - 1), r = t >> 4;
+  const int tx0 = blockIdx.x * (CEU_X - 1), hb = blockIdx.y * p.HB, n = blockIdx.z;
+  const int x = tx0 - 1 + xl;                                   // the low-resolution column this thread owns as w0
+  const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
+  const float inv = p.scale / *(const gfloat*)p.wsum;
+  int xlo = 0, xhi = 0;
+  if (x >= 0 && x < p.W) { xlo = ce_first_out(x, sw, p.W, p.OW); xhi = (x + 1 < p.W) ? ce_first_out(x + 1, sw, p.W, p.OW) : p.OW; }
+  const bool xlast = x == p.W - 1;
+  const int x1 = x + (x < p.W - 1 ? 1 : 0);
+  const gfloat* lg = (const gfloat*)p.x;
+  const int64_t __attribute__((address_space(1)))* tgt = (const int64_t __attribute__((address_space(1)))*)p.target;
+  const gfloat* cw = (const gfloat*)p.cw;
+  float lsum = 0.f;
+  float carry[2] = {0.f, 0.f};
+  const int hstart = hb > 0 ? hb - 1 : 0;
+  const int hend = hb + p.HB < p.H ? hb + p.HB : p.H;
+  for (int h = hstart; h < hend; ++h) {
+    const int ylo = ce_first_out(h, sh, p.H, p.OH);
+    const int yhi = (h + 1 < p.H) ? ce_first_out(h + 1, sh, p.H, p.OH) : p.OH;      // host: yhi - ylo <= CEU_R
+    const int Y = ylo + r;
+    const bool own = h >= hb;
+    float A0[CC], A1[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) { A0[c] = 0.f; A1[c] = 0.f; }
+    float lh0 = 0.f, lh1 = 0.f;
+    if (Y < yhi && xhi > xlo) {
+      int h0, h1;
+      ce_src_index(Y, sh, p.H, h0, h1, lh0, lh1);
+      const gfloat* b0 = lg + ((long)(n * p.H + h0) * p.W) * p.ld;
+      const gfloat* b1 = lg + ((long)(n * p.H + h1) * p.W) * p.ld;
+      float v00[CC], v01[CC], v10[CC], v11[CC];
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        v00[c] = b0[(long)x * p.ld + c]; v01[c] = b0[(long)x1 * p.ld + c];
+        v10[c] = b1[(long)x * p.ld + c]; v11[c] = b1[(long)x1 * p.ld + c];
+      }
+      const int64_t __attribute__((address_space(1)))* tp = tgt + ((long)n * p.OH + Y) * p.OW;
+      for (int X = xlo; X < xhi; ++X) {
+        int w0, w1; float lw0, lw1;
+        ce_src_index(X, sw, p.W, w0, w1, lw0, lw1);
+        const long tg = tp[X];
+        const bool valid = tg != p.ignore && tg >= 0 && tg < CC;
+        const float w = valid ? (cw ? cw[tg] : 1.f) : 0.f;
+        float z[CC];
+        float mx = -INFINITY, zt = 0.f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+          z[c] = lh0 * (lw0 * v00[c] + lw1 * v01[c]) + lh1 * (lw0 * v10[c] + lw1 * v11[c]);
+          mx = fmaxf(mx, z[c]);
+          if (c == tg) zt = z[c];
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) { z[c] = expf(z[c] - mx); se += z[c]; }
+        if (own && xl >= 1 && valid) lsum += w * (logf(se) + mx - zt);
+        const float k = w * inv / se, kt = w * inv;
+        const float a0 = lw0 + (xlast ? lw1 : 0.f), a1 = xlast ? 0.f : lw1;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+          const float gz = z[c] * k - ((valid && c == tg) ? kt : 0.f);
+          A0[c] = fmaf(a0, gz, A0[c]); A1[c] = fmaf(a1, gz, A1[c]);
+        }
+      }
+    }
+    // column w0 + 1 belongs to the right neighbour lane; then the rows of the band go through LDS
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      float fromleft = __shfl_up(A1[c], 1, CEU_X);
+      if (xl == 0) fromleft = 0.f;
+      const float R = A0[c] + fromleft;
+      S0[(r * CEU_X + xl) * CC + c] = lh0 * R;
+      S1[(r * CEU_X + xl) * CC + c] = lh1 * R;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = t + 256 * k;
+      if (j < (CEU_X - 1) * CC) {
+        const int ox = 1 + j / CC, c = j - (ox - 1) * CC;
+        float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < CEU_R; ++rr) { b0 += S0[(rr * CEU_X + ox) * CC + c]; b1 += S1[(rr * CEU_X + ox) * CC + c]; }
+        if (h == p.H - 1) { b0 += b1; b1 = 0.f; }
+        const float o = carry[k] + b0;
+        carry[k] = b1;
+        const int col = tx0 - 1 + ox;
+        if (own && col < p.W) {
+          gfloat* gp = (gfloat*)p.g + ((long)(n * p.H + h) * p.W + col) * p.ldg + c;
+          *gp = p.accumulate ? *gp + o : o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  lsum = block_sum(lsum, shs);
+  if (t == 0) ((gfloat*)p.ws)[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = lsum;
+}
+
+int ceu_hb(int H) { return H >= 64 ? 4 : (H >= 16 ? 2 : 1); }
+bool ceu_ok(int N, int H, int W, int OH, int OW, int C) {
+  if (C != 19 || N <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return false;
+  const float sh = (float)H / (float)OH;
+  for (int h = 0; h < H; ++h) {
+    const int lo = ce_first_out(h, sh, H, OH), hi = h + 1 < H ? ce_first_out(h + 1, sh, H, OH) : OH;
+    if (hi - lo > CEU_R) return false;
+  }
+  return true;
+}
+
 int ce_blocks(long total) { long b = cdiv(total, 256 * 4); if (b < 1) b = 1; if (b > 1024) b = 1024; return (int)b; }
 
 }  // namespace
@@ -155,6 +316,30 @@ extern "C" int addk_ce_fwd_bwd(const float* logits, const int64_t* target, int32
   if (rc) return rc;
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, b, scale, wsum, loss_out, 1);
   return addk_check_launch("ce_sum");
+}
+
+
+extern "C" int addk_ce_upsample_supported(int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t C) {
+  return ceu_ok(N, H, W, OH, OW, C) ? 1 : 0;
+}
+extern "C" int64_t addk_ce_upsample_ws_floats(int32_t N, int32_t H, int32_t W) {
+  return (int64_t)N * cdiv(H, ceu_hb(H)) * cdiv(W, CEU_X - 1);
+}
+extern "C" int addk_ce_upsample_fwd_bwd(const addk_ce_upsample_args* a, void* stream) {
+  ADDK_REQUIRE(a && a->logits && a->target && a->wsum && a->loss_out && a->g && a->ws, "ce_upsample: null pointer");
+  ADDK_REQUIRE(a->ld >= a->C && a->ldg >= a->C, "ce_upsample: short stride");
+  ADDK_REQUIRE(ceu_ok(a->N, a->H, a->W, a->OH, a->OW, a->C), "ce_upsample: unsupported shape (19 classes, at most %d output rows per input row)", CEU_R);
+  CeUpK k;
+  k.x = a->logits; k.ld = a->ld; k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
+  k.target = a->target; k.cw = a->class_w; k.ignore = a->ignore_index; k.wsum = a->wsum; k.scale = a->scale;
+  k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate; k.ws = a->ws; k.HB = ceu_hb(a->H);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(cdiv(a->W, CEU_X - 1), cdiv(a->H, k.HB), a->N);
+  hipLaunchKernelGGL(ce_up_kernel<19>, grid, dim3(256), 0, st, k);
+  int rc = addk_check_launch("ce_upsample");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, a->ws, (int)(grid.x * grid.y * grid.z), a->scale, a->wsum, a->loss_out, 1);
+  return addk_check_launch("ce_upsample_sum");
 }
 
 extern "C" int addk_entropy_sum(const float* logits, int32_t N, int32_t C, int64_t HW, float* out1, float* ws, void* stream) {

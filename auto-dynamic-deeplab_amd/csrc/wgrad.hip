@@ -1257,7 +1257,7 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
   const int wg_np = addk_get_conv_precision() == 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;
 #define ADDK_H3B_(B_, P_) { \
     static bool attr = false; \
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<2, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<2, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
     hipLaunchKernelGGL((wgrad_h3b_kernel<2, B_, P_>), grid, dim3(256), wg_h3b_lds(2, P_), st, k, ops, work); done = true; }
   if (kind == 5 && cty == 8 && wg_np && wgrad_split_enabled()) {
     if (ops) { if (wg_np == 3) ADDK_H3B_(true, 3) else ADDK_H3B_(true, 2) }

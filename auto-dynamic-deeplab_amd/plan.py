@@ -1101,10 +1101,36 @@ class Graph:
         return res
 
     def resize_to_nchw(self, src, OH, OW):
-        """Final logits resize (decoder.py:28) into a contiguous [N,C,OH,OW] tensor.  Returns (tensor, dy_setter)."""
+        """Final logits resize (decoder.py:28) into a contiguous [N,C,OH,OW] tensor.  Returns an OutRef.
+        In a fused training step (`self.fuse_ce`, set by train.TrainStep) nobody reads the full-resolution logits: the
+        resize is not emitted at all and the OutRef carries what the fused up-sampling + cross-entropy launch needs
+        (`addk_ce_upsample_fwd_bwd`, placed at the head of the backward list with the loss parameters TrainStep binds)."""
         lib = self.lib
         assert src.bn is None and not src.relu
         N, H, W, Cc = src.N, src.H, src.W, src.C
+        if (getattr(self, 'fuse_ce', False) and self.want_grad and src.needs_grad
+                and lib.addk_ce_upsample_supported(N, H, W, OH, OW, Cc) == 1):
+            out = OutRef(None)
+            out.fused_ce, out.shape, out.ce = True, (N, Cc, OH, OW), None
+
+            def emit_ce():
+                assert out.ce is not None, 'fused logits output without a loss binding'
+                a = L.CeUpsampleArgs()
+                s = self.src(src)
+                a.logits, a.ld = s.x, s.ld
+                a.N, a.H, a.W, a.C, a.OH, a.OW = N, H, W, Cc, OH, OW
+                ce = out.ce
+                a.target, a.class_w, a.ignore_index = ce['target'].data_ptr(), ce['class_w'], ce['ignore_index']
+                a.wsum, a.scale, a.loss_out = ce['wsum'].data_ptr(), ce['scale'], ce['loss'].data_ptr()
+                gs = self.grad(src.raw)
+                a.g, a.ldg, a.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
+                ws = torch.zeros(int(lib.addk_ce_upsample_ws_floats(N, H, W)), dtype=torch.float32, device=self.device)
+                a.ws = ws.data_ptr()
+                self.keep += [a, ws]
+                self._add(self.bwd, 'ce_upsample', lib.addk_ce_upsample_fwd_bwd, C.byref(a),
+                          rd=self.lz(src) + [ce['target'], ce['wsum']], wr=[gs, ce['loss'], ws])
+            self._bwd_emitters.append(emit_ce)
+            return out
         y = torch.empty((N, Cc, OH, OW), dtype=torch.float32, device=self.device)
         self.nbytes += y.numel() * 4
         ar = L.ResizeArgs()
@@ -1265,6 +1291,7 @@ class OutRef:
         self.y = y
         self.dy_ptr, self.dy_scale, self.dynamic = None, None, True
         self.bwd_args = None     # ResizeBwdArgs (logits path)
+        self.fused_ce = False    # logits consumed by the fused up-sampling + cross-entropy launch (train.TrainStep): y is None
         self.bwd_cmd = None      # generic nhwc path
 
     def set_grad(self, gy):

@@ -59,12 +59,14 @@ class TrainStep:
         self.comm = sync_comm
         g = self.g = Graph(dev, True, True, sync_comm)
         g.pgrad_views = gviews
+        # the step never hands out full-resolution logits: up-sampling + loss + their backward run as one launch per exit
+        g.fuse_ce = os.environ.get('ADDK_FUSE_CE', '1') == '1'
         a, self.inref = g.input_nchw(self.x)
         self.inref.bind(self.x)
         outs = model.emit(g, a)
         self.outs = outs
         nex = len(outs)
-        ncls = outs[0].y.shape[1]
+        ncls = outs[0].shape[1] if outs[0].fused_ce else outs[0].y.shape[1]
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.wsum = torch.zeros(1, dtype=torch.float32, device=dev)
         ws = torch.zeros(int(lib.addk_ce_ws_floats(N, H * W)), dtype=torch.float32, device=dev)
@@ -76,6 +78,10 @@ class TrainStep:
                self.wsum.data_ptr(), ws.data_ptr(), rd=[self.target], wr=[self.wsum, ws])
         self.dlogits = []
         for o in outs:
+            if o.fused_ce:
+                o.ce = dict(target=self.target, class_w=cwp, ignore_index=ignore_index, wsum=self.wsum, scale=1.0 / nex, loss=self.loss)
+                self.dlogits.append(None)
+                continue
             d = torch.empty_like(o.y)
             self.dlogits.append(d)
             g._add(g.fwd, 'ce_fwd_bwd', lib.addk_ce_fwd_bwd, o.y.data_ptr(), self.target.data_ptr(), N, ncls, H * W, cwp,

@@ -396,6 +396,28 @@ int addk_ce_fwd_bwd(const float* logits, const int64_t* target, int32_t N, int32
                     float* loss_out, float* dlogits, float* ws, void* stream);
 int64_t addk_ce_ws_floats(int32_t N, int64_t HW);
 
+/* Fused form for the training step: the bilinear up-sampling of the decoder's logits (decoder.py:28,
+ * F.interpolate(mode='bilinear', align_corners=False)) and the cross-entropy on it (train.py:70,231) in one pass over the
+ * LOW-resolution NHWC logits [N,H,W,C] — loss_out[0] += scale * CE(upsample(logits) -> [N,C,OH,OW], target), and
+ * g (+)= d loss / d logits.  The [N,C,OH,OW] tensor and its gradient are never materialised.  Deterministic (gather, fixed
+ * summation order).  addk_ce_upsample_supported() is 0 for shapes the kernel does not take (C != 19, more than 16 output
+ * rows per input row): the caller then runs addk_resize_fwd + addk_ce_fwd_bwd + addk_resize_bwd. */
+typedef struct {
+  const float* logits; int32_t ld;   /* NHWC, pixel stride ld >= C */
+  int32_t N, H, W, C, OH, OW;
+  const int64_t* target;             /* [N,OH,OW] */
+  const float* class_w;              /* [C] or NULL */
+  int32_t ignore_index;
+  const float* wsum;                 /* device scalar from addk_ce_count */
+  float scale;
+  float* loss_out;                   /* device scalar, accumulated */
+  float* g; int32_t ldg; int32_t accumulate;
+  float* ws;                         /* addk_ce_upsample_ws_floats() floats */
+} addk_ce_upsample_args;
+int addk_ce_upsample_supported(int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t C);
+int64_t addk_ce_upsample_ws_floats(int32_t N, int32_t H, int32_t W);
+int addk_ce_upsample_fwd_bwd(const addk_ce_upsample_args* a, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Fused SGD (torch.optim.SGD(momentum, weight_decay, nesterov), train.py:126) on a flat buffer.
  *   d = g*gscale + wd*p;  buf = first ? d : mom*buf + d;  p -= lr*(nesterov ? d + mom*buf : buf)

@@ -341,13 +341,15 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
         (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
         p64 = dict(m64.named_parameters())
     n = 0
-    ours, theirs = [], []
+    ours, theirs, groups = [], [], {}
     for k, p in mo.named_parameters():
         if p.dim() == 4 and p.grad is not None:
             assert pa[k].grad is not None, k
             if big:
                 ours.append(_chk('frozen_bn%d/g:%s' % (hw[0], k), pa[k].grad.cpu().double(), p64[k].grad, 1e-2))
                 theirs.append(rel_err(p.grad.double(), p64[k].grad))
+                grp = '.'.join(k.split('.')[:2]) if k.startswith('cells.') else k.split('.')[0]
+                groups.setdefault(grp, []).append((ours[-1], theirs[-1]))
             else:
                 _chk('frozen_bn%d/g:%s' % (hw[0], k), pa[k].grad, p.grad, 2e-3)
             n += 1
@@ -355,6 +357,9 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
     if big:
         med = lambda v: sorted(v)[len(v) // 2]
         REPORT.append('frozen_bn512 vs fp64: addk max %.2e median %.2e | fp32 oracle max %.2e median %.2e' % (max(ours), med(ours), max(theirs), med(theirs)))
+        for grp, v in groups.items():      # per module: median error of its conv-weight gradients, addk and the fp32 oracle, both vs fp64
+            REPORT.append('frozen_bn512 per-layer %-22s n=%3d  addk %.2e  fp32 oracle %.2e  ratio %.2f' % (
+                grp, len(v), med([a for a, _ in v]), med([b for _, b in v]), med([a for a, _ in v]) / max(med([b for _, b in v]), 1e-30)))
         assert max(ours) <= 3 * max(theirs) and med(ours) <= 3 * med(theirs)
 
 

@@ -54,6 +54,59 @@ def test_criterion_matches_torch(dev):
     la.backward(); lo.backward()
     assert abs(la.item() - lo.item()) < 1e-5 and rel_err(xa.grad, xo.grad) < 1e-5
 
+@pytest.mark.parametrize('lo_hw,hi_hw', [((16, 32), (128, 256)), ((17, 33), (65, 129)), ((9, 17), (65, 129)), ((33, 65), (33, 65)),
+                                         ((129, 257), (1025, 2049))], ids=['x8', 'x3.8', 'x7.6', 'x1', 'config4_odd'])
+def test_fused_upsample_cross_entropy_matches_fp64_reference(dev, lo_hw, hi_hw):
+    """addk_ce_upsample_fwd_bwd (the training step's loss head) against F.interpolate(bilinear, align_corners=False) +
+    nn.CrossEntropyLoss(weight, ignore_index) + autograd in fp64: loss and d loss / d low-resolution logits, with class
+    weights, ignored pixels, a padded pixel stride, accumulation into an existing gradient, and run-to-run bit equality."""
+    import ctypes as C
+    import torch.nn.functional as Fn
+    import addk._lib as L
+    lib = L.load()
+    N, (H, W), (OH, OW), ld = 2, lo_hw, hi_hw, 24
+    assert lib.addk_ce_upsample_supported(N, H, W, OH, OW, 19) == 1
+    x = rand_tensor(31, 'ceu_x', (N, H, W, 19)) * 3
+    _, t = _batch(N, hi_hw, seed=9)
+    w = torch.rand(19, generator=torch.Generator().manual_seed(4)) + 0.5
+    g0 = rand_tensor(32, 'ceu_g0', (N, H, W, ld))
+    for weight, acc in ((None, 0), (w, 1)):
+        x64 = x.double().requires_grad_(True)
+        up = Fn.interpolate(x64.permute(0, 3, 1, 2), size=hi_hw, mode='bilinear', align_corners=False)
+        lo = nn.CrossEntropyLoss(weight=None if weight is None else weight.double(), ignore_index=255)(up, t) * 0.5
+        lo.backward()
+        # ATen evaluates the source coordinates in the tensor's dtype: at non-integer scales the fp32 interpolation weights
+        # differ from the fp64 ones by ~1e-5 (coordinate ~1e2 x 2^-24), so the fp32 reference is the tighter anchor there
+        x32 = x.clone().requires_grad_(True)
+        up32 = Fn.interpolate(x32.permute(0, 3, 1, 2), size=hi_hw, mode='bilinear', align_corners=False)
+        (nn.CrossEntropyLoss(weight=weight, ignore_index=255)(up32, t) * 0.5).backward()
+        xa = torch.zeros((N, H, W, ld), device=dev); xa[..., :19] = x.to(dev)
+        ta = t.to(dev); wa = weight.to(dev) if weight is not None else None
+        wsum = torch.zeros(1, device=dev); ws1 = torch.zeros(int(lib.addk_ce_ws_floats(N, OH * OW)), device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(lib.addk_ce_count(ta.data_ptr(), N * OH * OW, wa.data_ptr() if wa is not None else None, 255, 19, wsum.data_ptr(), ws1.data_ptr(), st))
+        res = []
+        for rep in range(2):
+            loss = torch.full((1,), 0.25, device=dev)
+            g = g0.clone().to(dev)
+            ws = torch.zeros(int(lib.addk_ce_upsample_ws_floats(N, H, W)), device=dev)
+            a = L.CeUpsampleArgs()
+            a.logits, a.ld, a.N, a.H, a.W, a.C, a.OH, a.OW = xa.data_ptr(), ld, N, H, W, 19, OH, OW
+            a.target, a.class_w, a.ignore_index = ta.data_ptr(), wa.data_ptr() if wa is not None else None, 255
+            a.wsum, a.scale, a.loss_out = wsum.data_ptr(), 0.5, loss.data_ptr()
+            a.g, a.ldg, a.accumulate, a.ws = g.data_ptr(), ld, acc, ws.data_ptr()
+            L.check(lib.addk_ce_upsample_fwd_bwd(C.byref(a), st))
+            torch.cuda.synchronize()
+            res.append((loss.cpu(), g.cpu()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])        # deterministic
+        la, ga = res[0]
+        assert abs(float(la) - 0.25 - float(lo)) <= 2e-6 * abs(float(lo)), (float(la) - 0.25, float(lo))
+        base = g0[..., :19].double() if acc else 0
+        assert rel_err(ga[..., :19].double(), x64.grad + base) <= 5e-5
+        assert rel_err(ga[..., :19].double(), x32.grad.double() + base) <= 1e-5
+        assert torch.equal(ga[..., 19:], g0[..., 19:])                                            # padding channels untouched
+    assert lib.addk_ce_upsample_supported(N, H, W, OH, OW, 7) == 0 and lib.addk_ce_upsample_supported(1, 4, 4, 128, 128, 19) == 0
+
 
 def test_train_step_forward_backward_and_sgd(dev):
     from addk.train import TrainStep
@@ -94,6 +147,26 @@ def test_train_step_forward_backward_and_sgd(dev):
     assert rel_err(ts.flat_g, g0) < 1e-6
     assert rel_err(ts.flat_p, expect) < 1e-6
     assert rel_err(ts.mom_buf, buf) < 1e-6
+
+
+def test_train_step_fused_loss_head_equals_three_kernel_form(dev, monkeypatch):
+    """ADDK_FUSE_CE=0 keeps resize -> cross-entropy -> resize backward as three launches over full-resolution tensors; the
+    default fused head must give the same loss and gradients (same arithmetic, different summation order)."""
+    from addk.train import TrainStep
+    x, t = _batch(2, (65, 129))
+    out = {}
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('ADDK_FUSE_CE', fuse)
+        ma, _ = _models(dev)
+        ts = TrainStep(ma, (2, 3, 65, 129), use_graph=False)
+        names = [c.name for c in ts.g.bwd]
+        assert ('ce_upsample' in names) == (fuse == '1') and ('resize_nchw_bwd' in names) == (fuse == '0')
+        ts.load_batch(x.to(dev), t.to(dev))
+        ts.forward_backward_only()
+        torch.cuda.synchronize()
+        out[fuse] = (ts.loss.item(), ts.flat_g.clone())
+    assert abs(out['0'][0] - out['1'][0]) <= 2e-6 * abs(out['0'][0])
+    assert rel_err(out['1'][1], out['0'][1]) <= 2e-4
 
 
 def test_train_step_hipgraph_equals_eager(dev):
