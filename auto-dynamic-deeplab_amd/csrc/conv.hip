@@ -46,6 +46,10 @@ struct ConvK {
   // and only the taps of `taplist` can reach them (kill: the class has no tap at all -> zero gradient)
   int sub, ph, pw, MH, MW, ntaps_l, kill;
   int taplist[9];
+  // ... or ALL classes in ONE launch (ncls > 0): workgroups [gx0, next gx0) of the x grid belong to class c and use cl[c]
+  // in place of the single-class fields above (P, ntiles, slab included)
+  int ncls;
+  struct Cls { long P; double* slab; int ph, pw, MH, MW, ntaps_l, kill, ntiles, gx0; int taplist[9]; int pad_; } cl[4];
 };
 
 constexpr int BK = 32;
@@ -90,10 +94,23 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   const int n0 = blockIdx.y * BC;
   const int aq = t & 7, ar = t >> 3;
   const bool cls = MODE == MODE_DGRAD && p.sub > 1;
-  const int ntaps = cls ? p.ntaps_l : p.KH * p.KW;
-  const int ohw = cls ? p.MH * p.MW : p.OH * p.OW;
-  const int mw = cls ? p.MW : p.OW;
-  const int P32 = (int)p.P;
+  // this workgroup's parity class (wave-uniform): single-class launch -> the fields of p; combined launch -> cl[c]
+  int bx = blockIdx.x, gx = gridDim.x;
+  int c_ph = p.ph, c_pw = p.pw, c_MH = p.MH, c_MW = p.MW, c_ntaps = p.ntaps_l, c_kill = p.kill, c_ntiles = p.ntiles, c_idx = 0;
+  long c_P = p.P;
+  double* c_slab = p.slab;
+  if (MODE == MODE_DGRAD && p.ncls > 0) {
+    int c = 0;
+    while (c + 1 < p.ncls && bx >= p.cl[c + 1].gx0) ++c;
+    gx = (c + 1 < p.ncls ? p.cl[c + 1].gx0 : (int)gridDim.x) - p.cl[c].gx0;
+    bx -= p.cl[c].gx0;
+    c_ph = p.cl[c].ph; c_pw = p.cl[c].pw; c_MH = p.cl[c].MH; c_MW = p.cl[c].MW; c_ntaps = p.cl[c].ntaps_l; c_kill = p.cl[c].kill;
+    c_ntiles = p.cl[c].ntiles; c_P = p.cl[c].P; c_slab = p.cl[c].slab; c_idx = c;
+  }
+  const int ntaps = cls ? c_ntaps : p.KH * p.KW;
+  const int ohw = cls ? c_MH * c_MW : p.OH * p.OW;
+  const int mw = cls ? c_MW : p.OW;
+  const int P32 = (int)c_P;
   double tot0 = 0.0, tot1 = 0.0;
   // per-slot weight offsets (fixed for the whole kernel); -1 marks a slot outside the tile
   long woff[NBJ];
@@ -112,9 +129,9 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so workgroup b
   // takes tile (b % 8) * (ntiles / 8) + b / 8: every XCD walks a contiguous range of pixel tiles and the rows a k x k
   // tap re-reads (one image row above / below = a few tiles away) are served from that XCD's L2.  Speed only.
-  const int tpx = p.ntiles >> 3;
-  const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
-  for (int tlin = blockIdx.x; tlin < p.ntiles; tlin += gridDim.x) {
+  const int tpx = c_ntiles >> 3;
+  const bool swz = (c_ntiles & 7) == 0 && c_ntiles >= 64;
+  for (int tlin = bx; tlin < c_ntiles; tlin += gx) {
     const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
     int rn[NAJ], rh[NAJ], rw[NAJ];
     long roff[NAJ];              // element offset of (n, rh, rw) in a source with pixel stride 1 (scaled by S.ld per chunk)
@@ -125,7 +142,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
         int n = pp / ohw;
         int rem = pp - n * ohw;
         int oh = rem / mw, ow = rem - oh * mw;
-        if (cls) { oh = oh * p.sub + p.ph; ow = ow * p.sub + p.pw; }
+        if (cls) { oh = oh * p.sub + c_ph; ow = ow * p.sub + c_pw; }
         rn[j] = n;
         if (MODE == MODE_FWD) { rh[j] = oh * p.stride - p.pad; rw[j] = ow * p.stride - p.pad; }
         else                  { rh[j] = oh + p.pad;            rw[j] = ow + p.pad; }
@@ -145,7 +162,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
 
     auto load_chunk = [&](int s_, int tapi_, int c0_, int choff_) {
       const addk_src S = p.src[s_];
-      const int tap_ = cls ? p.taplist[tapi_] : tapi_;
+      const int tap_ = cls ? (p.ncls > 0 ? p.cl[c_idx].taplist[tapi_] : p.taplist[tapi_]) : tapi_;
       const int kh = tap_ / p.KW, kw = tap_ - kh * p.KW;
       const int c = c0_ + 4 * aq;
       const int nrem = S.C - c;          // valid channels from c on
@@ -169,7 +186,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
             poff = roff[j] + tapoff;
           } else {
             const int th = rh[j] - dh, tw = rw[j] - dw;
-            ok = th >= 0 && tw >= 0 && (th % p.stride == 0) && (tw % p.stride == 0) && !(cls && p.kill);
+            ok = th >= 0 && tw >= 0 && (th % p.stride == 0) && (tw % p.stride == 0) && !(cls && c_kill);
             const int ih = th / p.stride, iw = tw / p.stride;
             ok = ok && ih < p.H && iw < p.W;
             poff = ((long)rn[j] * p.H + ih) * p.W + iw;
@@ -337,7 +354,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
     }
 
     // ---- epilogue ----
-    const bool want_red = p.slab != nullptr;
+    const bool want_red = c_slab != nullptr;
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
       const int c = n0 + i * 16 + kq * 4;
@@ -349,7 +366,7 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
         const bool pv = pp < P32 && nrem > 0;
         if (cls && pv) {      // class-local pixel -> position in the full gradient map
           const int n = pp / ohw, rem = pp - n * ohw, i2 = rem / mw, j2 = rem - i2 * mw;
-          pp = (n * p.OH + i2 * p.sub + p.ph) * p.OW + j2 * p.sub + p.pw;
+          pp = (n * p.OH + i2 * p.sub + c_ph) * p.OW + j2 * p.sub + c_pw;
         }
         float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         if (MODE == MODE_FWD) {
@@ -417,8 +434,8 @@ __global__ void __launch_bounds__(256) conv_kernel(const ConvK p) {
       __syncthreads();
     }
   }
-  if (p.slab && t < BC && n0 + t < p.Cn) {
-    double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+  if (c_slab && t < BC && n0 + t < p.Cn) {
+    double* o = c_slab + ((long)bx * p.slab_ld + n0 + t) * 2;
     o[0] = tot0; o[1] = tot1;
   }
 }
@@ -479,6 +496,7 @@ int launch(ConvK& k, hipStream_t st, int grid_x = 0) {
   const int pt = pick_pt(k.P);
   const int BP = 64 * pt;
   k.ntiles = cdiv(k.P, BP);
+  for (int c = 0; c < k.ncls; ++c) k.cl[c].ntiles = cdiv(k.cl[c].P, BP);      // combined parity classes: k.P is the largest class
   k.red32 = k.P >= 4096;
   const int ct = pick_ct(k.Cn, k.ntiles);
   dim3 grid(grid_x > 0 ? grid_x : addk_conv_rows(k.P, k.Cn), cdiv(k.Cn, 16 * ct));   // workgroups beyond ntiles only write their (zero) slab row
@@ -558,7 +576,7 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
   k.Cn = a->Cout; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.ldy = a->ldy;
   k.w = a->w; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n; k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
   k.accumulate = 0; k.dst = addk_src{nullptr, nullptr, nullptr, 0, 0, 0, 0};
-  k.sub = 1; k.ph = k.pw = 0; k.MH = k.MW = 0; k.ntaps_l = 0; k.kill = 0;
+  k.sub = 1; k.ph = k.pw = 0; k.MH = k.MW = 0; k.ntaps_l = 0; k.kill = 0; k.ncls = 0;
   bool chan4 = true;
   for (int i = 0; i < a->nsrc; ++i) chan4 = chan4 && (a->src[i].C % 4 == 0);
   k.vecB = aligned16(a->w) && a->ldw % 4 == 0 && a->cin_total % 4 == 0 && a->w_choff % 4 == 0 && chan4;
@@ -596,7 +614,7 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
   k.vecY = aligned16(a->g) && a->ldg % 4 == 0 && src_vec_ok(a->dst);
   k.P = (long)a->N * a->H * a->W;
   ADDK_REQUIRE(k.P < (1L << 30) && (long)a->N * a->OH * a->OW < (1L << 30), "conv_dgrad: tensor too large for 32-bit pixel indexing");
-  k.sub = 1; k.ph = k.pw = 0; k.MH = k.MW = 0; k.ntaps_l = 0; k.kill = 0;
+  k.sub = 1; k.ph = k.pw = 0; k.MH = k.MW = 0; k.ntaps_l = 0; k.kill = 0; k.ncls = 0;
   const int rows = addk_conv_rows(k.P, a->dst.C);
   if (a->stride == 2 && a->KH * a->KW <= 9 && rows % 4 == 0 && a->H >= 2 && a->W >= 2) {
     // Stride 2: an input pixel only receives the taps whose offset matches its parity, (1,2,2,4) of the 9 taps of a 3x3
@@ -616,6 +634,45 @@ extern "C" int addk_conv_dgrad(const addk_conv_dgrad_args* a, void* stream) {
       if (ntl[cl]) ++nvalid;
     }
     if (nvalid == 0 || rows % nvalid != 0) nvalid = 0;       // 0: fall back to a quarter of the rows per class, every class launched
+    if (rows >= 16) {
+      // ONE launch for all classes (each alone is rows/4 workgroups = one per CU at the stems' sizes: 1 wave per SIMD).
+      // The slab rows (= workgroups) are shared out in proportion to the classes' tap counts so that they finish together;
+      // classes without taps get workgroups beyond the slab (they only store zeros, and only on a first touch).
+      ConvK c = k;
+      c.sub = 2; c.ncls = 0;
+      int tot = 0, nv = 0;
+      for (int cl = 0; cl < 4; ++cl) { tot += ntl[cl]; if (ntl[cl]) ++nv; }
+      int gx0 = 0, left = rows, seen = 0;
+      long pmax = 0;
+      for (int pass = 0; pass < 2; ++pass)          // classes with taps first: their workgroups are the slab rows 0..rows-1
+        for (int cl = 0; cl < 4; ++cl) {
+          if ((ntl[cl] > 0) != (pass == 0)) continue;
+          if (pass == 1 && a->accumulate) continue;            // nothing to add
+          ConvK::Cls& q = c.cl[c.ncls];
+          q.ph = cl >> 1; q.pw = cl & 1;
+          q.MH = (a->H - q.ph + 1) / 2; q.MW = (a->W - q.pw + 1) / 2;
+          q.P = (long)a->N * q.MH * q.MW;
+          q.ntaps_l = ntl[cl] ? ntl[cl] : 1; q.kill = ntl[cl] ? 0 : 1; q.pad_ = 0;
+          for (int i = 0; i < 9; ++i) q.taplist[i] = i < ntl[cl] ? tl[cl][i] : 0;
+          int gx;
+          if (pass == 0) {
+            ++seen;
+            gx = seen == nv ? left : (int)((long)rows * ntl[cl] / tot);
+            if (gx < 1) gx = 1;
+            if (gx > left - (nv - seen)) gx = left - (nv - seen);
+            q.slab = k.slab ? k.slab + (long)gx0 * k.slab_ld * 2 : nullptr;
+            left -= gx;
+          } else {
+            gx = rows / 4; q.slab = nullptr;
+          }
+          q.gx0 = gx0; gx0 += gx;
+          if (q.P > pmax) pmax = q.P;
+          ++c.ncls;
+        }
+      if (nv == 0) return ADDK_OK;               // cannot happen for a convolution (some tap always matches some class)
+      c.P = pmax;
+      return launch<MODE_DGRAD>(c, (hipStream_t)stream, gx0);
+    }
     int vi = 0;
     for (int cl = 0; cl < 4; ++cl) {
         const int ph = cl >> 1, pw = cl & 1;

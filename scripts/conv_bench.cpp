@@ -13,7 +13,7 @@ static float* dev_rand(size_t n, float scale) {
   for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = scale * ((s >> 8) * (1.0f / 8388608.0f) - 1.0f); }
   float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d;
 }
-struct Shape { const char* name; int N, H, W, Cin, Cout, k, dil; };
+struct Shape { const char* name; int N, H, W, Cin, Cout, k, dil, s; };      // s: stride (0 = 1)
 
 static void dw_bench(hipStream_t st, hipEvent_t e0, hipEvent_t e1, int reps) {
   struct D { const char* name; int N, H, W, C, k, s; } ds[] = {
@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
     {"cell 5x5 40->40 @125x253", 2, 125, 253, 40, 40, 5, 1},
     {"glue 1x1 400->80 @63x127", 2, 63, 127, 400, 80, 1, 1},
     {"glue 1x1 800->160 @32x64", 2, 32, 64, 800, 160, 1, 1},
+    {"stem2 3x3s2 64->128 @512x1024", 2, 512, 1024, 64, 128, 3, 1, 2},
   };
   const char* only = getenv("SHAPES");
   int reps = argc > 1 ? atoi(argv[1]) : 20;
@@ -67,31 +68,34 @@ int main(int argc, char** argv) {
   if (only && strstr(only, "dw")) { dw_bench(st, e0, e1, reps); return 0; }
   for (const Shape& s : shapes) {
     if (only && !strstr(s.name, only)) continue;
-    long P = (long)s.N * s.H * s.W;
+    const int str = s.s ? s.s : 1;
     int taps = s.k * s.k, pad = s.dil * (s.k - 1) / 2;
+    const int OH = (s.H + 2 * pad - s.dil * (s.k - 1) - 1) / str + 1, OW = (s.W + 2 * pad - s.dil * (s.k - 1) - 1) / str + 1;
+    long P = (long)s.N * s.H * s.W; const long PI = P; (void)PI;
+    const long PO = (long)s.N * OH * OW;
     float* x = dev_rand(P * s.Cin, 1.f); float* a = dev_rand(s.Cin, 1.f); float* b = dev_rand(s.Cin, 0.5f);
     float* w = dev_rand((size_t)s.Cout * taps * s.Cin, 0.05f);
-    float* y; hipMalloc(&y, P * s.Cout * 4);
+    float* y; hipMalloc(&y, PO * s.Cout * 4);
     float* g; hipMalloc(&g, P * s.Cin * 4);
-    int rows = addk_conv_rows(P, s.Cout);
+    int rows = addk_conv_rows(PO, s.Cout);
     double* slab; hipMalloc(&slab, (size_t)rows * s.Cout * 2 * 8);
     double* dab; hipMalloc(&dab, (size_t)addk_conv_rows(P, s.Cin) * s.Cin * 2 * 8);
     addk_conv_args ar; memset(&ar, 0, sizeof ar);
     ar.src[0].x = x; ar.src[0].a = a; ar.src[0].b = b; ar.src[0].ld = s.Cin; ar.src[0].C = s.Cin; ar.src[0].relu = 1; ar.nsrc = 1;
-    ar.N = s.N; ar.H = s.H; ar.W = s.W; ar.OH = s.H; ar.OW = s.W; ar.KH = ar.KW = s.k; ar.stride = 1; ar.pad = pad; ar.dil = s.dil;
+    ar.N = s.N; ar.H = s.H; ar.W = s.W; ar.OH = OH; ar.OW = OW; ar.KH = ar.KW = s.k; ar.stride = str; ar.pad = pad; ar.dil = s.dil;
     ar.Cout = s.Cout; ar.ldw = taps * s.Cin; ar.cin_total = s.Cin; ar.ldy = s.Cout; ar.w = w; ar.y = y; ar.stats = slab; ar.stats_ld = s.Cout;
     addk_conv_dgrad_args dg; memset(&dg, 0, sizeof dg);
-    dg.dy = y; dg.lddy = s.Cout; dg.Cout = s.Cout; dg.N = s.N; dg.H = s.H; dg.W = s.W; dg.OH = s.H; dg.OW = s.W; dg.KH = dg.KW = s.k;
-    dg.stride = 1; dg.pad = pad; dg.dil = s.dil; dg.w = w; dg.ldw = taps * s.Cin; dg.cin_total = s.Cin; dg.dst = ar.src[0];
+    dg.dy = y; dg.lddy = s.Cout; dg.Cout = s.Cout; dg.N = s.N; dg.H = s.H; dg.W = s.W; dg.OH = OH; dg.OW = OW; dg.KH = dg.KW = s.k;
+    dg.stride = str; dg.pad = pad; dg.dil = s.dil; dg.w = w; dg.ldw = taps * s.Cin; dg.cin_total = s.Cin; dg.dst = ar.src[0];
     dg.g = g; dg.ldg = s.Cin; dg.dab = dab;
     addk_conv_wgrad_args wg; memset(&wg, 0, sizeof wg);
-    wg.dy = y; wg.lddy = s.Cout; wg.Cout = s.Cout; wg.N = s.N; wg.H = s.H; wg.W = s.W; wg.OH = s.H; wg.OW = s.W; wg.KH = wg.KW = s.k;
-    wg.stride = 1; wg.pad = pad; wg.dil = s.dil; wg.src = ar.src[0]; wg.ldw = taps * s.Cin; wg.cin_total = s.Cin;
+    wg.dy = y; wg.lddy = s.Cout; wg.Cout = s.Cout; wg.N = s.N; wg.H = s.H; wg.W = s.W; wg.OH = OH; wg.OW = OW; wg.KH = wg.KW = s.k;
+    wg.stride = str; wg.pad = pad; wg.dil = s.dil; wg.src = ar.src[0]; wg.ldw = taps * s.Cin; wg.cin_total = s.Cin;
     hipMalloc(&wg.dw, (size_t)s.Cout * taps * s.Cin * 4);
-    wg.ws_floats = addk_conv_wgrad_ws(P, s.Cout, s.Cin, taps); hipMalloc(&wg.ws, wg.ws_floats * 4);
+    wg.ws_floats = addk_conv_wgrad_ws(PO, s.Cout, s.Cin, taps); hipMalloc(&wg.ws, wg.ws_floats * 4);
     ar.wpack_floats = addk_conv_fwd_pack_floats(&ar); if (ar.wpack_floats) hipMalloc(&ar.wpack, ar.wpack_floats * 4);
     dg.wpack_floats = addk_conv_dgrad_pack_floats(&dg); if (dg.wpack_floats) hipMalloc(&dg.wpack, dg.wpack_floats * 4);
-    double gf = 2.0 * P * s.Cout * taps * s.Cin * 1e-9;
+    double gf = 2.0 * PO * s.Cout * taps * s.Cin * 1e-9;
     for (int mode = 0; mode < 3; ++mode) {
       auto run = [&] { return mode == 0 ? addk_conv_fwd(&ar, st) : mode == 1 ? addk_conv_dgrad(&dg, st) : addk_conv_wgrad(&wg, st); };
       if (run() != 0) { printf("%s: error %s\n", s.name, addk_last_error()); return 1; }
@@ -110,7 +114,7 @@ int main(int argc, char** argv) {
         hipEventRecord(e0, st); for (int r = 0; r < reps; ++r) run(); hipEventRecord(e1, st); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); ms /= reps;
       }
-      double mb = 4.0 * P * (s.Cin + s.Cout) * 1e-6;
+      double mb = 4.0 * (P * s.Cin + PO * s.Cout) * 1e-6;
       printf("%-34s %-5s %8.1f us  %6.1f TFLOP/s (%.1f GF)  %6.0f GB/s of min traffic\n", s.name, mode == 0 ? "fwd" : mode == 1 ? "dgrad" : "wgrad", ms * 1e3, gf / ms, gf, mb / ms);
     }
     hipFree(x); hipFree(a); hipFree(b); hipFree(w); hipFree(y); hipFree(g); hipFree(slab); hipFree(dab); hipFree(wg.dw); hipFree(wg.ws);
