@@ -133,8 +133,8 @@ __global__ void confusion_kernel(const int64_t* gt, const int64_t* pred, long n,
 // (column w0 + 1).  A1 moves to the right neighbour lane, the 16 rows of the band are reduced through LDS in a fixed order
 // with the row weights, and the part that belongs to row h + 1 is carried in registers to the next band: a gather with no
 // atomics and no second pass over the 1.3 GB/exit of full-resolution logits and gradients the three-kernel form wrote and re-read.
-// A block owns 15 output columns x HB output rows; it re-walks one band above (for the carry) and one column to the left
-// (for A1): (HB+1)/HB * 16/15 redundant softmax work, counted once in the loss (own bands, xl >= 1).
+// A block owns 31 output columns x HB output rows; it re-walks one band above (for the carry) and one column to the left
+// (for A1): (HB+1)/HB * 32/31 redundant softmax work, counted once in the loss (own bands, xl >= 1).
 struct CeUpK {
   const float* x; int ld; int N, H, W, OH, OW;
   const int64_t* target; const float* cw; int ignore;
@@ -169,13 +169,16 @@ __host__ __device__ __forceinline__ int ce_first_out(int i, float scale, int in,
   return g;
 }
 
-constexpr int CEU_R = 16, CEU_X = 16;      // rows of a band / lanes per row (15 output columns + the left neighbour)
+constexpr int CEU_R = 8, CEU_X = 32;       // rows per pass / lanes per row (31 output columns + the left neighbour)
+constexpr int CEU_MAXBAND = 16;            // high-resolution rows per low-resolution row the kernel takes (host check)
 
 template <int CC>
 __global__ void __launch_bounds__(256) ce_up_kernel(const CeUpK p) {
+  constexpr int CP = (CC + 3) / 4 * 4;     // channels incl. the padding of a 16-byte-aligned pixel row
+  constexpr int NOUT = ((CEU_X - 1) * CC + 255) / 256;
   __shared__ float S0[CEU_R * CEU_X * CC], S1[CEU_R * CEU_X * CC];
   __shared__ float shs[4];
-  const int t = threadIdx.x, xl = t & (CEU_X - 1), r = t >> 4;
+  const int t = threadIdx.x, xl = t & (CEU_X - 1), r = t / CEU_X;
   const int tx0 = blockIdx.x * (CEU_X - 1), hb = blockIdx.y * p.HB, n = blockIdx.z;
   const int x = tx0 - 1 + xl;                                   // the low-resolution column this thread owns as w0
   const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
@@ -184,82 +187,102 @@ __global__ void __launch_bounds__(256) ce_up_kernel(const CeUpK p) {
   if (x >= 0 && x < p.W) { xlo = ce_first_out(x, sw, p.W, p.OW); xhi = (x + 1 < p.W) ? ce_first_out(x + 1, sw, p.W, p.OW) : p.OW; }
   const bool xlast = x == p.W - 1;
   const int x1 = x + (x < p.W - 1 ? 1 : 0);
-  const gfloat* lg = (const gfloat*)p.x;
+  const bool vec = (p.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && p.ld >= CP;
   const int64_t __attribute__((address_space(1)))* tgt = (const int64_t __attribute__((address_space(1)))*)p.target;
   const gfloat* cw = (const gfloat*)p.cw;
+  auto load_px = [&](const float* q, float (&v)[CP]) {
+    if (vec) {
+#pragma unroll
+      for (int c = 0; c < CP; c += 4) { const float4 f = ld4(q + c); v[c] = f.x; v[c + 1] = f.y; v[c + 2] = f.z; v[c + 3] = f.w; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) v[c] = ((const gfloat*)q)[c];
+    }
+  };
   float lsum = 0.f;
-  float carry[2] = {0.f, 0.f};
+  float carry[NOUT];
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k) carry[k] = 0.f;
   const int hstart = hb > 0 ? hb - 1 : 0;
   const int hend = hb + p.HB < p.H ? hb + p.HB : p.H;
   for (int h = hstart; h < hend; ++h) {
     const int ylo = ce_first_out(h, sh, p.H, p.OH);
-    const int yhi = (h + 1 < p.H) ? ce_first_out(h + 1, sh, p.H, p.OH) : p.OH;      // host: yhi - ylo <= CEU_R
-    const int Y = ylo + r;
+    const int yhi = (h + 1 < p.H) ? ce_first_out(h + 1, sh, p.H, p.OH) : p.OH;
     const bool own = h >= hb;
-    float A0[CC], A1[CC];
+    float b0[NOUT], b1[NOUT];
 #pragma unroll
-    for (int c = 0; c < CC; ++c) { A0[c] = 0.f; A1[c] = 0.f; }
-    float lh0 = 0.f, lh1 = 0.f;
-    if (Y < yhi && xhi > xlo) {
-      int h0, h1;
-      ce_src_index(Y, sh, p.H, h0, h1, lh0, lh1);
-      const gfloat* b0 = lg + ((long)(n * p.H + h0) * p.W) * p.ld;
-      const gfloat* b1 = lg + ((long)(n * p.H + h1) * p.W) * p.ld;
-      float v00[CC], v01[CC], v10[CC], v11[CC];
+    for (int k = 0; k < NOUT; ++k) { b0[k] = 0.f; b1[k] = 0.f; }
+    for (int yb = ylo; yb < yhi; yb += CEU_R) {                 // the band in passes of CEU_R rows (one pass at the x8 of config 2)
+      const int Y = yb + r;
+      float A0[CC], A1[CC];
+#pragma unroll
+      for (int c = 0; c < CC; ++c) { A0[c] = 0.f; A1[c] = 0.f; }
+      float lh0 = 0.f, lh1 = 0.f;
+      if (Y < yhi && xhi > xlo) {
+        int h0, h1;
+        ce_src_index(Y, sh, p.H, h0, h1, lh0, lh1);
+        const float* r0 = p.x + ((long)(n * p.H + h0) * p.W) * p.ld;
+        const float* r1 = p.x + ((long)(n * p.H + h1) * p.W) * p.ld;
+        float v00[CP], v01[CP], v10[CP], v11[CP];
+        load_px(r0 + (long)x * p.ld, v00); load_px(r0 + (long)x1 * p.ld, v01);
+        load_px(r1 + (long)x * p.ld, v10); load_px(r1 + (long)x1 * p.ld, v11);
+        const int64_t __attribute__((address_space(1)))* tp = tgt + ((long)n * p.OH + Y) * p.OW;
+        for (int X = xlo; X < xhi; ++X) {
+          int w0, w1; float lw0, lw1;
+          ce_src_index(X, sw, p.W, w0, w1, lw0, lw1);
+          const long tg = tp[X];
+          const bool valid = tg != p.ignore && tg >= 0 && tg < CC;
+          const float w = valid ? (cw ? cw[tg] : 1.f) : 0.f;
+          float z[CC];
+          float mx = -INFINITY, zt = 0.f;
+#pragma unroll
+          for (int c = 0; c < CC; ++c) {
+            z[c] = lh0 * (lw0 * v00[c] + lw1 * v01[c]) + lh1 * (lw0 * v10[c] + lw1 * v11[c]);
+            mx = fmaxf(mx, z[c]);
+            if (c == tg) zt = z[c];
+          }
+          float se = 0.f;
+#pragma unroll
+          for (int c = 0; c < CC; ++c) { z[c] = __expf(z[c] - mx); se += z[c]; }
+          if (own && xl >= 1 && valid) lsum += w * (logf(se) + mx - zt);
+          const float k = w * inv / se, kt = w * inv;
+          const float a0 = lw0 + (xlast ? lw1 : 0.f), a1 = xlast ? 0.f : lw1;
+#pragma unroll
+          for (int c = 0; c < CC; ++c) {
+            const float gz = z[c] * k - ((valid && c == tg) ? kt : 0.f);
+            A0[c] = fmaf(a0, gz, A0[c]); A1[c] = fmaf(a1, gz, A1[c]);
+          }
+        }
+      }
+      // column w0 + 1 belongs to the right neighbour lane; then the rows of the pass go through LDS
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
-        v00[c] = b0[(long)x * p.ld + c]; v01[c] = b0[(long)x1 * p.ld + c];
-        v10[c] = b1[(long)x * p.ld + c]; v11[c] = b1[(long)x1 * p.ld + c];
+        float fromleft = __shfl_up(A1[c], 1, CEU_X);
+        if (xl == 0) fromleft = 0.f;
+        const float R = A0[c] + fromleft;
+        S0[(r * CEU_X + xl) * CC + c] = lh0 * R;
+        S1[(r * CEU_X + xl) * CC + c] = lh1 * R;
       }
-      const int64_t __attribute__((address_space(1)))* tp = tgt + ((long)n * p.OH + Y) * p.OW;
-      for (int X = xlo; X < xhi; ++X) {
-        int w0, w1; float lw0, lw1;
-        ce_src_index(X, sw, p.W, w0, w1, lw0, lw1);
-        const long tg = tp[X];
-        const bool valid = tg != p.ignore && tg >= 0 && tg < CC;
-        const float w = valid ? (cw ? cw[tg] : 1.f) : 0.f;
-        float z[CC];
-        float mx = -INFINITY, zt = 0.f;
+      __syncthreads();
 #pragma unroll
-        for (int c = 0; c < CC; ++c) {
-          z[c] = lh0 * (lw0 * v00[c] + lw1 * v01[c]) + lh1 * (lw0 * v10[c] + lw1 * v11[c]);
-          mx = fmaxf(mx, z[c]);
-          if (c == tg) zt = z[c];
-        }
-        float se = 0.f;
+      for (int k = 0; k < NOUT; ++k) {
+        const int j = t + 256 * k;
+        if (j < (CEU_X - 1) * CC) {
+          const int off = CC + j;                               // (ox = 1 + j / CC, c = j % CC) -> ox * CC + c
 #pragma unroll
-        for (int c = 0; c < CC; ++c) { z[c] = expf(z[c] - mx); se += z[c]; }
-        if (own && xl >= 1 && valid) lsum += w * (logf(se) + mx - zt);
-        const float k = w * inv / se, kt = w * inv;
-        const float a0 = lw0 + (xlast ? lw1 : 0.f), a1 = xlast ? 0.f : lw1;
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-          const float gz = z[c] * k - ((valid && c == tg) ? kt : 0.f);
-          A0[c] = fmaf(a0, gz, A0[c]); A1[c] = fmaf(a1, gz, A1[c]);
+          for (int rr = 0; rr < CEU_R; ++rr) { b0[k] += S0[rr * CEU_X * CC + off]; b1[k] += S1[rr * CEU_X * CC + off]; }
         }
       }
+      __syncthreads();
     }
-    // column w0 + 1 belongs to the right neighbour lane; then the rows of the band go through LDS
 #pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      float fromleft = __shfl_up(A1[c], 1, CEU_X);
-      if (xl == 0) fromleft = 0.f;
-      const float R = A0[c] + fromleft;
-      S0[(r * CEU_X + xl) * CC + c] = lh0 * R;
-      S1[(r * CEU_X + xl) * CC + c] = lh1 * R;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NOUT; ++k) {
       const int j = t + 256 * k;
       if (j < (CEU_X - 1) * CC) {
         const int ox = 1 + j / CC, c = j - (ox - 1) * CC;
-        float b0 = 0.f, b1 = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < CEU_R; ++rr) { b0 += S0[(rr * CEU_X + ox) * CC + c]; b1 += S1[(rr * CEU_X + ox) * CC + c]; }
-        if (h == p.H - 1) { b0 += b1; b1 = 0.f; }
-        const float o = carry[k] + b0;
-        carry[k] = b1;
+        if (h == p.H - 1) { b0[k] += b1[k]; b1[k] = 0.f; }
+        const float o = carry[k] + b0[k];
+        carry[k] = b1[k];
         const int col = tx0 - 1 + ox;
         if (own && col < p.W) {
           gfloat* gp = (gfloat*)p.g + ((long)(n * p.H + h) * p.W + col) * p.ldg + c;
@@ -267,7 +290,6 @@ __global__ void __launch_bounds__(256) ce_up_kernel(const CeUpK p) {
         }
       }
     }
-    __syncthreads();
   }
   lsum = block_sum(lsum, shs);
   if (t == 0) ((gfloat*)p.ws)[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = lsum;
@@ -279,7 +301,7 @@ bool ceu_ok(int N, int H, int W, int OH, int OW, int C) {
   const float sh = (float)H / (float)OH;
   for (int h = 0; h < H; ++h) {
     const int lo = ce_first_out(h, sh, H, OH), hi = h + 1 < H ? ce_first_out(h + 1, sh, H, OH) : OH;
-    if (hi - lo > CEU_R) return false;
+    if (hi - lo > CEU_MAXBAND) return false;
   }
   return true;
 }
@@ -328,7 +350,7 @@ extern "C" int64_t addk_ce_upsample_ws_floats(int32_t N, int32_t H, int32_t W) {
 extern "C" int addk_ce_upsample_fwd_bwd(const addk_ce_upsample_args* a, void* stream) {
   ADDK_REQUIRE(a && a->logits && a->target && a->wsum && a->loss_out && a->g && a->ws, "ce_upsample: null pointer");
   ADDK_REQUIRE(a->ld >= a->C && a->ldg >= a->C, "ce_upsample: short stride");
-  ADDK_REQUIRE(ceu_ok(a->N, a->H, a->W, a->OH, a->OW, a->C), "ce_upsample: unsupported shape (19 classes, at most %d output rows per input row)", CEU_R);
+  ADDK_REQUIRE(ceu_ok(a->N, a->H, a->W, a->OH, a->OW, a->C), "ce_upsample: unsupported shape (19 classes, at most %d output rows per input row)", CEU_MAXBAND);
   CeUpK k;
   k.x = a->logits; k.ld = a->ld; k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
   k.target = a->target; k.cw = a->class_w; k.ignore = a->ignore_index; k.wsum = a->wsum; k.scale = a->scale;
