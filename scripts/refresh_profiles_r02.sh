@@ -13,11 +13,15 @@ done
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --force-sync > $O/bench_force_sync_graph.json 2> /dev/null
 ADDK_GRAPH_DDP=0 timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --force-sync > $O/bench_force_sync_eager.json 2> /dev/null
 echo "force-sync: $(python3 -c "import json;print(json.load(open('$O/bench_force_sync_graph.json'))['ms_per_step'], json.load(open('$O/bench_force_sync_eager.json'))['ms_per_step'])")"
+# config 5's architecture (F=40, searched_arch/40_5e_38_lr/genotype_1) at the full size, same step, fp32 storage
+timeout -k 10 400 python3 bench.py --F 40 --genotype 40_5e_38_lr/genotype_1 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config5_F40_genotype1.json 2> /dev/null
+echo "config 5 (F=40 g1): $(python3 -c "import json;d=json.load(open('$O/bench_config5_F40_genotype1.json'));print(d['ms_per_step'], d['value'], d['plan_device_gb'])")"
 for s in 2 1; do
   rm -rf $O/pt; mkdir -p $O/pt
   ADDK_STREAMS=$s timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
   cp $(ls $O/pt/*/*kernel_stats.csv | head -1) $O/step_kernel_stats_${s}stream.csv
   python3 scripts/trace_summary.py $(ls $O/pt/*/*kernel_trace.csv | head -1) 90 > $O/step_last_step_summary_${s}stream.txt
+  python3 scripts/overlap.py $(ls $O/pt/*/*kernel_trace.csv | head -1) > $O/step_overlap_${s}stream.txt
   rm -rf $O/pt
 done
 head -3 $O/step_last_step_summary_2stream.txt
