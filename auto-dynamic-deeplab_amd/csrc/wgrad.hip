@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
       }
     }
 }
+inline bool wgrad_split_narrow() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT_NARROW"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 inline bool wgrad_split_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 constexpr size_t wg_h3b_lds(int nt, int np) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + 3 * 104 * 32); }
 
@@ -839,6 +840,181 @@ __global__ void __launch_bounds__(256, 2) wgrad_hk_kernel(const WgK pv, const Wg
       }
     }
 }
+
+
+// Split-bf16 form of wgrad_hk_kernel (same work decomposition, partial-tile layout and epilogue; arithmetic, LDS images and
+// transposed fragment reads as in wgrad_h3b_kernel): every wave uses all CT output-channel tiles and owns a quarter of the taps.
+constexpr int HKB_ZWP = 72;                 // patch row pitch in pixels: 64 + 4 * 2 (5x5, dilation 2), a multiple of 8
+template <int KS, int CT, bool BATCH, int NP>
+__global__ void __launch_bounds__(256, 2) wgrad_hkb_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
+  if (BATCH) {
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
+  constexpr int TAPS = KS * KS, TPW = (TAPS + 3) / 4, HK = KS / 2;
+  constexpr int BCO = 16 * CT, YQ = BCO / 4;
+  constexpr int NYJ = (H3_KP * YQ + 255) / 256;
+  constexpr int NZJ = (KS * HK_ZW * 4 + 255) / 256;
+  constexpr int YIMG = H3_KP * 32 + 32, ZROW = HKB_ZWP * 32;       // bytes per dy tile image / per patch row (one plane)
+  constexpr int YPL = CT * YIMG, ZPL = KS * ZROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  unsigned char* Yb = wsm;                                        // [NP][CT][64 px][16 co]
+  unsigned char* Zb = wsm + NP * YPL;                             // [NP][KS rows][HKB_ZWP px][16 ci]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
+  const int co0 = yt * BCO, c0 = zt * 16;
+  const int d = p.dil, ZW = H3_KP + (KS - 1) * d;
+  const int spr = (p.OW + H3_KP - 1) / H3_KP;
+  const int nseg = p.N * p.OH * spr;
+  const int sbeg = blk_y * p.chunkP;
+  int send = sbeg + p.chunkP; if (send > nseg) send = nseg;
+
+  int yrow[NYJ], yqv[NYJ];
+#pragma unroll
+  for (int k = 0; k < NYJ; ++k) { const int slot = t + 256 * k; yrow[k] = slot / YQ; yqv[k] = slot - yrow[k] * YQ; }   // yrow >= 64: outside
+  const int zq = t & 3, zc = c0 + 4 * zq, nremz = p.src.C - zc;
+  int zr[NZJ], zj[NZJ];
+#pragma unroll
+  for (int k = 0; k < NZJ; ++k) {
+    const int pix = (t + 256 * k) >> 2;
+    zr[k] = pix / ZW; zj[k] = pix - zr[k] * ZW;         // zr >= KS marks a slot outside the patch
+  }
+  float4 za = make_float4(1.f, 1.f, 1.f, 1.f), zb = zero4();
+  if (p.src.a && nremz > 0) { za = ld4(p.src.a + zc); zb = ld4(p.src.b + zc); }
+  const bool zrelu = p.src.relu != 0;
+  const int tq = li >> 2, tp = li & 3;
+  const int lrow = 8 * kq + tq;
+  int zrow_off[TPW], zshift[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    int tap = wave * TPW + j; if (tap > TAPS - 1) tap = TAPS - 1;      // surplus slots of the last wave recompute the last tap (discarded)
+    zrow_off[j] = (tap / KS) * ZROW; zshift[j] = (tap % KS) * d;
+  }
+
+  f32x4 acc[CT][TPW];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ry[NYJ], rz[NZJ];
+  unsigned ymask = 0, zmask = 0;
+  auto load_step = [&](int seg) {
+    const int rowid = seg / spr, sx = seg - rowid * spr;
+    const int n = rowid / p.OH, oh = rowid - n * p.OH;
+    const int ow0 = sx * H3_KP;
+    const long pp0 = (long)rowid * p.OW + ow0;
+    ymask = 0; zmask = 0;
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      const int co = co0 + 4 * yqv[k];
+      const bool ok = yrow[k] < H3_KP && co < p.Cout && ow0 + yrow[k] < p.OW;
+      ry[k] = ld4(ok ? p.dy + (pp0 + yrow[k]) * p.lddy + co : p.dy);
+      ymask |= (ok ? 1u : 0u) << k;
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      const int ih = oh + (zr[k] - HK) * d, iw = ow0 - HK * d + zj[k];
+      const bool ok = zr[k] < KS && nremz > 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rz[k] = ld4(ok ? p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + zc : p.src.x);
+      zmask |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      float4 v = ry[k];
+      const bool ok = (ymask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (yrow[k] < H3_KP) {
+        uint2 pl[NP];
+        wg_split4<NP>(v, pl);
+        const int off = (yqv[k] >> 2) * YIMG + wg_prow(yrow[k]) + 8 * (yqv[k] & 3);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(Yb + m * YPL + off) = pl[m];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) {
+      float4 v = rz[k];
+      v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
+      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const bool ok = (zmask >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (zr[k] < KS) {
+        uint2 pl[NP];
+        wg_split4<NP>(v, pl);
+        const int off = zr[k] * ZROW + wg_prow(zj[k]) + 8 * zq;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(Zb + m * ZPL + off) = pl[m];
+      }
+    }
+  };
+  auto rd = [&](const unsigned char* base, int plane_bytes, int pix0, wg_bf16x8* f) {
+    const int o0 = wg_prow(pix0 + lrow) + 8 * tp, o1 = wg_prow(pix0 + lrow + 4) + 8 * tp;
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o0));
+      const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o1));
+      struct { wg_s16x4 a, b; } pr = {lo, hi};          // whole-register reinterpretation (see wgrad_h3b_kernel)
+      f[m] = __builtin_bit_cast(wg_bf16x8, pr);
+    }
+  };
+  auto mma = [&](f32x4 (&c)[CT][TPW], int j, const wg_bf16x8 (&y)[CT][NP], const wg_bf16x8* z) {
+#define WG_TERM(YI, ZI) _Pragma("unroll") for (int i = 0; i < CT; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i][YI], z[ZI], c[i][j], 0, 0, 0);
+    if (NP == 3) { WG_TERM(2, 0) WG_TERM(0, 2) WG_TERM(1, 1) }
+    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0)
+#undef WG_TERM
+  };
+
+  if (sbeg < send) {
+    load_step(sbeg);
+    store_step();
+    __syncthreads();
+    for (int seg = sbeg; seg < send; ++seg) {
+      const bool more = seg + 1 < send;
+      if (more) load_step(seg + 1);
+#pragma unroll
+      for (int ks = 0; ks < H3_KP / 32; ++ks) {
+        wg_bf16x8 yf[CT][NP];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) rd(Yb + i * YIMG, YPL, ks * 32, yf[i]);
+        wg_bf16x8 zf[2][NP];
+        rd(Zb + zrow_off[0], ZPL, ks * 32 + zshift[0], zf[0]);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          if (j + 1 < TPW) rd(Zb + zrow_off[j + 1], ZPL, ks * 32 + zshift[j + 1], zf[(j + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(acc, j, yf, zf[j & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      if (more) { store_step(); __syncthreads(); }
+    }
+  }
+  const int C = p.src.C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * TAPS * C;
+  const int c = c0 + li;
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cow = co0 + i * 16 + kq * 4 + r;
+      if (cow < p.Cout && c < C) {
+        gfloat* o = wsb + (long)cow * TAPS * C + c;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const int tap = wave * TPW + j;
+          if (tap < TAPS) o[tap * C] = acc[i][j][r];
+        }
+      }
+    }
+}
+constexpr size_t wg_hkb_lds(int ks, int ct, int np) { return (size_t)np * ((size_t)ct * (H3_KP * 32 + 32) + (size_t)ks * HKB_ZWP * 32); }
 
 // Register-streaming weight gradient for the narrow cell convolutions (Cout, C <= 160; 1x1, dilated k x k, strided):
 // no LDS staging and no barrier in the main loop.  A wave walks its own pixel range four pixels per MFMA k-step; lane
@@ -1238,8 +1414,20 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_OS(1, 4, 2) ADDK_OS(2, 3, 3) ADDK_OS(3, 2, 2) ADDK_OS(4, 4, 4)
 #undef ADDK_OS
+  const int hk_np = addk_get_conv_precision() == 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;
+#define ADDK_HKB_(K_, C_, B_, P_) { \
+    static bool attr = false; \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hkb_kernel<K_, C_, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    hipLaunchKernelGGL((wgrad_hkb_kernel<K_, C_, B_, P_>), grid, dim3(256), wg_hkb_lds(K_, C_, P_), st, k, ops, work); done = true; }
+#define ADDK_HKB(K_, C_) \
+  if (kind == 7 && ctz == K_ && cty == C_ && hk_np && wgrad_split_enabled() && wgrad_split_narrow()) { \
+    if (ops) { if (hk_np == 3) ADDK_HKB_(K_, C_, true, 3) else ADDK_HKB_(K_, C_, true, 2) } \
+    else { if (hk_np == 3) ADDK_HKB_(K_, C_, false, 3) else ADDK_HKB_(K_, C_, false, 2) } }
+  ADDK_HKB(3, 3) ADDK_HKB(3, 5) ADDK_HKB(5, 3)
+#undef ADDK_HKB
+#undef ADDK_HKB_
 #define ADDK_HK(K_, C_) \
-  if (kind == 7 && ctz == K_ && cty == C_) { \
+  if (!done && kind == 7 && ctz == K_ && cty == C_) { \
     if (ops) hipLaunchKernelGGL((wgrad_hk_kernel<K_, C_, true>), grid, dim3(256), 0, st, k, ops, work); \
     else hipLaunchKernelGGL((wgrad_hk_kernel<K_, C_, false>), grid, dim3(256), 0, st, k, ops, work); \
     done = true; }
@@ -1252,16 +1440,22 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_RS(3, 3) ADDK_RS(3, 4) ADDK_RS(4, 3) ADDK_RS(4, 4)
 #undef ADDK_RS
-  // wide 3x3 (decoder, ASPP: 128-channel blocks) in a split-bf16 mode: the transposed-read kernel; the 64-channel blocks
-  // (stem1) stay on fp32, as the narrow launches of the forward / data-gradient kernels do (conv3.hip, c3_planes)
+  // 3x3 convolutions in a split-bf16 mode: the transposed-read kernel — the 128-channel blocks (decoder, ASPP) always, the
+  // 64-channel blocks (stem1) unless ADDK_WGRAD_SPLIT_NARROW=0 (0.76 -> 0.61 ms, the stem1 weight gradient's distance to fp64
+  // unchanged at 1.47e-3 against the fp32 oracle's 1.56e-3; the FORWARD / data-gradient launches with <= 64 output channels
+  // stay on fp32: conv3.hip c3_planes)
   const int wg_np = addk_get_conv_precision() == 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;
-#define ADDK_H3B_(B_, P_) { \
+#define ADDK_H3B_(N_, B_, P_) { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<2, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
-    hipLaunchKernelGGL((wgrad_h3b_kernel<2, B_, P_>), grid, dim3(256), wg_h3b_lds(2, P_), st, k, ops, work); done = true; }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    hipLaunchKernelGGL((wgrad_h3b_kernel<N_, B_, P_>), grid, dim3(256), wg_h3b_lds(N_, P_), st, k, ops, work); done = true; }
   if (kind == 5 && cty == 8 && wg_np && wgrad_split_enabled()) {
-    if (ops) { if (wg_np == 3) ADDK_H3B_(true, 3) else ADDK_H3B_(true, 2) }
-    else { if (wg_np == 3) ADDK_H3B_(false, 3) else ADDK_H3B_(false, 2) }
+    if (ops) { if (wg_np == 3) ADDK_H3B_(2, true, 3) else ADDK_H3B_(2, true, 2) }
+    else { if (wg_np == 3) ADDK_H3B_(2, false, 3) else ADDK_H3B_(2, false, 2) }
+  }
+  if (kind == 5 && cty == 4 && wg_np && wgrad_split_enabled() && wgrad_split_narrow()) {
+    if (ops) { if (wg_np == 3) ADDK_H3B_(1, true, 3) else ADDK_H3B_(1, true, 2) }
+    else { if (wg_np == 3) ADDK_H3B_(1, false, 3) else ADDK_H3B_(1, false, 2) }
   }
 #undef ADDK_H3B_
 #define ADDK_H3(NT_) \
