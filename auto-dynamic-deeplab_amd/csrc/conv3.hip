@@ -666,11 +666,14 @@ int c3b_wc(int Cn) {
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
 // bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  Launches with <= 64 output
-// channels (stem1, the cells' 40-channel dilated convs) stay on the fp32 kernel: the 2-wave blocks of the split kernel stage
-// 13-22 slots per thread and spill (5x5 at 40 channels: 113 vs 88 us), and in the whole-network frozen-BatchNorm gradient test
-// at 2x512x1024 they — not the wide variants — doubled the distance to the fp64 oracle (median 4.7e-4 vs 2.5e-4 with the fp32
-// kernels; with them excluded 2.5e-4, and the decoder / ASPP / late-cell gradients are 2-6x CLOSER to fp64 than on fp32 MFMA).
-// ADDK_C3B_MINC moves the threshold (experiments).
+// channels (stem1, the cells' 40-channel dilated convs) stay on the fp32 kernel for SPEED: the 2-wave blocks of the split
+// kernel stage 13-22 slots per thread and spill (5x5 at 40 channels: 125 vs 78 us, stem1 forward 0.82 vs 0.73 ms; the step
+// measures the same with either).  Accuracy does not separate the two: the network amplifies any 1e-7 perturbation of the
+// stems to 1e-4..1e-3 in the whole-network frozen-BatchNorm gradients, and over four input draws at 2x512x1024 split-bf16
+// everywhere was CLOSER to fp64 than the fp32 kernels in all four (median 0.40-0.89x the fp32 oracle's error against
+// 0.84-1.22x; profiles/r02_split_threshold_study.txt) — the one draw of test_add_whole_net_frozen_bn_gradients that had
+// suggested the opposite (4.9e-4 vs 2.5e-4) was a sample of that spread.  ADDK_C3B_MINC / addk_set_split_min_channels move
+// the threshold.
 int g_c3b_minc = -1;
 inline int c3_planes(int Cn, int taps) {
   const int m = addk_get_conv_precision();

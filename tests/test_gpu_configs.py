@@ -269,3 +269,46 @@ def test_full_size_config4_dynamic_inference(dev, hw):
             ec = rel_err(conf_a, conf_o)
             _log('%-60s logits sub8 %.3e  confidence %.3e  (%.1f ms)', 'config4 %dx%d dynamic %s exit vs oracle' % (hw + (name,)), e, ec, secs * 1e3)
             assert tuple(ya.shape) == (1, 19) + hw and e <= 1e-3 and ec <= 1e-3
+
+
+@pytest.mark.skipif(__import__('os').environ.get('ADDK_STUDY') != '1', reason='measurement study (ADDK_STUDY=1), not a parity gate')
+def test_study_split_threshold_over_input_draws(dev):
+    """Whole-network frozen-BN conv-weight gradients at 2x512x1024 over several input draws, for three arithmetics of the
+    halo kernels: exact fp32, the shipped rule (split-bf16 above 64 output channels) and split-bf16 everywhere.  The network
+    amplifies any 1e-7 perturbation of the stems to 1e-4..1e-3 in the gradients (the fp32 oracle itself sits there), so one
+    draw cannot rank the arithmetics; the report lists median and maximum error vs fp64 relative to the fp32 oracle's."""
+    import addk
+    import addk._lib as L
+    from test_gpu_parity import _build_add
+    lib = L.load()
+    hw = (512, 1024)
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    rows = []
+    for draw in range(int(__import__('os').environ.get('ADDK_STUDY_DRAWS', '3'))):
+        x = rand_tensor(900 + draw, 'study_x', (2, 3) + hw)
+        tgt = torch.from_numpy(np.random.default_rng(950 + draw).integers(0, 19, (2,) + hw)).long()
+        _, mo, _ = _build_add(dev, 20, ARCH_C2)
+        mo.eval()
+        (sum(crit(y, tgt) for y in mo(x)) / 2).backward()
+        m64 = oracle.ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(20), ARCH_C2['low_level_layer']).double()
+        m64.load_state_dict(mo.state_dict()); m64.eval()
+        (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
+        p64 = dict(m64.named_parameters())
+        keys = [k for k, p in mo.named_parameters() if p.dim() == 4 and p.grad is not None]
+        theirs = sorted(rel_err(dict(mo.named_parameters())[k].grad.double(), p64[k].grad) for k in keys)
+        for name, prec, minc in (('fp32', 'fp32', 65), ('rule>64', 'bf16x6', 65), ('all', 'bf16x6', 0)):
+            addk.set_precision(prec)
+            lib.addk_set_split_min_channels(minc)
+            ma, _, _ = _build_add(dev, 20, ARCH_C2)
+            ma.eval()
+            (sum(crit(y, tgt.to(dev)) for y in ma(x.to(dev))) / 2).backward()
+            torch.cuda.synchronize()
+            pa = dict(ma.named_parameters())
+            ours = sorted(rel_err(pa[k].grad.cpu().double(), p64[k].grad) for k in keys)
+            rows.append('draw %d %-8s median %.2e (%.2f x oracle)  max %.2e (%.2f x oracle)' % (
+                draw, name, ours[len(ours) // 2], ours[len(ours) // 2] / theirs[len(theirs) // 2], ours[-1], ours[-1] / theirs[-1]))
+            del ma
+            torch.cuda.empty_cache()
+    addk.set_precision('bf16x6'); lib.addk_set_split_min_channels(65)
+    REPORT.extend(rows)
+    print('\n'.join(rows))
