@@ -402,23 +402,26 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
   }
 }
 
-template <int WC, int KS, int MODE, int NP, bool BIGD>
-__global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
-  constexpr int BC = 32 * WC, NTHR = 64 * WC;
+// PH = 2 (the <= 64-channel launches): the block's waves are also split over the two 64-pixel halves of the tile — wave w owns
+// channels [32 (w % WC), +32) of pixels [64 (w / WC), +64), two accumulator tiles — so that 4 waves share the staging work of
+// a 64-channel block (2-wave blocks staged 13-22 slots per thread and spilled).
+template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1>
+__global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
+  constexpr int BC = 32 * WC, NTHR = 64 * WC * PH, PT = CB_PT / PH;
   constexpr int TAPS = KS * KS, HK = KS / 2;
   constexpr int PWP = cb_pwmax(KS, BIGD);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
   constexpr int NS = (KS * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
   static_assert(NS <= 32, "slot mask is 32 bits");
   constexpr int PLANE = KS * PWP * 2;                             // uint4 units per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* red = reinterpret_cast<double*>(smem);                  // [BC][2] running statistics of this block
-  uint4* Pl = reinterpret_cast<uint4*>(smem + ((BC * 16 + 15) & ~15));   // [NP][KS][PWP][2] 16-byte halves
+  double* red = reinterpret_cast<double*>(smem);                  // [PH][BC][2] running statistics of this block (per pixel half)
+  uint4* Pl = reinterpret_cast<uint4*>(smem + ((PH * BC * 16 + 15) & ~15));   // [NP][KS][PWP][2] 16-byte halves
   uint2* Pl2 = reinterpret_cast<uint2*>(Pl);
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lp32 = lane & 31, hh = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wave = wv % WC, wpx = wv / WC, lp32 = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.y * BC;
   const int d = p.dil, PW = C3_BP + (KS - 1) * d;
-  for (int i = t; i < BC * 2; i += NTHR) red[i] = 0.0;
+  for (int i = t; i < PH * BC * 2; i += NTHR) red[i] = 0.0;
 
   const int q = t & 3;
   // fragment read base per kernel column: pixel lane%32 + kw*d of patch row 0, the 16-byte half swizzled by bit 3 of the pixel
@@ -455,9 +458,9 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
       vmask |= (ok ? 1u : 0u) << k;
     }
 
-    f32x16 acc[CB_PT];
+    f32x16 acc[PT];
 #pragma unroll
-    for (int j = 0; j < CB_PT; ++j)
+    for (int j = 0; j < PT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
@@ -513,7 +516,7 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
       const int kh = tap / KS, kw = tap - kh * KS;
       const uint4* b = Pl + xb[kw];
 #pragma unroll
-      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + (kh * PWP + j * 32) * 2];
+      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + (kh * PWP + (wpx * PT + j) * 32) * 2];
     };
     // The accumulation inside the bf16 MFMA is not symmetric: what falls below its internal guard bits is floored, not rounded, so
     // a result sits, on average, 0.17 rms errors BELOW the exact sum whatever the sign of the data (scripts/bf16_bias_probe.hip:
@@ -559,8 +562,8 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
         load_w(T0 + tap + 2, wr[(tap + 2) % 3]);
         if (tap == 0 && more) load_patch(s2, c2);
 #pragma unroll
-        for (int j = 0; j < CB_PT; ++j) {
-          const int nj = (j + 1) % CB_PT, ntap = tap + (j + 1) / CB_PT;
+        for (int j = 0; j < PT; ++j) {
+          const int nj = (j + 1) % PT, ntap = tap + (j + 1) / PT;
           if (ntap < TAPS) read_x(ntap, nj, xr[(j + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
           mma(acc[j], wr[tap % 3], xr[j & 1]);
@@ -590,8 +593,8 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[g][e] = 0.f; s2v[g][e] = 0.f; }
 #pragma unroll
-    for (int j = 0; j < CB_PT; ++j) {
-      const int lp = j * 32 + lp32;
+    for (int j = 0; j < PT; ++j) {
+      const int lp = (wpx * PT + j) * 32 + lp32;
       const long pp = (long)rowid * p.W + ow0 + lp;
       const bool pin = ow0 + lp < p.W;
 #pragma unroll
@@ -638,7 +641,7 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
           float a = s1[g][e], b = s2v[g][e];
 #pragma unroll
           for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-          if (lp32 == 0) { double* r = red + (wave * 32 + 8 * g + 4 * hh + e) * 2; r[0] += (double)a; r[1] += (double)b; }
+          if (lp32 == 0) { double* r = red + ((wpx * BC) + wave * 32 + 8 * g + 4 * hh + e) * 2; r[0] += (double)a; r[1] += (double)b; }
         }
     }
   }
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
     __syncthreads();
     if (t < BC && n0 + t < p.Cn) {
       double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
-      o[0] = red[2 * t]; o[1] = red[2 * t + 1];
+      o[0] = red[2 * t] + (PH > 1 ? red[2 * (BC + t)] : 0.0); o[1] = red[2 * t + 1] + (PH > 1 ? red[2 * (BC + t) + 1] : 0.0);
     }
   }
 }
@@ -654,7 +657,7 @@ __global__ void __launch_bounds__(64 * WC, 2) conv3b_kernel(const C3K p) {
 // 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 3..5 that pads the channel count least (ties: the wider)
 int c3b_wc(int Cn) {
   { static int f = -1; if (f < 0) { const char* e = getenv("ADDK_C3B_FORCEWC"); f = e ? atoi(e) : 0; } if (f && Cn <= 64) return f; }   // experiment knob
-  if (Cn <= 64) return 2;                 // 2-wave blocks stage 13+ slots per thread (register spills): only where nothing wider fits
+  if (Cn <= 64) return 2;                 // two channel tiles; the launch adds the two pixel halves (4 waves, conv3b_kernel PH = 2)
   int best = 4; long bc = -1;
   const int cands[3] = {5, 4, 3};
   for (int i = 0; i < 3; ++i) {
@@ -665,20 +668,20 @@ int c3b_wc(int Cn) {
 }
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
-// bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  Launches with <= 64 output
-// channels (stem1, the cells' 40-channel dilated convs) stay on the fp32 kernel for SPEED: the 2-wave blocks of the split
-// kernel stage 13-22 slots per thread and spill (5x5 at 40 channels: 125 vs 78 us, stem1 forward 0.82 vs 0.73 ms; the step
-// measures the same with either).  Accuracy does not separate the two: the network amplifies any 1e-7 perturbation of the
-// stems to 1e-4..1e-3 in the whole-network frozen-BatchNorm gradients, and over four input draws at 2x512x1024 split-bf16
-// everywhere was CLOSER to fp64 than the fp32 kernels in all four (median 0.40-0.89x the fp32 oracle's error against
-// 0.84-1.22x; profiles/r02_split_threshold_study.txt) — the one draw of test_add_whole_net_frozen_bn_gradients that had
-// suggested the opposite (4.9e-4 vs 2.5e-4) was a sample of that spread.  ADDK_C3B_MINC / addk_set_split_min_channels move
-// the threshold.
+// bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  Every halo launch takes the
+// split kernel, the <= 64-channel ones (stem1, the cells' 40-channel dilated convs) on 4-wave blocks = 2 channel tiles x 2
+// pixel halves (PH = 2; the first 2-wave form staged 13-22 slots per thread, spilled and was slower than fp32: 125 vs 78 us
+// for a 5x5 at 40 channels, now 62).  Accuracy: the network amplifies any 1e-7 perturbation of the stems to 1e-4..1e-3 in the
+// whole-network frozen-BatchNorm gradients, so one input draw cannot rank arithmetics — the draw of
+// test_add_whole_net_frozen_bn_gradients that once suggested keeping the narrow launches on fp32 (4.9e-4 vs 2.5e-4 median) was
+// a sample of that spread: over four more draws at 2x512x1024 split-bf16 everywhere was CLOSER to fp64 than the fp32 kernels
+// in all four (median 0.40-0.89x the fp32 oracle's error against 0.84-1.22x; profiles/r02_split_threshold_study.txt).
+// ADDK_C3B_MINC / addk_set_split_min_channels(n) keep launches with fewer than n output channels on the fp32 kernel.
 int g_c3b_minc = -1;
 inline int c3_planes(int Cn, int taps) {
   const int m = addk_get_conv_precision();
   (void)taps;
-  if (g_c3b_minc < 0) { const char* e = getenv("ADDK_C3B_MINC"); g_c3b_minc = e ? atoi(e) : 65; }
+  if (g_c3b_minc < 0) { const char* e = getenv("ADDK_C3B_MINC"); g_c3b_minc = e ? atoi(e) : 0; }
   if (m == 0 || Cn < g_c3b_minc) return 0;
   return m == 2 ? 3 : 2;
 }
@@ -724,13 +727,15 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
   const bool bigd = pk.taps == 9 && k.dil > 2;
   const int ks = pk.taps == 9 ? 3 : 5;
-  const size_t lds = (size_t)((32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd) * 32;
+  const int ph = wc == 2 ? 2 : 1;                                  // <= 64 channels: 4 waves = 2 channel tiles x 2 pixel halves
+  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd) * 32;
   dim3 grid(rows, cdiv(k.Cn, 32 * wc));
   bool done = false;
 #define ADDK_C3B_(W_, K_, M_, P_, D_) { \
+    constexpr int H_ = W_ == 2 ? 2 : 1; \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
-    hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, D_>), grid, dim3(64 * W_), lds, st, k); done = true; }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_, H_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, D_, H_>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
 #define ADDK_C3B(W_, K_, D_) \
   if (!done && wc == W_ && ks == K_ && bigd == D_) { \
     if (mode == MODE_FWD) { if (np == 3) ADDK_C3B_(W_, K_, MODE_FWD, 3, D_) else ADDK_C3B_(W_, K_, MODE_FWD, 2, D_) } \
@@ -843,7 +848,7 @@ static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK
   return c3_launch(k, pk, MODE_DGRAD, rows, (hipStream_t)stream, a->wpack_ready != 0, desc_out);
 }
 
-extern "C" int addk_set_split_min_channels(int c) { g_c3b_minc = c < 0 ? 65 : c; return ADDK_OK; }
+extern "C" int addk_set_split_min_channels(int c) { g_c3b_minc = c < 0 ? 0 : c; return ADDK_OK; }
 int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) { return c3_fwd(a, rows, stream, nullptr); }
 int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) { return c3_dgrad(a, rows, stream, nullptr); }
 

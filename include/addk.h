@@ -104,8 +104,8 @@ int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a);
  * Every other kernel computes in fp32.  Process-wide; set before plans are built (packed-weight buffers are sized per mode).
  * Environment: ADDK_MATH=fp32|bf16x6|bf16x3. */
 int addk_set_conv_precision(int mode);
-/* Split-bf16 modes: launches with fewer output channels than this stay on the exact fp32 kernel (default 65, see conv3.hip;
- * tests lower it to reach the narrow variants).  c < 0 restores the default. */
+/* Split-bf16 modes: launches with fewer output channels than this stay on the exact fp32 kernel (default 0 = none, see
+ * conv3.hip; 65 = round-2's first rule, kept for A/B runs).  c < 0 restores the default. */
 int addk_set_split_min_channels(int c);
 /* Specialised kernels that may replace the generic ones (all on by default; results agree to fp32 rounding).  The mask is
  * process-wide and is meant for tests and A/B timing; the environment (ADDK_PW=0, ADDK_C3=0, ADDK_WGRAD_H3=0, ADDK_DWTILE=0, ADDK_WGRAD_RS=0) sets the
