@@ -159,7 +159,11 @@ class TrainStep:
                 torch.cuda.synchronize()
                 try:
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    # A step with RCCL exchanges is captured in THREAD-LOCAL error mode: ProcessGroupNCCL's watchdog thread keeps
+                    # querying the events of the eager step's collectives, and in the default global mode such a query from
+                    # another thread while this one captures is an illegal call that aborts the process (seen as a rare
+                    # SIGABRT of `bench.py --force-sync`, timing dependent).
+                    with torch.cuda.graph(graph, capture_error_mode='thread_local' if self.has_coll else 'global'):
                         self._run()
                     self.graph = graph
                 except Exception as e:            # a collective step whose capture the runtime refuses: stay on the eager list
