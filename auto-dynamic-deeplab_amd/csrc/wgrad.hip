@@ -1440,10 +1440,8 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_RS(3, 3) ADDK_RS(3, 4) ADDK_RS(4, 3) ADDK_RS(4, 4)
 #undef ADDK_RS
-  // 3x3 convolutions in a split-bf16 mode: the transposed-read kernel — the 128-channel blocks (decoder, ASPP) always, the
-  // 64-channel blocks (stem1) unless ADDK_WGRAD_SPLIT_NARROW=0 (0.76 -> 0.61 ms, the stem1 weight gradient's distance to fp64
-  // unchanged at 1.47e-3 against the fp32 oracle's 1.56e-3; the FORWARD / data-gradient launches with <= 64 output channels
-  // stay on fp32: conv3.hip c3_planes)
+  // 3x3 convolutions in a split-bf16 mode: the transposed-read kernel — the 128-channel blocks (decoder, ASPP) and the
+  // 64-channel blocks (stem1: 0.76 -> 0.61 ms alone; ADDK_WGRAD_SPLIT_NARROW=0 keeps stem1 and the cells' dilated convs on fp32)
   const int wg_np = addk_get_conv_precision() == 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;
 #define ADDK_H3B_(N_, B_, P_) { \
     static bool attr = false; \
