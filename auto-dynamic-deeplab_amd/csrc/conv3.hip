@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CB_PT = 4;                   // 32-pixel tiles per wave (128 pixels)
-constexpr int cb_pwmax(int ks, bool bigd) { return ks == 3 ? (bigd ? C3_BP + 2 * 18 : C3_BP + 2 * 2) : C3_BP + 4 * 2; }
+constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP) { return ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
 
 __device__ __forceinline__ unsigned bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b << 16); }
@@ -405,11 +405,13 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
 // PH = 2 (the <= 64-channel launches): the block's waves are also split over the two 64-pixel halves of the tile — wave w owns
 // channels [32 (w % WC), +32) of pixels [64 (w / WC), +64), two accumulator tiles — so that 4 waves share the staging work of
 // a 64-channel block (2-wave blocks staged 13-22 slots per thread and spilled).
-template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1>
+// BPX = 64: half-width pixel tiles (two accumulator tiles per wave) for launches that would otherwise put fewer than ~1.5
+// blocks on a CU (ASPP at 64x128, the 80-channel cell convs at 63x127: 126-256 blocks of 128 pixels = one wave per SIMD or less).
+template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP>
 __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
-  constexpr int BC = 32 * WC, NTHR = 64 * WC * PH, PT = CB_PT / PH;
+  constexpr int BC = 32 * WC, NTHR = 64 * WC * PH, PT = BPX / 32 / PH;
   constexpr int TAPS = KS * KS, HK = KS / 2;
-  constexpr int PWP = cb_pwmax(KS, BIGD);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
+  constexpr int PWP = cb_pwmax(KS, BIGD, BPX);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
   constexpr int NS = (KS * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
   static_assert(NS <= 32, "slot mask is 32 bits");
   constexpr int PLANE = KS * PWP * 2;                             // uint4 units per plane
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wave = wv % WC, wpx = wv / WC, lp32 = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.y * BC;
-  const int d = p.dil, PW = C3_BP + (KS - 1) * d;
+  const int d = p.dil, PW = BPX + (KS - 1) * d;
   for (int i = t; i < PH * BC * 2; i += NTHR) red[i] = 0.0;
 
   const int q = t & 3;
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
     const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
     const int rowid = tile / p.spr, sx = tile - rowid * p.spr;
     const int n = rowid / p.H, oh = rowid - n * p.H;
-    const int ow0 = sx * C3_BP;
+    const int ow0 = sx * BPX;
     unsigned vmask = 0;
     const int pbase = (n * p.H + oh - HK * d) * p.W + ow0 - HK * d;
     const unsigned par0 = (unsigned)(oh + ow0);                 // parity of (ih + iw) of patch element (r, pj) = par0 + r*d + pj (the -2 HK d is even)
@@ -664,10 +666,14 @@ int c3b_wc(int Cn) {
     const long cols = (long)cdiv(Cn, 32 * cands[i]) * 32 * cands[i];
     if (bc < 0 || cols < bc) { bc = cols; best = cands[i]; }
   }
+  // 5-wave blocks sit badly on 4 SIMDs (one block per CU at this register count, one SIMD with two waves): 4-wave blocks win
+  // up to ~10 % more padded columns (ASPP data gradient, 400 channels: 4 x 128 instead of 3 x 160, 304 -> 200 us)
+  if (best == 5 && (long)cdiv(Cn, 128) * 128 * 10 <= bc * 11) best = 4;
   return best;
 }
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
+inline bool c3b_half_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_HALF"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 // bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  Every halo launch takes the
 // split kernel, the <= 64-channel ones (stem1, the cells' 40-channel dilated convs) on 4-wave blocks = 2 channel tiles x 2
 // pixel halves (PH = 2; the first 2-wave form staged 13-22 slots per thread, spilled and was slower than fp32: 125 vs 78 us
@@ -718,32 +724,39 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   k.nT = pk.nchunks * pk.taps;
   k.wp = pk.out;
   k.wp_blk = (long)pk.nchunks * pk.taps * wc * np * 64;          // 16-byte units per column block
-  k.spr = cdiv(k.W, C3_BP);
+  const bool bigd = pk.taps == 9 && k.dil > 2;
+  const int ks = pk.taps == 9 ? 3 : 5;
+  const int ph = wc == 2 ? 2 : 1;                                  // <= 64 channels: 4 waves = 2 channel tiles x 2 pixel halves
+  // half-width tiles where 128-pixel tiles leave the chip short of blocks (instantiated for 3- and 4-wave blocks)
+  const long blocks128 = (long)k.N * k.H * cdiv(k.W, C3_BP) * cdiv(k.Cn, 32 * wc);
+  const bool half = ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && blocks128 < 384 && c3b_half_enabled();
+  const int bpx = half ? 64 : C3_BP;
+  k.spr = cdiv(k.W, bpx);
   k.ntiles = k.N * k.H * k.spr;
   k.red32 = 1;
   if (desc_out) { *desc_out = pk; return ADDK_OK; }
   const long total = (long)cdiv(k.Cn, 32 * wc) * k.nT * wc * 64;   // pack threads: one per (tile, lane)
   int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
   if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
-  const bool bigd = pk.taps == 9 && k.dil > 2;
-  const int ks = pk.taps == 9 ? 3 : 5;
-  const int ph = wc == 2 ? 2 : 1;                                  // <= 64 channels: 4 waves = 2 channel tiles x 2 pixel halves
-  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd) * 32;
+  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd, bpx) * 32;
   dim3 grid(rows, cdiv(k.Cn, 32 * wc));
   bool done = false;
-#define ADDK_C3B_(W_, K_, M_, P_, D_) { \
+#define ADDK_C3B_(W_, K_, M_, P_, D_, X_) { \
     constexpr int H_ = W_ == 2 ? 2 : 1; \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_, H_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
-    hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, D_, H_>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
-#define ADDK_C3B(W_, K_, D_) \
-  if (!done && wc == W_ && ks == K_ && bigd == D_) { \
-    if (mode == MODE_FWD) { if (np == 3) ADDK_C3B_(W_, K_, MODE_FWD, 3, D_) else ADDK_C3B_(W_, K_, MODE_FWD, 2, D_) } \
-    else { if (np == 3) ADDK_C3B_(W_, K_, MODE_DGRAD, 3, D_) else ADDK_C3B_(W_, K_, MODE_DGRAD, 2, D_) } }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_, H_, X_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, D_, H_, X_>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
+#define ADDK_C3BX(W_, K_, D_, X_) \
+  if (!done && wc == W_ && ks == K_ && bigd == D_ && bpx == X_) { \
+    if (mode == MODE_FWD) { if (np == 3) ADDK_C3B_(W_, K_, MODE_FWD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_FWD, 2, D_, X_) } \
+    else { if (np == 3) ADDK_C3B_(W_, K_, MODE_DGRAD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_DGRAD, 2, D_, X_) } }
+#define ADDK_C3B(W_, K_, D_) ADDK_C3BX(W_, K_, D_, C3_BP)
   ADDK_C3B(2, 3, false) ADDK_C3B(3, 3, false) ADDK_C3B(4, 3, false) ADDK_C3B(5, 3, false)
   ADDK_C3B(3, 3, true) ADDK_C3B(4, 3, true) ADDK_C3B(5, 3, true) ADDK_C3B(2, 3, true)
   ADDK_C3B(2, 5, false) ADDK_C3B(3, 5, false) ADDK_C3B(4, 5, false) ADDK_C3B(5, 5, false)
+  ADDK_C3BX(3, 3, false, 64) ADDK_C3BX(3, 5, false, 64) ADDK_C3BX(4, 3, false, 64) ADDK_C3BX(4, 3, true, 64)
 #undef ADDK_C3B
+#undef ADDK_C3BX
 #undef ADDK_C3B_
   if (!done) { addk_set_error("conv3b: no instantiation for %d waves, %d taps", wc, pk.taps); return ADDK_ERR_UNSUPPORTED; }
   return addk_check_launch("conv3b");
