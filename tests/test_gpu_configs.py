@@ -175,7 +175,8 @@ def test_train_mode_gradient_spread_is_the_references_own(dev, hw):
     args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4), 0)
     crit = nn.CrossEntropyLoss(ignore_index=255)
     e32s, eas, coss, cos32 = [], [], [], []
-    for k in range(6):
+    ndraw = 4          # ~30 s each, almost all of it the oracle's fp64 pass
+    for k in range(ndraw):
         mo = oracle.ADD(*args)
         fill_params(mo, 600 + k)
         m64 = oracle.ADD(*args); m64.load_state_dict(mo.state_dict()); m64.double()
@@ -198,13 +199,13 @@ def test_train_mode_gradient_spread_is_the_references_own(dev, hw):
         for gx, acc in ((ga, coss), (grads['o32'], cos32)):
             acc.append(sum(float((gx[n] * g64[n]).sum()) for n in g64) / (den * sum(float((gx[n] ** 2).sum()) for n in g64) ** 0.5))
     med = lambda v: sorted(v)[len(v) // 2]
-    _log('train-mode gradient rel-L2 vs fp64 over 6 inputs at %s: fp32 oracle %s | addk %s | cos addk %s | cos fp32 oracle %s', hw,
+    _log('train-mode gradient rel-L2 vs fp64 over %d inputs at %s: fp32 oracle %s | addk %s | cos addk %s | cos fp32 oracle %s', ndraw, hw,
          ' '.join('%.2e' % v for v in e32s), ' '.join('%.2e' % v for v in eas), ' '.join('%.5f' % v for v in coss),
          ' '.join('%.5f' % v for v in cos32))
     assert med(eas) <= 2.0 * med(e32s), (eas, e32s)
     assert max(eas) <= 3.0 * max(e32s), (eas, e32s)
     # direction: as good as the fp32 oracle's own on every input (some weight draws are chaotic for the reference too:
-    # measured rel-L2 0.9 / cos 0.7 for BOTH on 2 of 6 draws), and >= 0.99 wherever the reference manages that
+    # measured rel-L2 0.9 / cos 0.7 for BOTH on 1 of the 4 draws, 2 of 6), and >= 0.99 wherever the reference manages that
     for ca, c32 in zip(coss, cos32):
         assert ca >= min(0.99, c32 - 0.05), (coss, cos32)
 
