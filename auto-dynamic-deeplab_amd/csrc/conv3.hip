@@ -658,7 +658,6 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
 
 // 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 3..5 that pads the channel count least (ties: the wider)
 int c3b_wc(int Cn) {
-  { static int f = -1; if (f < 0) { const char* e = getenv("ADDK_C3B_FORCEWC"); f = e ? atoi(e) : 0; } if (f && Cn <= 64) return f; }   // experiment knob
   if (Cn <= 64) return 2;                 // two channel tiles; the launch adds the two pixel halves (4 waves, conv3b_kernel PH = 2)
   int best = 4; long bc = -1;
   const int cands[3] = {5, 4, 3};
