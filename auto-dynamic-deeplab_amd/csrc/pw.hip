@@ -45,7 +45,7 @@ struct PwK {
 // neighbouring lanes share them), zero padding after the prologue as in the reference; tap weights sit in LDS as [tap][channel].
 // No barrier in the main loop and no round trip of the depthwise output through HBM (operations.py:51-53: ReLU, dw, pw in one launch).
 template <int CT, int KG, int MODE, bool RED32, int SEP = 0>     // CT column tiles of 16, KG groups of 16 reduction channels
-__device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2], const float* dwl = nullptr) {
+__device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2], const float* dwl = nullptr, float* patch = nullptr, const float* abl = nullptr) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.y * (CT * 16);
@@ -110,44 +110,82 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
       x[g] = v;
     }
   };
-  auto load_tile_sep = [&](int tile, float4 (&x)[KG]) {
-    constexpr int HK = SEP / 2;
-    const int pp = tile * 16 + li;
-    const bool pin = pp < p.P;
-    const int hw = p.H * p.W;
-    const int n = pp / hw, rem = pp - n * hw;
-    const int oh = rem / p.W, ow = rem - oh * p.W;
-#pragma unroll
-    for (int g = 0; g < KG; ++g) x[g] = zero4();
+  // Fused SepConv half, LDS-tiled: the block owns 64 consecutive pixels of one image row; it stages the haloed input patch
+  // [SEP rows][64 + SEP - 1 px][channels] once (all loads independent, BatchNorm/ReLU applied on the way in, zero padding
+  // after it), and every lane then builds its B fragment — the depthwise output of (pixel 16 wave + li, channels 16g + 4kq ..)
+  // — from SEP*SEP 16-byte LDS reads per group.  The pixel stride KP = 16 KG + 4 floats makes the 16 pixel lanes of a
+  // fragment read hit 16 distinct 4-bank groups (52 and 84 are = 4 * odd mod 64).
+  constexpr int SEPX = SEP ? SEP : 1, PWX = 64 + SEPX - 1, KP = KG * 16 + 4, KQ = KG * 4;
+  constexpr int NSLOT = (SEPX * PWX * KQ + 255) / 256;
+  auto stage_patch = [&](int n, int oh, int ow0) {
+    constexpr int HK = SEPX / 2;
+    constexpr int NB = 8;                                               // independent loads per thread in flight
 #pragma unroll 1
-    for (int kh = 0; kh < SEP; ++kh)              // one patch row (SEP x KG independent 16-byte loads) in flight at a time
+    for (int b0 = 0; b0 < NSLOT; b0 += NB) {
+      float4 rv[NB];
+      unsigned okm = 0;
 #pragma unroll
-      for (int kw = 0; kw < SEP; ++kw) {
-        const int ih = oh - HK + kh, iw = ow - HK + kw;
-        const bool sp = pin && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        const long off = sp ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0;
-#pragma unroll
-        for (int g = 0; g < KG; ++g) {
-          const int k = 16 * g + 4 * kq;
-          const bool ok = sp && k < p.K;
-          float4 v = ld4(p.src.x + (ok ? off + k : 0));
-          if (pro) {
-            v.x = fmaf(pa[g].x, v.x, pb[g].x); v.y = fmaf(pa[g].y, v.y, pb[g].y); v.z = fmaf(pa[g].z, v.z, pb[g].z); v.w = fmaf(pa[g].w, v.w, pb[g].w);
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          }
-          v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-          const float4 w4 = *reinterpret_cast<const float4*>(dwl + (kh * SEP + kw) * (KG * 16) + k);
-          x[g].x = fmaf(w4.x, v.x, x[g].x); x[g].y = fmaf(w4.y, v.y, x[g].y); x[g].z = fmaf(w4.z, v.z, x[g].z); x[g].w = fmaf(w4.w, v.w, x[g].w);
-        }
+      for (int u = 0; u < NB; ++u) {
+        const int slot = t + 256 * (b0 + u);
+        const int r = slot / (PWX * KQ), rem = slot - r * (PWX * KQ), px = rem / KQ, q = rem - px * KQ;
+        const int ih = oh - HK + r, iw = ow0 - HK + px;
+        const bool ok = b0 + u < NSLOT && r < SEPX && 4 * q < p.K && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        okm |= (ok ? 1u : 0u) << u;
+        rv[u] = ld4(p.src.x + (ok ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + 4 * q : 0));
       }
-    if (p.t && pin) {
 #pragma unroll
-      for (int g = 0; g < KG; ++g) { const int k = 16 * g + 4 * kq; if (k < p.K) st4(p.t + (long)pp * p.ldt + k, x[g]); }
+      for (int u = 0; u < NB; ++u) {
+        const int slot = t + 256 * (b0 + u);
+        const int r = slot / (PWX * KQ), rem = slot - r * (PWX * KQ), px = rem / KQ, q = rem - px * KQ;
+        float4 v = rv[u];
+        if (pro) {
+          const float4 av = lds_ld4(abl + 4 * q), bv = lds_ld4(abl + KG * 16 + 4 * q);
+          v.x = fmaf(av.x, v.x, bv.x); v.y = fmaf(av.y, v.y, bv.y); v.z = fmaf(av.z, v.z, bv.z); v.w = fmaf(av.w, v.w, bv.w);
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        const bool ok = (okm >> u) & 1u;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        if (b0 + u < NSLOT && r < SEPX) lds_st4(patch + (r * PWX + px) * KP + 4 * q, v);
+      }
     }
   };
-  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles16; tile += wstride) {
-    if (SEP) { load_tile_sep(tile, xf); if (KG <= 3) load_panel(); } else load_tile(tile, xf);
-    const int pp = tile * 16 + li;
+  auto dw_from_patch = [&](float4 (&x)[KG]) {
+    const float* pb0 = patch + (16 * wave + li) * KP + 4 * kq;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) x[g] = zero4();
+#pragma unroll
+    for (int kh = 0; kh < SEPX; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < SEPX; ++kw)
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+          const float4 v = lds_ld4(pb0 + (kh * PWX + kw) * KP + 16 * g);
+          const float4 w4 = lds_ld4(dwl + (kh * SEPX + kw) * (KG * 16) + 16 * g + 4 * kq);
+          x[g].x = fmaf(w4.x, v.x, x[g].x); x[g].y = fmaf(w4.y, v.y, x[g].y); x[g].z = fmaf(w4.z, v.z, x[g].z); x[g].w = fmaf(w4.w, v.w, x[g].w);
+        }
+  };
+  const int spr = SEP ? (p.W + 63) / 64 : 1;
+  for (int tile = SEP ? (int)blockIdx.x : blockIdx.x * 4 + wave; tile < p.ntiles16; tile += SEP ? p.gx : wstride) {
+    int pp; bool pin;
+    if (SEP) {            // tile = row segment (n, oh, 64 px): block-wide staging, then per-wave fragments
+      const int rowid = tile / spr, sx = tile - rowid * spr;
+      const int n = rowid / p.H, oh = rowid - n * p.H, ow = sx * 64 + 16 * wave + li;
+      if (tile != (int)blockIdx.x) __syncthreads();          // every wave is done with the previous segment's patch
+      if (KG <= 3 && tile == (int)blockIdx.x) load_panel();  // in the same round trip as the patch
+      stage_patch(n, oh, sx * 64);
+      __syncthreads();
+      dw_from_patch(xf);
+      pin = ow < p.W;
+      pp = rowid * p.W + ow;
+      if (p.t && pin) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) { const int k = 16 * g + 4 * kq; if (k < p.K) st4(p.t + (long)pp * p.ldt + k, xf[g]); }
+      }
+    } else {
+      load_tile(tile, xf);
+      pp = tile * 16 + li;
+      pin = pp < p.P;
+    }
     if (pro && !SEP) {
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
@@ -181,7 +219,7 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(wf[i][(SEP && KG > 3) ? 0 : g], e), get4(xf[g], e), acc[i], 0, 0, 0);
     }
     // ---- epilogue: lane holds channels n0 + i*16 + kq*4 + {0..3} of pixel pp ----
-    if (pp < p.P) {
+    if (pin) {
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
         const int c = n0 + i * 16 + kq * 4;
@@ -258,13 +296,21 @@ template <int CT, int KG, bool RED32, int SEP>
 __device__ __forceinline__ void sep_block(const PwK& p) {
   __shared__ double red[4][CT * 16][2];
   __shared__ __attribute__((aligned(16))) float dwl[SEP * SEP * KG * 16];      // depthwise tap weights [tap][channel], zero beyond K
+  __shared__ __attribute__((aligned(16))) float abl[2 * KG * 16];              // lazy-BatchNorm coefficients a | b of the input
+  extern __shared__ __attribute__((aligned(16))) float sep_patch[];            // [SEP][64 + SEP - 1][16 KG + 4]
   for (int i = threadIdx.x; i < SEP * SEP * KG * 16; i += 256) {
     const int tp = i / (KG * 16), c = i - tp * (KG * 16);
     dwl[i] = c < p.K ? ((const gfloat*)p.dww)[(long)c * (SEP * SEP) + tp] : 0.f;
   }
-  __syncthreads();
-  pw_body<CT, KG, PW_FWD, RED32, SEP>(p, red, dwl);
+  for (int i = threadIdx.x; i < KG * 16; i += 256) {
+    const bool ok = p.src.a != nullptr && i < p.K;
+    abl[i] = ok ? ((const gfloat*)p.src.a)[i] : 1.f;
+    abl[KG * 16 + i] = ok ? ((const gfloat*)p.src.b)[i] : 0.f;
+  }
+  __syncthreads();          // abl is read while the patch is staged
+  pw_body<CT, KG, PW_FWD, RED32, SEP>(p, red, dwl, sep_patch, abl);
 }
+constexpr size_t sep_lds(int kg, int sep) { return (size_t)sep * (64 + sep - 1) * (kg * 16 + 4) * 4; }
 template <int CT, int KG, bool RED32, int SEP>
 __global__ void __launch_bounds__(256, 2) sep_kernel(const PwK p) { sep_block<CT, KG, RED32, SEP>(p); }
 // the fused halves of one dependency level (the parallel branches of a cell) in ONE launch: block (x, 0, z) runs descriptor z
@@ -502,13 +548,13 @@ bool sep_fill(const addk_sep_args* a, PwK& k, PwCfg& c) {
   k.src = s; k.K = s.C; k.Cn = a->Cout; k.w = a->pw_w; k.ldw = a->ldw; k.w_off = 0;
   k.y = a->y; k.ldy = a->ldy; k.bias = nullptr;
   k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
-  k.P = a->N * a->H * a->W; k.ntiles16 = cdiv(k.P, 16);
+  k.P = a->N * a->H * a->W; k.ntiles16 = a->N * a->H * cdiv(a->W, 64);      // fused form: tiles are 64-pixel row segments
   k.dww = a->dw_w; k.H = a->H; k.W = a->W; k.t = a->t; k.ldt = a->ldt; k.ea = a->ea; k.eb = a->eb; k.nterm = a->nterm;
   for (int i = 0; i < a->nterm; ++i) k.term[i] = a->term[i];
   const int rows = addk_conv_rows(k.P, a->Cout);
   c.kg = kg; c.ct = kg; c.red32 = 1;          // one block covers every output channel: the depthwise part is computed once; per-lane statistics in fp32 (a lane sums a handful of values), fp64 across lanes and blocks
   k.rows = rows;
-  c.gx = rows; if (c.gx > cdiv(k.ntiles16, 4)) c.gx = cdiv(k.ntiles16, 4); if (c.gx < 1) c.gx = 1;
+  c.gx = rows; if (c.gx > k.ntiles16) c.gx = k.ntiles16; if (c.gx < 1) c.gx = 1;
   c.gy = 1; k.gx = c.gx; k.gy = 1;
   return true;
 }
@@ -517,8 +563,12 @@ template <bool BATCH>
 int sep_dispatch(int kg, int K, int red32, dim3 grid, hipStream_t st, const PwK* one, const PwK* tab) {
 #define ADDK_SEP(KG_, K_, R_) \
   if (kg == KG_ && K == K_ && (red32 != 0) == R_) { \
-    if (BATCH) hipLaunchKernelGGL((sep_batch_kernel<KG_, KG_, R_, K_>), grid, dim3(256), 0, st, tab); \
-    else hipLaunchKernelGGL((sep_kernel<KG_, KG_, R_, K_>), grid, dim3(256), 0, st, *one); \
+    static bool attr = false; \
+    if (!attr) { \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_batch_kernel<KG_, KG_, R_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_kernel<KG_, KG_, R_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384); attr = true; } \
+    if (BATCH) hipLaunchKernelGGL((sep_batch_kernel<KG_, KG_, R_, K_>), grid, dim3(256), sep_lds(KG_, K_), st, tab); \
+    else hipLaunchKernelGGL((sep_kernel<KG_, KG_, R_, K_>), grid, dim3(256), sep_lds(KG_, K_), st, *one); \
     return addk_check_launch("sep_fwd"); }
   ADDK_SEP(3, 3, true) ADDK_SEP(3, 5, true) ADDK_SEP(5, 3, true) ADDK_SEP(5, 5, true)
 #undef ADDK_SEP
