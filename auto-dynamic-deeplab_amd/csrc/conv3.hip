@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
 }
 
 // 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 3..5 that pads the channel count least (ties: the wider)
-int c3b_wc(int Cn) {
+int c3b_wc(int Cn, long P) {
   if (Cn <= 64) return 2;                 // two channel tiles; the launch adds the two pixel halves (4 waves, conv3b_kernel PH = 2)
   int best = 4; long bc = -1;
   const int cands[3] = {5, 4, 3};
@@ -668,6 +668,8 @@ int c3b_wc(int Cn) {
   // 5-wave blocks sit badly on 4 SIMDs (one block per CU at this register count, one SIMD with two waves): 4-wave blocks win
   // up to ~10 % more padded columns (ASPP data gradient, 400 channels: 4 x 128 instead of 3 x 160, 304 -> 200 us)
   if (best == 5 && (long)cdiv(Cn, 128) * 128 * 10 <= bc * 11) best = 4;
+  // small maps (160 channels at 32x64): two 3-wave column blocks on half-width tiles instead of one 5-wave block per row
+  if (best == 5 && P < 8192) best = 3;
   return best;
 }
 
@@ -706,7 +708,7 @@ int c3_bct(int Cn, long P) {
 }
 long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
   if (const int np = c3_planes(Cn, taps)) {            // bf16 planes: 1 KB per (tap, 32-row tile, plane)
-    const int wc = c3b_wc(Cn);
+    const int wc = c3b_wc(Cn, P);
     return (long)cdiv(Cn, 32 * wc) * nchunks * taps * wc * np * 256;
   }
   const int bct = c3_bct(Cn, P);
@@ -714,11 +716,15 @@ long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
 }
 bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn) {
   if (!c3_enabled() || KH != KW || !(KH == 3 || KH == 5) || stride != 1 || dil < 1 || dil > c3_maxdil(KH)) return false;
-  return pad == dil * (KH / 2) && OH == H && OW == W && W >= 100 && P >= 8192 && Cn >= 32;
+  if (!(pad == dil * (KH / 2) && OH == H && OW == W && Cn >= 32)) return false;
+  // the split kernel has half-width (64-pixel) tiles and also takes the 32x64 maps of level 3 (dil_conv at 160 channels: 152 us on
+  // the generic kernel); the fp32 halo kernel keeps its 128-pixel tiles and the larger maps
+  if (c3_planes(Cn, KH * KW)) return W >= 48 && P >= 2048;
+  return W >= 100 && P >= 8192;
 }
 
 int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
-  const int wc = c3b_wc(k.Cn);
+  const int wc = c3b_wc(k.Cn, k.P);
   pk.bct = wc; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = k.dil & 1;
   k.nT = pk.nchunks * pk.taps;
   k.wp = pk.out;
@@ -728,7 +734,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const int ph = wc == 2 ? 2 : 1;                                  // <= 64 channels: 4 waves = 2 channel tiles x 2 pixel halves
   // half-width tiles where 128-pixel tiles leave the chip short of blocks (instantiated for 3- and 4-wave blocks)
   const long blocks128 = (long)k.N * k.H * cdiv(k.W, C3_BP) * cdiv(k.Cn, 32 * wc);
-  const bool half = ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && blocks128 < 384 && c3b_half_enabled();
+  const bool half = ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && blocks128 < 384 && c3b_half_enabled();      // (rows of <= 64 pixels land here too)
   const int bpx = half ? 64 : C3_BP;
   k.spr = cdiv(k.W, bpx);
   k.ntiles = k.N * k.H * k.spr;
