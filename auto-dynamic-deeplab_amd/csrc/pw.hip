@@ -576,6 +576,91 @@ int sep_dispatch(int kg, int K, int red32, dim3 grid, hipStream_t st, const PwK*
   return ADDK_ERR_UNSUPPORTED;
 }
 
+
+// stem0 (ADD.py:153-157): 3x3 stride-2 convolution of the 3-channel image into 64 channels.  On the generic implicit-GEMM
+// kernel every tap was a 32-channel chunk with 3 live k slots (9 chunks, 18 barriers, 8x the matrix work: 0.38 ms = 0.85 TB/s on a
+// launch that moves 320 MB).  Here a tap is ONE k-step of v_mfma_f32_16x16x4_f32 — k = the pixel's 3 channels + a zero —
+// with all 9 x 4 weight fragments register-stationary: lane (li, kq) loads channel kq of its pixel's nine neighbours (independent
+// 4-byte loads, L1 hits: an input pixel is read by 2.25 outputs) and stores 16 bytes per output tile.  No LDS, no barrier.
+struct StemK {
+  const float* x; int ld; int N, H, W, OH, OW;
+  const float* w; int ldw;
+  float* y; int ldy;
+  double* slab; int slab_ld;
+  int P, ntiles16, rows, gx;
+};
+template <int CT, bool RED32>
+__global__ void __launch_bounds__(256) stem0_kernel(const StemK p) {
+  __shared__ double red[4][CT * 16][2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  float wf[CT][9];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      wf[i][tap] = kq < 3 ? ((const gfloat*)p.w)[(long)(i * 16 + li) * p.ldw + tap * 3 + kq] : 0.f;
+  typedef typename std::conditional<RED32, float, double>::type red_t;
+  red_t s1[CT][4], s2[CT][4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[i][e] = 0; s2[i][e] = 0; }
+  const int ohw = p.OH * p.OW;
+  const gfloat* xg = (const gfloat*)p.x;
+  for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles16; tile += p.gx * 4) {
+    const int pp = tile * 16 + li;
+    const bool pok = pp < p.P;
+    const int n = pp / ohw, rem = pp - n * ohw, oh = rem / p.OW, ow = rem - oh * p.OW;
+    float xv[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ih = 2 * oh - 1 + tap / 3, iw = 2 * ow - 1 + tap % 3;
+      const bool ok = pok && kq < 3 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const float v = xg[ok ? ((long)(n * p.H + ih) * p.W + iw) * p.ld + kq : 0];
+      xv[tap] = ok ? v : 0.f;
+    }
+    f32x4 acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int i = 0; i < CT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][tap], xv[tap], acc[i], 0, 0, 0);
+    if (pok) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        st4(p.y + (long)pp * p.ldy + i * 16 + kq * 4, v);
+        if (p.slab) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const red_t f = (red_t)get4(v, e); s1[i][e] += f; s2[i][e] += f * f; }
+        }
+      }
+    }
+  }
+  if (p.slab) {
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red_t a = s1[i][e], b = s2[i][e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (li == 0) { red[wave][i * 16 + kq * 4 + e][0] = (double)a; red[wave][i * 16 + kq * 4 + e][1] = (double)b; }
+      }
+    __syncthreads();
+    if (t < CT * 16) {
+      gdouble* o = (gdouble*)p.slab + ((long)blockIdx.x * p.slab_ld + t) * 2;
+      o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
+      o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
+      for (int r = blockIdx.x + p.gx; r < p.rows; r += p.gx) {     // rows no workgroup owns
+        gdouble* z = (gdouble*)p.slab + ((long)r * p.slab_ld + t) * 2;
+        z[0] = 0.0; z[1] = 0.0;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Returns 0 when the launch was taken, 1 when the shape is not covered (caller falls back), <0 on error.
@@ -607,7 +692,27 @@ static int pwk_try_fwd(const addk_conv_args* a, int rows, hipStream_t st) {
   return 1;
 }
 
+
+// stem0: 3 input channels (pixel stride 4), 3x3, stride 2, pad 1, 64 output channels, no prologue / bias
+static int stem0_try_fwd(const addk_conv_args* a, int rows, hipStream_t st) {
+  if (a->nsrc != 1 || a->KH != 3 || a->KW != 3 || a->stride != 2 || a->pad != 1 || a->dil != 1 || a->bias || a->bias_n) return 1;
+  const addk_src& s = a->src[0];
+  if (s.C != 3 || s.ld < 3 || s.a || s.b || s.relu || a->Cout != 64 || a->cin_total != 3 || a->w_choff != 0) return 1;
+  if (!aligned16(a->y) || a->ldy % 4 || a->ldy < 64) return 1;
+  if (a->OH != (a->H + 2 - 3) / 2 + 1 || a->OW != (a->W + 2 - 3) / 2 + 1) return 1;
+  StemK k{};
+  k.x = s.x; k.ld = s.ld; k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
+  k.w = a->w; k.ldw = a->ldw; k.y = a->y; k.ldy = a->ldy;
+  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.P = a->N * a->OH * a->OW; k.ntiles16 = cdiv(k.P, 16); k.rows = rows;
+  k.gx = rows; if (k.gx > cdiv(k.ntiles16, 4)) k.gx = cdiv(k.ntiles16, 4); if (k.gx < 1) k.gx = 1;
+  if (k.P >= 4096) hipLaunchKernelGGL((stem0_kernel<4, true>), dim3(k.gx), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((stem0_kernel<4, false>), dim3(k.gx), dim3(256), 0, st, k);
+  return addk_check_launch("stem0");
+}
+
 int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream) {
+  { const int r = stem0_try_fwd(a, rows, (hipStream_t)stream); if (r <= 0) return r; }
   PwK k;
   if (pw_fill_fwd(a, k)) {
     const int r = pw_launch<PW_FWD>(k, rows, (hipStream_t)stream);
