@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CB_PT = 4;                   // 32-pixel tiles per wave (128 pixels)
-constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP) { return ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
+constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP) { return ks == 1 ? bpx : ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
 
 __device__ __forceinline__ unsigned bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b << 16); }
@@ -674,6 +674,7 @@ int c3b_wc(int Cn, long P) {
 }
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
+inline bool c3b_pointwise_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_POINTWISE"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 inline bool c3b_half_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_HALF"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 // bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  Every halo launch takes the
 // split kernel, the <= 64-channel ones (stem1, the cells' 40-channel dilated convs) on 4-wave blocks = 2 channel tiles x 2
@@ -715,6 +716,10 @@ long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
   return (long)cdiv(Cn, 16 * bct) * nchunks * taps * bct * 256;
 }
 bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn) {
+  if (KH == 1 && KW == 1) {      // wide pointwise heads (ASPP 1x1, the 1280 -> 256 concat conv): the split kernel as a plain GEMM (KS = 1)
+    return c3_enabled() && c3b_pointwise_enabled() && stride == 1 && dil == 1 && pad == 0 && OH == H && OW == W && Cn >= 192 && c3_planes(Cn, 1) != 0 &&
+           W >= 48 && P >= 2048;
+  }
   if (!c3_enabled() || KH != KW || !(KH == 3 || KH == 5) || stride != 1 || dil < 1 || dil > c3_maxdil(KH)) return false;
   if (!(pad == dil * (KH / 2) && OH == H && OW == W && Cn >= 32)) return false;
   // the split kernel has half-width (64-pixel) tiles and also takes the 32x64 maps of level 3 (dil_conv at 160 channels: 152 us on
@@ -730,11 +735,11 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   k.wp = pk.out;
   k.wp_blk = (long)pk.nchunks * pk.taps * wc * np * 64;          // 16-byte units per column block
   const bool bigd = pk.taps == 9 && k.dil > 2;
-  const int ks = pk.taps == 9 ? 3 : 5;
+  const int ks = pk.taps == 1 ? 1 : pk.taps == 9 ? 3 : 5;
   const int ph = wc == 2 ? 2 : 1;                                  // <= 64 channels: 4 waves = 2 channel tiles x 2 pixel halves
   // half-width tiles where 128-pixel tiles leave the chip short of blocks (instantiated for 3- and 4-wave blocks)
   const long blocks128 = (long)k.N * k.H * cdiv(k.W, C3_BP) * cdiv(k.Cn, 32 * wc);
-  const bool half = ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && blocks128 < 384 && c3b_half_enabled();      // (rows of <= 64 pixels land here too)
+  const bool half = ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && !(wc == 3 && ks == 1) && blocks128 < 384 && c3b_half_enabled();      // (rows of <= 64 pixels land here too)
   const int bpx = half ? 64 : C3_BP;
   k.spr = cdiv(k.W, bpx);
   k.ntiles = k.N * k.H * k.spr;
@@ -760,6 +765,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   ADDK_C3B(3, 3, true) ADDK_C3B(4, 3, true) ADDK_C3B(5, 3, true) ADDK_C3B(2, 3, true)
   ADDK_C3B(2, 5, false) ADDK_C3B(3, 5, false) ADDK_C3B(4, 5, false) ADDK_C3B(5, 5, false)
   ADDK_C3BX(3, 3, false, 64) ADDK_C3BX(3, 5, false, 64) ADDK_C3BX(4, 3, false, 64) ADDK_C3BX(4, 3, true, 64)
+  ADDK_C3B(4, 1, false) ADDK_C3B(3, 1, false) ADDK_C3B(5, 1, false) ADDK_C3BX(4, 1, false, 64)
 #undef ADDK_C3B
 #undef ADDK_C3BX
 #undef ADDK_C3B_
