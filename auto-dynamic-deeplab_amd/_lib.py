@@ -78,7 +78,7 @@ class BnEvalEntry(C.Structure):
 class BnBwdArgs(C.Structure):
     _fields_ = [('slab', vp * MAX_SLAB), ('rows', i32 * MAX_SLAB), ('nslab', i32), ('C', i32), ('count', f64),
                 ('gamma', vp), ('mean', vp), ('invstd', vp), ('a', vp), ('dgamma', vp), ('dbeta', vp),
-                ('accumulate', i32), ('c1', vp), ('c2', vp), ('dmv', vp)]
+                ('accumulate', i32), ('c1', vp), ('c2', vp), ('dmv', vp), ('centered', i32), ('_pad', i32)]
 
 
 class SlabReduceItem(C.Structure):
@@ -90,7 +90,7 @@ class BnCoeffsItem(C.Structure):
 
 
 class BnApplyItem(C.Structure):
-    _fields_ = [('g', vp), ('x', vp), ('c1', vp), ('c2', vp), ('out', vp), ('P', i64), ('ldg', i32), ('ldx', i32), ('ldo', i32),
+    _fields_ = [('g', vp), ('x', vp), ('c1', vp), ('c2', vp), ('mean', vp), ('out', vp), ('P', i64), ('ldg', i32), ('ldx', i32), ('ldo', i32),
                 ('C', i32)]
 
 

@@ -124,7 +124,7 @@ __device__ __forceinline__ void bn_bwd_body(const addk_bn_bwd_args& p, double (*
     double t = dA - mean * dB;
     double dgamma = invstd * t, dbeta = dB;
     double dvar = -0.5 * gamma * t * invstd * invstd * invstd;
-    double dmean_tot = -a * dB - 2.0 * mean * dvar;
+    double dmean_tot = -a * dB - (p.centered ? 0.0 : 2.0 * mean * dvar);
     if (p.dgamma) p.dgamma[c] = (float)((p.accumulate ? (double)p.dgamma[c] : 0.0) + dgamma);
     if (p.dbeta) p.dbeta[c] = (float)((p.accumulate ? (double)p.dbeta[c] : 0.0) + dbeta);
     if (p.dmv) { p.dmv[2 * c] = (float)dmean_tot; p.dmv[2 * c + 1] = (float)dvar; }

@@ -2,7 +2,7 @@
 //   affine_sum      — the branch sum of a cell block (ADD.py:108) with the branches' BatchNorms applied on
 //                     the fly, written into the block's slot of the cell concat buffer (ADD.py:112)
 //   affine_sum_bwd  — its gradient + the per-channel sums that drive the branches' BN backward
-//   bn_bwd_apply    — dy = alpha*g + c1 + c2*x (training-mode BatchNorm backward on the raw conv output)
+//   bn_bwd_apply    — dy = g + c1 + c2*(x - mean) (training-mode BatchNorm backward on the raw conv output)
 //   sgd_step, fill
 #include "common.h"
 
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
 }
 
 // vector-aligned form: every load is a plain 16-byte load issued up front (coefficients and data are one round trip)
-__global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* g, int ldg, const float* x, int ldx, const float* alpha,
+__global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* g, int ldg, const float* x, int ldx, const float* mean,
                                                                const float* c1, const float* c2, long P, float* out, int ldo,
                                                                int nq, int npl) {
   const int q = threadIdx.x % nq, pl = threadIdx.x / nq;
@@ -124,22 +124,22 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* g, i
   if (pp0 >= P) return;
   float4 gv = ld4(g + pp0 * ldg + c);
   float4 xv = c2 ? ld4(x + pp0 * ldx + c) : zero4();
-  const float4 al = alpha ? ld4(alpha + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 mu = mean ? ld4(mean + c) : zero4();
   const float4 k1 = c1 ? ld4(c1 + c) : zero4();
   const float4 k2 = c2 ? ld4(c2 + c) : zero4();
   for (long pp = pp0;;) {
     const long nx = pp + (long)gridDim.x * npl;
     float4 gn = zero4(), xn = zero4();
     if (nx < P) { gn = ld4(g + nx * ldg + c); if (c2) xn = ld4(x + nx * ldx + c); }
-    st4(out + pp * ldo + c, make_float4(fmaf(al.x, gv.x, fmaf(k2.x, xv.x, k1.x)), fmaf(al.y, gv.y, fmaf(k2.y, xv.y, k1.y)),
-                                        fmaf(al.z, gv.z, fmaf(k2.z, xv.z, k1.z)), fmaf(al.w, gv.w, fmaf(k2.w, xv.w, k1.w))));
+    st4(out + pp * ldo + c, make_float4(gv.x + fmaf(k2.x, xv.x - mu.x, k1.x), gv.y + fmaf(k2.y, xv.y - mu.y, k1.y),
+                                        gv.z + fmaf(k2.z, xv.z - mu.z, k1.z), gv.w + fmaf(k2.w, xv.w - mu.w, k1.w)));
     if (nx >= P) break;
     pp = nx; gv = gn; xv = xn;
   }
 }
 
 // several independent tensors in one launch (vector-aligned items only): block (x, y) strides over the pixels of item y
-struct BnApplyItem { const float* g; const float* x; const float* c1; const float* c2; float* out; long P; int ldg, ldx, ldo, C; };
+struct BnApplyItem { const float* g; const float* x; const float* c1; const float* c2; const float* mean; float* out; long P; int ldg, ldx, ldo, C; };
 __global__ void __launch_bounds__(256) bn_bwd_apply_batch_kernel(const BnApplyItem* __restrict__ tab) {
   const BnApplyItem it = tab[blockIdx.y];
   const int nq = it.C >> 2, npl = 256 / nq;
@@ -149,33 +149,34 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_batch_kernel(const BnApplyIt
   long pp = (long)blockIdx.x * npl + pl;
   if (pp >= it.P) return;
   const float4 k1 = ld4(it.c1 + c), k2 = ld4(it.c2 + c);
+  const float4 mu = it.mean ? ld4(it.mean + c) : zero4();
   const long step = (long)gridDim.x * npl;
   float4 gv = ld4(it.g + pp * it.ldg + c), xv = ld4(it.x + pp * it.ldx + c);
   for (;;) {
     const long nx = pp + step;
     float4 gn = zero4(), xn = zero4();
     if (nx < it.P) { gn = ld4(it.g + nx * it.ldg + c); xn = ld4(it.x + nx * it.ldx + c); }
-    st4(it.out + pp * it.ldo + c, make_float4(gv.x + fmaf(k2.x, xv.x, k1.x), gv.y + fmaf(k2.y, xv.y, k1.y),
-                                              gv.z + fmaf(k2.z, xv.z, k1.z), gv.w + fmaf(k2.w, xv.w, k1.w)));
+    st4(it.out + pp * it.ldo + c, make_float4(gv.x + fmaf(k2.x, xv.x - mu.x, k1.x), gv.y + fmaf(k2.y, xv.y - mu.y, k1.y),
+                                              gv.z + fmaf(k2.z, xv.z - mu.z, k1.z), gv.w + fmaf(k2.w, xv.w - mu.w, k1.w)));
     if (nx >= it.P) break;
     pp = nx; gv = gn; xv = xn;
   }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* g, int ldg, const float* x, int ldx, const float* alpha,
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* g, int ldg, const float* x, int ldx, const float* mean,
                                                            const float* c1, const float* c2, long P, int C, float* out, int ldo,
                                                            int nq, int npl, int vec) {
   const int q = threadIdx.x % nq, pl = threadIdx.x / nq;
   if (pl >= npl) return;
   const int c = 4 * q, nrem = C - c;
-  float4 al = alpha ? ld4g(alpha + c, nrem, vec) : make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 mu = mean ? ld4g(mean + c, nrem, vec) : zero4();
   float4 k1 = c1 ? ld4g(c1 + c, nrem, vec) : zero4();
   float4 k2 = c2 ? ld4g(c2 + c, nrem, vec) : zero4();
   for (long pp = (long)blockIdx.x * npl + pl; pp < P; pp += (long)gridDim.x * npl) {
     float4 gv = ld4g(g + pp * ldg + c, nrem, vec);
     float4 xv = c2 ? ld4g(x + pp * ldx + c, nrem, vec) : zero4();
-    float4 o = make_float4(fmaf(al.x, gv.x, fmaf(k2.x, xv.x, k1.x)), fmaf(al.y, gv.y, fmaf(k2.y, xv.y, k1.y)),
-                           fmaf(al.z, gv.z, fmaf(k2.z, xv.z, k1.z)), fmaf(al.w, gv.w, fmaf(k2.w, xv.w, k1.w)));
+    float4 o = make_float4(gv.x + fmaf(k2.x, xv.x - mu.x, k1.x), gv.y + fmaf(k2.y, xv.y - mu.y, k1.y),
+                           gv.z + fmaf(k2.z, xv.z - mu.z, k1.z), gv.w + fmaf(k2.w, xv.w - mu.w, k1.w));
     st4g(out + pp * ldo + c, o, nrem, vec);
   }
 }
@@ -250,19 +251,19 @@ extern "C" int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stre
   return addk_check_launch("affine_sum_bwd");
 }
 
-extern "C" int addk_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* alpha, const float* c1,
+extern "C" int addk_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* mean, const float* c1,
                                  const float* c2, int64_t P, int32_t C, float* out, int32_t ldo, void* stream) {
   ADDK_REQUIRE(g && out && P > 0 && C > 0 && C <= 1024 && ldg >= C && ldo >= C && (!c2 || (x && ldx >= C)), "bn_bwd_apply: bad args");
   ADDK_REQUIRE((c1 == nullptr) == (c2 == nullptr), "bn_bwd_apply: c1/c2 come together");
   int vec = aligned16(g) && aligned16(out) && ldg % 4 == 0 && ldo % 4 == 0 && C % 4 == 0 && (!x || (aligned16(x) && ldx % 4 == 0)) &&
-            (!alpha || aligned16(alpha)) && (!c1 || (aligned16(c1) && aligned16(c2)));
+            (!mean || aligned16(mean)) && (!c1 || (aligned16(c1) && aligned16(c2)));
   EwMap m = ew_map(C);
   if (vec && C == m.nq * 4) {
-    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(ew_blocks(P, m.npl)), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, alpha, c1, c2,
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(ew_blocks(P, m.npl)), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, mean, c1, c2,
                        (long)P, out, ldo, m.nq, m.npl);
     return addk_check_launch("bn_bwd_apply");
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, m.npl)), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, alpha, c1, c2,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(P, m.npl)), dim3(256), 0, (hipStream_t)stream, g, ldg, x, ldx, mean, c1, c2,
                      (long)P, C, out, ldo, m.nq, m.npl, vec);
   return addk_check_launch("bn_bwd_apply");
 }
@@ -285,7 +286,7 @@ extern "C" int addk_sgd_step(float* p, const float* g, float* buf, int64_t n, co
 }
 
 // table entries as addk_bn_apply_item (include/addk.h); every item must be vector-aligned (16-byte pointers, ld % 4 == 0,
-// C % 4 == 0, C <= 1024) with alpha = NULL and c1, c2 given
+// C % 4 == 0, C <= 1024) with c1, c2 given (mean optional)
 extern "C" int addk_bn_bwd_apply_batch(const addk_bn_apply_item* dev_table, int32_t n, int64_t max_P, void* stream) {
   ADDK_REQUIRE(dev_table && n > 0 && max_P > 0, "bn_bwd_apply_batch: bad args");
   static_assert(sizeof(addk_bn_apply_item) == sizeof(BnApplyItem), "item layout");

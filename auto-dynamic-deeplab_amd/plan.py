@@ -844,6 +844,11 @@ class Graph:
                 for i, (p, r) in enumerate(st.slabs):
                     ba.slab[i], ba.rows[i] = p.ptr, r
                 ba.nslab, ba.C, ba.count = len(st.slabs), Cc, st.count
+                # dy_raw = G + c1 + c2*(x - mean): the mean is subtracted first, as the reference does (batchnorm.py:51-53), instead
+                # of folding -c2*mean into c1 where it cancels against c2*x (ADDK_BN_CENTERED=0 restores the folded form)
+                centered = os.environ.get('ADDK_BN_CENTERED', '1') == '1'
+                ba.centered = int(centered)
+                mu = st.mean if centered else None
                 ba.gamma, ba.mean, ba.invstd, ba.a = gam, st.mean.ptr, st.invstd.ptr, a.ptr
                 if mod.weight is not None:
                     gp, acc = self.param_grad(mod.weight)
@@ -872,11 +877,12 @@ class Graph:
                     ba.c1, ba.c2 = c1.ptr, c2.ptr
                     self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2]).payload = ba
                 # dy_raw = G + c1 + c2*x, in place on the accumulated gradient
-                cap = self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, None, c1.ptr, c2.ptr,
-                                raw.P, Cc, g.ptr, g.ld, rd=[g, raw, c1, c2], wr=[g])
+                cap = self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, mu.ptr if mu else None,
+                                c1.ptr, c2.ptr, raw.P, Cc, g.ptr, g.ld, rd=[g, raw, c1, c2, mu], wr=[g])
                 if Cc % 4 == 0 and Cc <= 1024 and g.ld % 4 == 0 and raw.ld % 4 == 0 and g.ptr % 16 == 0 and raw.ptr % 16 == 0:
                     it = L.BnApplyItem()
                     it.g, it.x, it.c1, it.c2, it.out, it.P = g.ptr, raw.ptr, c1.ptr, c2.ptr, g.ptr, raw.P
+                    it.mean = mu.ptr if mu else None
                     it.ldg, it.ldx, it.ldo, it.C = g.ld, raw.ld, g.ld, Cc
                     cap.payload = it
             self._bwd_emitters.append(emit_bwd)

@@ -292,6 +292,7 @@ typedef struct addk_bn_bwd_args {
   float* dgamma; float* dbeta; int32_t accumulate;
   float* c1; float* c2;          /* out (NULL when dmv is used) */
   float* dmv;                    /* out [C][2] (dmean_tot, dvar) or NULL */
+  int32_t centered; int32_t _pad; /* 1: c1 (dmv[0]) leaves out the -2*mean*dvar part: the consumer applies c2*(x - mean) */
 } addk_bn_bwd_args;
 int addk_bn_bwd(const addk_bn_bwd_args* a, void* stream);
 int addk_bn_bwd_batch(const addk_bn_bwd_args* dev_table, int32_t n, int32_t max_C, void* stream);
@@ -323,15 +324,16 @@ typedef struct addk_affine_sum_bwd_args {
 int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stream);
 int addk_ew_rows(int64_t P, int32_t C);
 
-/* dy[p,c] = alpha[c]*g[p,c] + c1[c] + c2[c]*x[p,c]   (BN backward applied to the accumulated gradient;
- * alpha/c1/c2 may be NULL = 1/0/0).  out may alias g. */
-int addk_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* alpha,
+/* dy[p,c] = g[p,c] + c1[c] + c2[c]*(x[p,c] - mean[c])   (BN backward applied to the accumulated gradient;
+ * mean/c1/c2 may be NULL = 0).  The centred form (addk_bn_bwd_args.centered) keeps c2*x from cancelling against a c1 that
+ * carries -c2*mean: the reference subtracts the mean first (batchnorm.py:51-53 / ATen batch_norm_backward).  out may alias g. */
+int addk_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* mean,
                       const float* c1, const float* c2, int64_t P, int32_t C, float* out, int32_t ldo,
                       void* stream);
 /* the same for n independent tensors in one launch (vector-aligned items only: 16-byte pointers, ld % 4 == 0, C % 4 == 0;
- * alpha = 1): out[p,c] = g[p,c] + c1[c] + c2[c]*x[p,c] */
+ * out[p,c] = g[p,c] + c1[c] + c2[c]*(x[p,c] - mean[c]), mean may be NULL */
 typedef struct addk_bn_apply_item {
-  const float* g; const float* x; const float* c1; const float* c2; float* out; int64_t P; int32_t ldg, ldx, ldo, C;
+  const float* g; const float* x; const float* c1; const float* c2; const float* mean; float* out; int64_t P; int32_t ldg, ldx, ldo, C;
 } addk_bn_apply_item;
 int addk_bn_bwd_apply_batch(const addk_bn_apply_item* dev_table, int32_t n, int64_t max_P, void* stream);
 

@@ -1,9 +1,10 @@
 """Shared helpers for tests and for tests/golden/make_golden.py (no reference code here)."""
-import zlib
 from types import SimpleNamespace
 
 import numpy as np
 import torch
+
+import addk  # noqa: F401  (registers the package that lives in ./auto-dynamic-deeplab_amd/)
 
 GENOTYPE_AUTODEEPLAB = np.array(  # searched_arch/autodeeplab/genotype.npy (data; unsorted rows 8,9 — SURVEY Q1)
     [[0, 7], [1, 4], [2, 4], [3, 6], [5, 4], [8, 4], [11, 5], [13, 5], [19, 7], [18, 5]], dtype=np.int64)
@@ -21,41 +22,7 @@ def make_args(F=20, B=5, sync_bn=False):
     return SimpleNamespace(F=F, B=B, sync_bn=sync_bn)
 
 
-def _rng(seed, name):
-    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
-
-
-def rand_tensor(seed, name, shape, scale=1.0):
-    return torch.from_numpy((_rng(seed, name).standard_normal(shape) * scale).astype(np.float32))
-
-
-@torch.no_grad()
-def fill_params(module, seed):
-    """Deterministic, RNG-order-independent parameter fill keyed on state_dict names.
-    Conv weights ~ N(0, 2/fan_in) (kaiming scale), BN gamma ~ 1+0.2N, beta ~ 0.2N,
-    running_mean ~ 0.3N, running_var ~ U(0.5,1.5).  Returns a float64 checksum."""
-    chk = 0.0
-    for name, t in module.state_dict().items():
-        if name.endswith('num_batches_tracked'):
-            t.zero_()
-            continue
-        r = _rng(seed, name)
-        shp = tuple(t.shape)
-        if name.endswith('running_var'):
-            v = 0.5 + r.random(shp)
-        elif name.endswith('running_mean'):
-            v = 0.3 * r.standard_normal(shp)
-        elif t.dim() == 1 and name.endswith('weight'):
-            v = 1.0 + 0.2 * r.standard_normal(shp)
-        elif t.dim() == 1:
-            v = 0.2 * r.standard_normal(shp)
-        else:
-            fan_in = int(np.prod(shp[1:]))
-            v = r.standard_normal(shp) * np.sqrt(2.0 / fan_in)
-        v = v.astype(np.float32)
-        t.copy_(torch.from_numpy(v).reshape(shp))
-        chk += float(np.abs(v.astype(np.float64)).sum())
-    return chk
+from addk.synth import _rng, fill_params, rand_tensor     # noqa: E402,F401  (the product's own synthetic-data helpers)
 
 
 def probe_weights(seed, name, shape):

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, '..'))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
 sys.path.insert(0, '/root/reference')
 
 from _util import (ARCH_C2, ARCH_C3, ARCH_C4, GENOTYPE_AUTODEEPLAB, GENOTYPE_BASELINE_2, GENOTYPE_40_1,  # noqa: E402
