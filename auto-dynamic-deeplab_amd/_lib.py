@@ -38,10 +38,16 @@ class ConvWgradArgs(C.Structure):
                 ('ldw', i32), ('cin_total', i32), ('w_choff', i32), ('accumulate', i32), ('ws', vp), ('ws_floats', i64)]
 
 
+class BnFinalizeArgs(C.Structure):
+    _fields_ = [('partial', vp), ('rows', i32), ('C', i32), ('count', f64), ('gamma', vp), ('beta', vp),
+                ('running_mean', vp), ('running_var', vp), ('momentum', f32), ('eps', f32), ('a', vp), ('b', vp),
+                ('mean', vp), ('invstd', vp)]
+
+
 class SepArgs(C.Structure):
     _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('Cout', i32), ('ldw', i32), ('dw_w', vp), ('pw_w', vp),
-                ('y', vp), ('ldy', i32), ('ldt', i32), ('t', vp), ('stats', vp), ('stats_ld', i32), ('nterm', i32), ('ea', vp), ('eb', vp),
-                ('term', Src * MAX_TERMS)]
+                ('y', vp), ('ldy', i32), ('ldt', i32), ('t', vp), ('stats', vp), ('stats_ld', i32), ('stats_rows', i32), ('nterm', i32), ('ea', vp), ('eb', vp),
+                ('term', Src * MAX_TERMS), ('fin', BnFinalizeArgs), ('fin_counter', vp)]
 
 
 class CeUpsampleArgs(C.Structure):
@@ -63,12 +69,6 @@ class DwBwdArgs(C.Structure):
 
 class DwWreduceItem(C.Structure):
     _fields_ = [('ws', vp), ('dw', vp), ('rows', i32), ('n', i32), ('accumulate', i32), ('_pad', i32)]
-
-
-class BnFinalizeArgs(C.Structure):
-    _fields_ = [('partial', vp), ('rows', i32), ('C', i32), ('count', f64), ('gamma', vp), ('beta', vp),
-                ('running_mean', vp), ('running_var', vp), ('momentum', f32), ('eps', f32), ('a', vp), ('b', vp),
-                ('mean', vp), ('invstd', vp)]
 
 
 class BnEvalEntry(C.Structure):
@@ -148,6 +148,7 @@ _SIGS = {
     'addk_nearest_u8': (i32, [vp, i32, i32, vp, i32, i32, vp, vp, i32, vp]),
     'addk_finish_sample': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'addk_sep_fwd_supported': (i32, [C.POINTER(SepArgs)]),
+    'addk_sep_rows': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_fwd': (i32, [C.POINTER(SepArgs), vp]),
     'addk_sep_fwd_batch_key': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_fwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),

@@ -292,35 +292,6 @@ __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p)
   __shared__ double red[4][CT * 16][2];
   pw_body<CT, KG, MODE, RED32>(p, red);
 }
-template <int CT, int KG, bool RED32, int SEP>
-__device__ __forceinline__ void sep_block(const PwK& p) {
-  __shared__ double red[4][CT * 16][2];
-  __shared__ __attribute__((aligned(16))) float dwl[SEP * SEP * KG * 16];      // depthwise tap weights [tap][channel], zero beyond K
-  __shared__ __attribute__((aligned(16))) float abl[2 * KG * 16];              // lazy-BatchNorm coefficients a | b of the input
-  extern __shared__ __attribute__((aligned(16))) float sep_patch[];            // [SEP][64 + SEP - 1][16 KG + 4]
-  for (int i = threadIdx.x; i < SEP * SEP * KG * 16; i += 256) {
-    const int tp = i / (KG * 16), c = i - tp * (KG * 16);
-    dwl[i] = c < p.K ? ((const gfloat*)p.dww)[(long)c * (SEP * SEP) + tp] : 0.f;
-  }
-  for (int i = threadIdx.x; i < KG * 16; i += 256) {
-    const bool ok = p.src.a != nullptr && i < p.K;
-    abl[i] = ok ? ((const gfloat*)p.src.a)[i] : 1.f;
-    abl[KG * 16 + i] = ok ? ((const gfloat*)p.src.b)[i] : 0.f;
-  }
-  __syncthreads();          // abl is read while the patch is staged
-  pw_body<CT, KG, PW_FWD, RED32, SEP>(p, red, dwl, sep_patch, abl);
-}
-constexpr size_t sep_lds(int kg, int sep) { return (size_t)sep * (64 + sep - 1) * (kg * 16 + 4) * 4; }
-template <int CT, int KG, bool RED32, int SEP>
-__global__ void __launch_bounds__(256, 2) sep_kernel(const PwK p) { sep_block<CT, KG, RED32, SEP>(p); }
-// the fused halves of one dependency level (the parallel branches of a cell) in ONE launch: block (x, 0, z) runs descriptor z
-template <int CT, int KG, bool RED32, int SEP>
-__global__ void __launch_bounds__(256, 2) sep_batch_kernel(const PwK* __restrict__ tab) {
-  const PwK& p = tab[blockIdx.z];          // by reference: a local copy with its runtime-indexed term[] would live in scratch
-  if ((int)blockIdx.x >= p.gx) return;
-  sep_block<CT, KG, RED32, SEP>(p);
-}
-
 // several independent pointwise convs of one dependency level in ONE launch: block (x, y, z) runs descriptor z
 template <int CT, int KG, int MODE, bool RED32>
 __global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_batch_kernel(const PwK* __restrict__ tab) {
@@ -532,50 +503,6 @@ bool pw_fill_dgrad(const addk_conv_dgrad_args* a, PwK& k) {
 }
 inline int pw_key(const PwCfg& c, int mode) { return (mode << 12) | (c.ct << 8) | (c.kg << 4) | c.red32; }
 
-// ---- fused SepConv half ----
-bool sep_fill(const addk_sep_args* a, PwK& k, PwCfg& c) {
-  if (!a || !(a->K == 3 || a->K == 5) || a->N <= 0 || a->H <= 0 || a->W <= 0) return false;
-  const addk_src& s = a->src;
-  const int kg = cdiv(s.C, 16);
-  if (!(kg == 3 || kg == 5) || a->Cout != s.C || !s.x || !src_vec_ok(s) || !a->dw_w || !a->pw_w || !a->y) return false;
-  if (!aligned16(a->y) || a->ldy % 4 || a->ldy < a->Cout || !aligned16(a->pw_w) || a->ldw % 4 || a->ldw < s.C) return false;
-  if (a->t && (!aligned16(a->t) || a->ldt % 4 || a->ldt < s.C)) return false;
-  if (a->nterm < 0 || a->nterm > ADDK_MAX_TERMS || (a->ea == nullptr) != (a->eb == nullptr)) return false;
-  if ((a->nterm > 0 || a->ea) && a->stats) return false;               // the sum epilogue is an inference form
-  if (a->ea && (!aligned16(a->ea) || !aligned16(a->eb))) return false;
-  for (int i = 0; i < a->nterm; ++i) if (!a->term[i].x || a->term[i].C != a->Cout || !src_vec_ok(a->term[i])) return false;
-  k = PwK{};
-  k.src = s; k.K = s.C; k.Cn = a->Cout; k.w = a->pw_w; k.ldw = a->ldw; k.w_off = 0;
-  k.y = a->y; k.ldy = a->ldy; k.bias = nullptr;
-  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
-  k.P = a->N * a->H * a->W; k.ntiles16 = a->N * a->H * cdiv(a->W, 64);      // fused form: tiles are 64-pixel row segments
-  k.dww = a->dw_w; k.H = a->H; k.W = a->W; k.t = a->t; k.ldt = a->ldt; k.ea = a->ea; k.eb = a->eb; k.nterm = a->nterm;
-  for (int i = 0; i < a->nterm; ++i) k.term[i] = a->term[i];
-  const int rows = addk_conv_rows(k.P, a->Cout);
-  c.kg = kg; c.ct = kg; c.red32 = 1;          // one block covers every output channel: the depthwise part is computed once; per-lane statistics in fp32 (a lane sums a handful of values), fp64 across lanes and blocks
-  k.rows = rows;
-  c.gx = rows; if (c.gx > k.ntiles16) c.gx = k.ntiles16; if (c.gx < 1) c.gx = 1;
-  c.gy = 1; k.gx = c.gx; k.gy = 1;
-  return true;
-}
-inline int sep_key(const PwCfg& c, int K) { return (K << 16) | (c.kg << 4) | c.red32; }
-template <bool BATCH>
-int sep_dispatch(int kg, int K, int red32, dim3 grid, hipStream_t st, const PwK* one, const PwK* tab) {
-#define ADDK_SEP(KG_, K_, R_) \
-  if (kg == KG_ && K == K_ && (red32 != 0) == R_) { \
-    static bool attr = false; \
-    if (!attr) { \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_batch_kernel<KG_, KG_, R_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384); \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sep_kernel<KG_, KG_, R_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384); attr = true; } \
-    if (BATCH) hipLaunchKernelGGL((sep_batch_kernel<KG_, KG_, R_, K_>), grid, dim3(256), sep_lds(KG_, K_), st, tab); \
-    else hipLaunchKernelGGL((sep_kernel<KG_, KG_, R_, K_>), grid, dim3(256), sep_lds(KG_, K_), st, *one); \
-    return addk_check_launch("sep_fwd"); }
-  ADDK_SEP(3, 3, true) ADDK_SEP(3, 5, true) ADDK_SEP(5, 3, true) ADDK_SEP(5, 5, true)
-#undef ADDK_SEP
-  addk_set_error("sep_fwd: no instantiation");
-  return ADDK_ERR_UNSUPPORTED;
-}
-
 
 // stem0 (ADD.py:153-157): 3x3 stride-2 convolution of the 3-channel image into 64 channels.  On the generic implicit-GEMM
 // kernel every tap was a 32-channel chunk with 3 live k slots (9 chunks, 18 barriers, 8x the matrix work: 0.38 ms = 0.85 TB/s on a
@@ -774,43 +701,4 @@ extern "C" int addk_conv_batch_run(const void* dev_blob, const int64_t* meta, vo
   const PwK* tab = reinterpret_cast<const PwK*>(dev_blob);
   if (mode == PW_FWD) return pw_batch_launch<PW_FWD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
   return pw_batch_launch<PW_DGRAD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
-}
-
-// ---- fused SepConv half: C ABI ---------------------------------------------------------------------------------------
-extern "C" int addk_sep_fwd_supported(const addk_sep_args* a) {
-  PwK k; PwCfg c;
-  return (addk_get_fast_paths() & ADDK_FAST_PW) && sep_fill(a, k, c) ? 1 : 0;
-}
-extern "C" int addk_sep_fwd(const addk_sep_args* a, void* stream) {
-  PwK k; PwCfg c;
-  ADDK_REQUIRE(sep_fill(a, k, c), "sep_fwd: shape not covered by the fused kernel (K in {3,5}, C == Cout in (32,48] or (64,80], aligned)");
-  return sep_dispatch<false>(c.kg, a->K, c.red32, dim3(c.gx, 1), (hipStream_t)stream, &k, nullptr);
-}
-// batched form (one dependency level): key >= 0 groups launches that share a kernel variant
-extern "C" int addk_sep_fwd_batch_key(const addk_sep_args* a) {
-  PwK k; PwCfg c;
-  if (!(addk_get_fast_paths() & ADDK_FAST_PW) || !sep_fill(a, k, c)) return -1;
-  return sep_key(c, a->K);
-}
-extern "C" int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
-  if (!a || n <= 0 || !meta) { addk_set_error("sep_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
-  const int64_t total = (int64_t)n * sizeof(PwK);
-  if (host_blob && blob_bytes < total) { addk_set_error("sep_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
-  int key0 = -1, gx = 0;
-  for (int i = 0; i < n; ++i) {
-    PwK k; PwCfg c;
-    if (!sep_fill(&a[i], k, c)) { addk_set_error("sep_batch_prepare: launch %d is not covered", i); return ADDK_ERR_INVALID; }
-    const int key = sep_key(c, a[i].K);
-    if (i == 0) key0 = key;
-    if (key != key0) { addk_set_error("sep_batch_prepare: mixed kernel variants"); return ADDK_ERR_INVALID; }
-    if (c.gx > gx) gx = c.gx;
-    if (host_blob) reinterpret_cast<PwK*>(host_blob)[i] = k;
-  }
-  meta[0] = key0; meta[1] = n; meta[2] = gx; meta[3] = 1;
-  return total;
-}
-extern "C" int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
-  ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "sep_batch_run: bad args");
-  const int key = (int)meta[0], K = key >> 16, kg = (key >> 4) & 15, red32 = key & 1;
-  return sep_dispatch<true>(kg, K, red32, dim3((unsigned)meta[2], 1, (unsigned)meta[1]), (hipStream_t)stream, nullptr, reinterpret_cast<const PwK*>(dev_blob));
 }

@@ -1,0 +1,340 @@
+// Fused SepConv half (reference modeling/operations.py:51-53 and :55-57): lazy BatchNorm / ReLU prologue -> depthwise
+// KS x KS (stride 1, dilation 1, 'same') -> pointwise 1x1 on the fp32 matrix cores -> epilogue, ONE launch, 2-D LDS tiles.
+//
+// Round 2's fused form staged KS input rows per 64-pixel output row segment: a 5x re-read of the input through the
+// texture path (307 MB for a 10 MB tensor) that made it slower than the two launches it replaced.  Here a workgroup owns a
+// (4R) x 16 pixel tile of ALL channels:
+//   * the haloed input patch [(4R+KS-1)][16+KS-1][C] is staged ONCE (read amplification 1.6-2.5x, from L2), prologue and
+//     zero padding applied on the way in.  Pixel stride KP floats with KP = 8 (mod 16): the 16-byte tap reads of a wave
+//     (lane (li, kq) reads pixel li + dx, channel quad 4g + kq) touch every bank exactly once per 16-lane group for every
+//     tap shift — brute-forced over the ds_read_b128 lane groups of MI355X_MICROARCH.md §LDS (C = 40 -> KP 40, no padding);
+//   * wave w owns rows [wR, wR+R) x 16 pixels: lane (li = pixel, kq) computes the depthwise output of channels
+//     16g + 4kq .. +3 — exactly the B fragment v_mfma_f32_16x16x4_f32 wants from it (k = the lane's 4 channels, one k-step
+//     per element), so the depthwise result goes from the VALU registers straight into the matrix pipe: no transpose, no LDS
+//     round trip.  With R = 2 an input row is read once for the two output rows it feeds (sliding accumulators), tap
+//     weights of the current group in registers;
+//   * pointwise weights sit in LDS as ready A fragments ([g][tile][lane] float4, conflict-free);
+//   * training epilogue: raw store, depthwise output stored for the backward pass, BatchNorm (sum, sumsq) partials ->
+//     slab row -> the LAST workgroup finalizes the statistics (bnfin.h): no bn_finalize launch;
+//     inference epilogue: own frozen BatchNorm + the other branches of the cell block (ADD.py:108).
+#include "common.h"
+#include "bnfin.h"
+
+namespace {
+
+struct SepfK {
+  addk_src src; int N, H, W, C;
+  const float* dww; const float* pww; int ldw;
+  float* y; int ldy; float* t; int ldt;
+  double* slab; int slab_ld; int rows;
+  const float* ea; const float* eb; int nterm; addk_src term[ADDK_MAX_TERMS];
+  int tiles_x, tiles_y, gx;
+  BnFin fin;
+};
+
+__device__ __forceinline__ float4 fma4(float4 w, float4 v, float4 a) {
+  return make_float4(fmaf(w.x, v.x, a.x), fmaf(w.y, v.y, a.y), fmaf(w.z, v.z, a.z), fmaf(w.w, v.w, a.w));
+}
+
+template <int KS, int KG, int KP, int R>
+struct SepfGeo {
+  static constexpr int CT = KG, PH = 4 * R + KS - 1, PW = 16 + KS - 1, NPIX = PH * PW, KQ = KP / 4;
+  static constexpr int PATCH = NPIX * KP + 8;                     // floats (+8: the clamped tail read of the last pixel stays inside)
+  static constexpr int DWL = KS * KS * KG * 16, PWL = KG * CT * 64 * 4;
+  static constexpr int RED = (4 * CT * 16 * 2 > 1026 ? 4 * CT * 16 * 2 : 1026) * 2;   // floats: [4][CT*16][2] doubles, or the finalize scratch
+  static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + RED) * 4;
+};
+
+template <int KS, int KG, int KP, int R>
+__device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
+  typedef SepfGeo<KS, KG, KP, R> G;
+  constexpr int CT = G::CT, PH = G::PH, PW = G::PW, NPIX = G::NPIX, KQ = G::KQ, HK = KS / 2;
+  float* patch = sm;
+  float* dwl = patch + G::PATCH;                 // [KS*KS][KG*16]
+  float* pwl = dwl + G::DWL;                     // [KG][CT][64] float4
+  double* red = reinterpret_cast<double*>(pwl + G::PWL);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int C = p.C, nq = C >> 2;
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y; const int n = b / p.tiles_y;
+  const int oh0 = ty * (4 * R), ow0 = tx * 16;
+
+  // ---- stage: weights (tiny, L2-resident) and the input patch; every global load here is independent of every other ----
+  for (int i = t; i < G::DWL; i += 256) dwl[i] = 0.f;
+  __syncthreads();
+  for (int i = t; i < C * KS * KS; i += 256) {                 // coalesced read of [C][KS*KS], transposed into [tap][channel]
+    const int c = i / (KS * KS), tp = i - c * (KS * KS);
+    dwl[tp * (KG * 16) + c] = ((const gfloat*)p.dww)[i];
+  }
+  for (int s = t; s < KG * CT * 64; s += 256) {
+    const int g = s / (CT * 64), rem = s - g * (CT * 64), ct = rem >> 6, ln = rem & 63;
+    const int nn = ct * 16 + (ln & 15), k = 16 * g + 4 * (ln >> 4);
+    const bool ok = nn < C && k < C;
+    float4 v = ld4(ok ? p.pww + (long)nn * p.ldw + k : p.pww);
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    lds_st4(pwl + s * 4, v);
+  }
+  {
+    const int npl = 256 / KQ;                                  // pixel lanes; thread = (pixel lane, channel quad incl. the zero padding quads)
+    const int q = t % KQ, pl = t / KQ;
+    const bool qact = pl < npl && q < nq;
+    float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+    if (p.src.a && qact) { av = ld4(p.src.a + 4 * q); bv = ld4(p.src.b + 4 * q); }
+    const bool relu = p.src.relu != 0;
+    const float* xb = p.src.x + (qact ? 4 * q : 0);
+    const int ih0 = oh0 - HK, iw0 = ow0 - HK;
+    if (pl < npl) {
+      constexpr int UN = 6;
+      for (int base = pl; base < NPIX; base += UN * npl) {
+        float4 v[UN]; bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int pix = base + u * npl;
+          const int pr = pix / PW, pc = pix - pr * PW;
+          const int ih = ih0 + pr, iw = iw0 + pc;
+          ok[u] = qact && pix < NPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          v[u] = ld4(xb + (ok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int pix = base + u * npl;
+          float4 z = fma4(av, v[u], bv);
+          if (relu) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
+          z.x = ok[u] ? z.x : 0.f; z.y = ok[u] ? z.y : 0.f; z.z = ok[u] ? z.z : 0.f; z.w = ok[u] ? z.w : 0.f;
+          if (pix < NPIX) lds_st4(patch + pix * KP + 4 * q, z);
+        }
+      }
+    }
+    if (t < 8) patch[NPIX * KP + t] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- compute: wave = rows [wave*R, wave*R + R) x 16 pixels ----
+  f32x4 macc[R][CT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < CT; ++i) macc[r][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int pp[R]; bool pin[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int oh = oh0 + wave * R + r, ow = ow0 + li;
+    pin[r] = oh < p.H && ow < p.W;
+    pp[r] = (n * p.H + oh) * p.W + ow;
+  }
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    const int q = 4 * g + kq;
+    const int qr = q < KQ ? q : q - 2;             // quads past the padded pixel (only when KP < 16 KG): re-read a valid quad, its tap weights are 0
+    float4 wr[KS * KS];
+#pragma unroll
+    for (int tp = 0; tp < KS * KS; ++tp) wr[tp] = lds_ld4(dwl + tp * (KG * 16) + 4 * q);
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = zero4();
+    const float* pb = patch + ((wave * R) * PW + li) * KP + 4 * qr;
+#pragma unroll
+    for (int i = 0; i < R + KS - 1; ++i)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) {
+        const float4 v = lds_ld4(pb + (i * PW + dx) * KP);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int kh = i - r;
+          if (kh >= 0 && kh < KS) acc[r] = fma4(wr[kh * KS + dx], v, acc[r]);
+        }
+      }
+    if (p.t && 4 * q < C) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) if (pin[r]) st4(p.t + (long)pp[r] * p.ldt + 4 * q, acc[r]);
+    }
+    float4 wf[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) wf[i] = lds_ld4(pwl + ((g * CT + i) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+          macc[r][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(wf[i], e), get4(acc[r], e), macc[r][i], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane holds channels i*16 + kq*4 + {0..3} of pixel pp[r] ----
+  float s1[CT][4], s2[CT][4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[i][e] = 0.f; s2[i][e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int c = i * 16 + kq * 4;
+    if (c >= C) continue;                                   // C % 4 == 0: a quad is valid as a whole
+    float4 ea = make_float4(1.f, 1.f, 1.f, 1.f), eb = zero4();
+    if (p.ea) { ea = ld4(p.ea + c); eb = ld4(p.eb + c); }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!pin[r]) continue;
+      float4 v = make_float4(macc[r][i][0], macc[r][i][1], macc[r][i][2], macc[r][i][3]);
+      if (p.ea) v = fma4(ea, v, eb);
+      for (int ti = 0; ti < p.nterm; ++ti) {
+        const addk_src& T = p.term[ti];
+        const float4 u = prologue4(ld4(T.x + (long)pp[r] * T.ld + c), T.a, T.b, c, 4, T.relu != 0, true);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      st4(p.y + (long)pp[r] * p.ldy + c, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float f = get4(v, e); s1[i][e] += f; s2[i][e] = fmaf(f, f, s2[i][e]); }
+    }
+  }
+  if (p.slab) {            // butterfly over the 16 pixel lanes (fp64), the four waves through LDS, one slab row per workgroup
+    double (*rd)[CT * 16][2] = reinterpret_cast<double (*)[CT * 16][2]>(red);
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double a = (double)s1[i][e], bsum = (double)s2[i][e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); bsum += __shfl_xor(bsum, m); }
+        if (li == 0) { rd[wave][i * 16 + kq * 4 + e][0] = a; rd[wave][i * 16 + kq * 4 + e][1] = bsum; }
+      }
+    __syncthreads();
+    const bool fused = p.fin.a != nullptr;
+    if (t < CT * 16 && t < C) {
+      double* o = p.slab + ((long)blockIdx.x * p.slab_ld + t) * 2;
+      const double o0 = rd[0][t][0] + rd[1][t][0] + rd[2][t][0] + rd[3][t][0];
+      const double o1 = rd[0][t][1] + rd[1][t][1] + rd[2][t][1] + rd[3][t][1];
+      if (fused) { slab_store_wt(o, o0); slab_store_wt(o + 1, o1); }
+      else {
+        ((gdouble*)o)[0] = o0; ((gdouble*)o)[1] = o1;
+        for (int r = blockIdx.x + p.gx; r < p.rows; r += p.gx) {       // rows no workgroup owns
+          gdouble* z = (gdouble*)p.slab + ((long)r * p.slab_ld + t) * 2;
+          z[0] = 0.0; z[1] = 0.0;
+        }
+      }
+    }
+    if (fused) bn_finalize_by_last_block(p.fin, p.slab, p.slab_ld, 0, C, (unsigned)p.gx, red);
+  }
+}
+
+template <int KS, int KG, int KP, int R>
+__global__ void __launch_bounds__(256, 2) sepf_kernel(const SepfK p) {
+  extern __shared__ __attribute__((aligned(16))) float sepf_sm[];
+  sepf_body<KS, KG, KP, R>(p, sepf_sm);
+}
+template <int KS, int KG, int KP, int R>
+__global__ void __launch_bounds__(256, 2) sepf_batch_kernel(const SepfK* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) float sepf_sm[];
+  const SepfK& p = tab[blockIdx.z];          // by reference: a local copy with its runtime-indexed term[] would live in scratch
+  if ((int)blockIdx.x >= p.gx) return;
+  sepf_body<KS, KG, KP, R>(p, sepf_sm);
+}
+
+struct SepfCfg { int ks, kg, kp, r; };
+inline int sepf_key(const SepfCfg& c) { return (c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r; }
+
+bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
+  if (!a || !(a->K == 3 || a->K == 5) || a->N <= 0 || a->H <= 0 || a->W <= 0) return false;
+  const addk_src& s = a->src;
+  const int kg = cdiv(s.C, 16);
+  if (!(kg == 3 || kg == 5) || a->Cout != s.C || !s.x || !src_vec_ok(s) || !a->dw_w || !a->pw_w || !a->y) return false;
+  if (!aligned16(a->y) || a->ldy % 4 || a->ldy < a->Cout || !aligned16(a->pw_w) || a->ldw % 4 || a->ldw < s.C) return false;
+  if (a->t && (!aligned16(a->t) || a->ldt % 4 || a->ldt < s.C)) return false;
+  if (a->nterm < 0 || a->nterm > ADDK_MAX_TERMS || (a->ea == nullptr) != (a->eb == nullptr)) return false;
+  if ((a->nterm > 0 || a->ea) && a->stats) return false;               // the sum epilogue is an inference form
+  if (a->ea && (!aligned16(a->ea) || !aligned16(a->eb))) return false;
+  if (a->fin.a && (!a->stats || !a->fin_counter || !a->fin.b || a->fin.count <= 0)) return false;
+  for (int i = 0; i < a->nterm; ++i) if (!a->term[i].x || a->term[i].C != a->Cout || !src_vec_ok(a->term[i])) return false;
+  int kp = s.C; while (kp % 16 != 8) kp += 4;
+  if (!((kg == 3 && (kp == 40 || kp == 56)) || (kg == 5 && (kp == 72 || kp == 88)))) return false;
+  k = SepfK{};
+  k.src = s; k.N = a->N; k.H = a->H; k.W = a->W; k.C = s.C;
+  k.dww = a->dw_w; k.pww = a->pw_w; k.ldw = a->ldw; k.y = a->y; k.ldy = a->ldy; k.t = a->t; k.ldt = a->ldt;
+  k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
+  k.ea = a->ea; k.eb = a->eb; k.nterm = a->nterm;
+  for (int i = 0; i < a->nterm; ++i) k.term[i] = a->term[i];
+  // two rows per wave where that still gives the chip >= 1.5 workgroups per CU (the LDS patch of a KG = 5 tile is 56 KB at R = 1)
+  const long blocks2 = (long)a->N * cdiv(a->H, 8) * cdiv(a->W, 16);
+  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1;
+  k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
+  k.rows = a->stats_rows;
+  if (k.slab && k.gx > k.rows) return false;             // the caller sizes the slab with addk_sep_rows
+  if (a->fin.a) {
+    k.fin.a = a->fin.a; k.fin.b = a->fin.b; k.fin.mean = a->fin.mean; k.fin.invstd = a->fin.invstd; k.fin.gamma = a->fin.gamma; k.fin.beta = a->fin.beta;
+    k.fin.running_mean = a->fin.running_mean; k.fin.running_var = a->fin.running_var; k.fin.count = a->fin.count;
+    k.fin.momentum = a->fin.momentum; k.fin.eps = a->fin.eps; k.fin.counter = (unsigned*)a->fin_counter;
+  }
+  return true;
+}
+
+template <int KS, int KG, int KP, int R>
+int sepf_go(bool batch, dim3 grid, hipStream_t st, const SepfK* one, const SepfK* tab) {
+  typedef SepfGeo<KS, KG, KP, R> G;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepf_kernel<KS, KG, KP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepf_batch_kernel<KS, KG, KP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    attr = true;
+  }
+  if (batch) hipLaunchKernelGGL((sepf_batch_kernel<KS, KG, KP, R>), grid, dim3(256), G::LDS, st, tab);
+  else hipLaunchKernelGGL((sepf_kernel<KS, KG, KP, R>), grid, dim3(256), G::LDS, st, *one);
+  return addk_check_launch("sep_fwd");
+}
+
+int sepf_dispatch(const SepfCfg& c, bool batch, dim3 grid, hipStream_t st, const SepfK* one, const SepfK* tab) {
+#define ADDK_SEPF(KS_, KG_, KP_, R_) if (c.ks == KS_ && c.kg == KG_ && c.kp == KP_ && c.r == R_) return sepf_go<KS_, KG_, KP_, R_>(batch, grid, st, one, tab);
+  ADDK_SEPF(3, 3, 40, 1) ADDK_SEPF(3, 3, 40, 2) ADDK_SEPF(5, 3, 40, 1) ADDK_SEPF(5, 3, 40, 2)
+  ADDK_SEPF(3, 3, 56, 1) ADDK_SEPF(3, 3, 56, 2) ADDK_SEPF(5, 3, 56, 1) ADDK_SEPF(5, 3, 56, 2)
+  ADDK_SEPF(3, 5, 72, 1) ADDK_SEPF(5, 5, 72, 1) ADDK_SEPF(3, 5, 88, 1) ADDK_SEPF(5, 5, 88, 1)
+#undef ADDK_SEPF
+  addk_set_error("sep_fwd: no instantiation");
+  return ADDK_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// slab rows a fused launch writes (= its workgroups): the caller sizes `stats` with max(this, addk_conv_rows)
+extern "C" int addk_sep_rows(const addk_sep_args* a) {
+  SepfK k; SepfCfg c;
+  addk_sep_args b = *a; b.stats = nullptr; b.fin.a = nullptr;
+  return sepf_fill(&b, k, c) ? k.gx : 0;
+}
+extern "C" int addk_sep_fwd_supported(const addk_sep_args* a) {
+  SepfK k; SepfCfg c;
+  return (addk_get_fast_paths() & ADDK_FAST_PW) && sepf_fill(a, k, c) ? 1 : 0;
+}
+extern "C" int addk_sep_fwd(const addk_sep_args* a, void* stream) {
+  SepfK k; SepfCfg c;
+  ADDK_REQUIRE(sepf_fill(a, k, c), "sep_fwd: shape not covered by the fused kernel (K in {3,5}, C == Cout in (32,48] or (64,80], aligned, stats_rows >= addk_sep_rows)");
+  return sepf_dispatch(c, false, dim3(k.gx), (hipStream_t)stream, &k, nullptr);
+}
+// batched form (one dependency level): key >= 0 groups launches that share a kernel variant
+extern "C" int addk_sep_fwd_batch_key(const addk_sep_args* a) {
+  SepfK k; SepfCfg c;
+  if (!(addk_get_fast_paths() & ADDK_FAST_PW) || !sepf_fill(a, k, c)) return -1;
+  return sepf_key(c);
+}
+extern "C" int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  if (!a || n <= 0 || !meta) { addk_set_error("sep_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
+  const int64_t total = (int64_t)n * sizeof(SepfK);
+  if (host_blob && blob_bytes < total) { addk_set_error("sep_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
+  int key0 = -1, gx = 0;
+  for (int i = 0; i < n; ++i) {
+    SepfK k; SepfCfg c;
+    if (!sepf_fill(&a[i], k, c)) { addk_set_error("sep_batch_prepare: launch %d is not covered", i); return ADDK_ERR_INVALID; }
+    const int key = sepf_key(c);
+    if (i == 0) key0 = key;
+    if (key != key0) { addk_set_error("sep_batch_prepare: mixed kernel variants"); return ADDK_ERR_INVALID; }
+    if (k.gx > gx) gx = k.gx;
+    if (host_blob) reinterpret_cast<SepfK*>(host_blob)[i] = k;
+  }
+  meta[0] = key0; meta[1] = n; meta[2] = gx; meta[3] = 1;
+  return total;
+}
+extern "C" int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
+  ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "sep_batch_run: bad args");
+  const int key = (int)meta[0];
+  SepfCfg c{key >> 16, (key >> 12) & 15, (key >> 4) & 255, key & 15};
+  return sepf_dispatch(c, true, dim3((unsigned)meta[2], 1, (unsigned)meta[1]), (hipStream_t)stream, nullptr, reinterpret_cast<const SepfK*>(dev_blob));
+}

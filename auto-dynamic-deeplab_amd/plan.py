@@ -19,6 +19,9 @@ import torch
 from . import _lib as L
 
 
+TRACE_BN = None        # diagnostics (tests/tools): a list that receives (BatchNorm module, raw TRef) of every Graph.bn call
+
+
 class Buf:
     """Flat fp32 device buffer."""
     __slots__ = ('t', 'ptr', 'n', 'gbuf', 'ginit')
@@ -779,13 +782,18 @@ class Graph:
         rows = self.lib.addk_conv_rows(P, Cc)
         return self.buf(rows * Cc * 4), rows      # fp64 [rows][C][2]
 
-    def bn(self, raw, mod, slab=None, rows=0, post_relu=False, needs_grad=True):
-        """Apply BatchNorm module `mod` lazily to `raw`.  Training: statistics come from `slab`."""
+    def bn(self, raw, mod, slab=None, rows=0, post_relu=False, needs_grad=True, fuse=None):
+        """Apply BatchNorm module `mod` lazily to `raw`.  Training: statistics come from `slab`.  `fuse` = (args, cmd) of the
+        producing launch when its kernel can finalize the statistics itself (last workgroup, csrc/bnfin.h): the finalize
+        arguments go into `args.fin` and no bn_finalize launch is emitted (local BatchNorm only: the SyncBN exchange sits
+        between the slab and the finalize)."""
         lib = self.lib
         Cc = raw.C
         a, b = self.vec(Cc), self.vec(Cc)
         training = self.training and mod.training
         count = float(raw.P)
+        if TRACE_BN is not None:
+            TRACE_BN.append((mod, raw))
         st = BNState(mod, Cc, a, b, training, count)
         gam = self.param(mod.weight) if mod.weight is not None else None
         bet = self.param(mod.bias) if mod.bias is not None else None
@@ -816,10 +824,19 @@ class Graph:
             fa.eps = mod.eps
             fa.a, fa.b, fa.mean, fa.invstd = a.ptr, b.ptr, st.mean.ptr, st.invstd.ptr
             self.keep.append(fa)
-            cfin = self._add(self.fwd, 'bn_finalize', lib.addk_bn_finalize, C.byref(fa),
-                             rd=[red if sync else slab, mod.weight, mod.bias],
-                             wr=[a, b, st.mean, st.invstd] + ([mod.running_mean, mod.running_var] if fa.running_mean else []))
-            cfin.payload = fa
+            stat_wr = [a, b, st.mean, st.invstd] + ([mod.running_mean, mod.running_var] if fa.running_mean else [])
+            if fuse is not None and not sync and os.environ.get('ADDK_FUSE_FINALIZE', '1') == '1':
+                args, cmd = fuse
+                for f_ in ('count', 'gamma', 'beta', 'running_mean', 'running_var', 'momentum', 'eps', 'a', 'b', 'mean', 'invstd'):
+                    setattr(args.fin, f_, getattr(fa, f_))
+                ctr = self.buf(4, zero=True)                # ticket counter of this BatchNorm call (the launch leaves it at zero)
+                args.fin_counter = ctr.ptr
+                cmd.rd += [r for r in (_region(mod.weight), _region(mod.bias)) if r]
+                cmd.wr += [r for r in (_region(x) for x in stat_wr + [ctr]) if r]
+            else:
+                cfin = self._add(self.fwd, 'bn_finalize', lib.addk_bn_finalize, C.byref(fa),
+                                 rd=[red if sync else slab, mod.weight, mod.bias], wr=stat_wr)
+                cfin.payload = fa
         else:
             # inference: (a, b) of ALL BatchNorms come from one batched launch placed where the first one is emitted
             e = L.BnEvalEntry()
@@ -963,9 +980,10 @@ class Graph:
 
     def sep_half(self, src, dw_mod, pw_mod, bn_mod, sum_terms=None, out=None):
         """One half of SepConv (operations.py:51-54 / 55-58): ReLU -> depthwise k x k -> pointwise 1x1 -> BN (lazy), as ONE
-        launch where the fused kernel covers the shape (addk_sep_fwd: the depthwise output stays on chip; in training it is
-        also written out because the backward pass reads it).  Inference only: `sum_terms` (other branches of the cell
-        block) makes the epilogue apply this op's frozen BatchNorm and write the block sum (ADD.py:108) into `out`."""
+        launch where the fused kernel covers the shape (addk_sep_fwd, csrc/sepf.hip: the depthwise output stays on chip; in
+        training it is also written out because the backward pass reads it, and the launch's last workgroup finalizes the
+        BatchNorm statistics itself).  Inference only: `sum_terms` (other branches of the cell block) makes the epilogue apply
+        this op's frozen BatchNorm and write the block sum (ADD.py:108) into `out`."""
         lib = self.lib
         k = dw_mod.kernel_size[0]
         N, H, W, Cc = src.N, src.H, src.W, src.C
@@ -975,10 +993,10 @@ class Graph:
         ar.src = self.src(src, True)
         ar.N, ar.H, ar.W, ar.K, ar.Cout, ar.ldw = N, H, W, k, Cout, Cc
         ar.dw_w, ar.pw_w = self.param(dw_mod.weight), self.param(pw_mod.weight)
-        fused = (os.environ.get('ADDK_FUSE_SEP', '0') == '1' and dw_mod.stride[0] == 1 and dw_mod.dilation[0] == 1
+        fused = (os.environ.get('ADDK_FUSE_SEP', '1') == '1' and dw_mod.stride[0] == 1 and dw_mod.dilation[0] == 1
                  and dw_mod.padding[0] == k // 2 and pw_mod.kernel_size[0] == 1 and (sum_terms is None or not (training or self.want_grad)))
         if fused:
-            raw = out if out is not None else self.tensor(N, H, W, Cout)
+            raw = out if (out is not None and sum_terms is not None) else self.tensor(N, H, W, Cout)
             ar.y, ar.ldy = raw.ptr, raw.ld
             fused = bool(lib.addk_sep_fwd_supported(C.byref(ar)))
         if not fused:
@@ -988,7 +1006,9 @@ class Graph:
         t = self.dwconv(src, dw_mod, relu_in=True, fwd=False) if self.want_grad else None
         slab = rows = None
         if training:
-            slab, rows = self.stats_slab(N * H * W, Cout)
+            rows = max(int(lib.addk_sep_rows(C.byref(ar))), int(lib.addk_conv_rows(N * H * W, Cout)))
+            slab = self.buf(rows * Cout * 4)
+            ar.stats_rows = rows
         if t is not None:
             self.conv([t], pw_mod.weight, Cout, 1, out=raw, stats=slab, fwd=False)       # backward of the pointwise half
             ar.t, ar.ldt = t.raw.ptr, t.raw.ld
@@ -1005,17 +1025,19 @@ class Graph:
                 assert (tm.N, tm.H, tm.W, tm.C) == (N, H, W, Cout), 'branch shapes differ'
                 ar.term[i] = self.src(tm)
                 rd += self.lz(tm)
-            ar.y, ar.ldy = out.ptr, out.ld
             rd += [st.a, st.b]
-            raw = out
         self.keep.append(ar)
         c = self._add(self.fwd, 'sep_fwd', lib.addk_sep_fwd, C.byref(ar), rd=rd, wr=[raw, slab, t.raw if t is not None else None])
-        bk = int(lib.addk_sep_fwd_batch_key(C.byref(ar)))
+        if sum_terms is not None:
+            bk = int(lib.addk_sep_fwd_batch_key(C.byref(ar)))
+            if bk >= 0:
+                c.payload, c.bkey = ar, bk
+            return Act(raw, None, False, False)
+        act = self.bn(raw, bn_mod, slab, rows or 0, fuse=(ar, c))
+        bk = int(lib.addk_sep_fwd_batch_key(C.byref(ar)))         # after bn(): the fused finalize is part of the launch's validity
         if bk >= 0:
             c.payload, c.bkey = ar, bk
-        if sum_terms is not None:
-            return Act(raw, None, False, False)
-        return self.bn(raw, bn_mod, slab, rows or 0)
+        return act
 
     def affine_sum(self, terms, out=None, relu_out=False):
         """Materialise sum_i relu_i?(a_i*x_i+b_i) (optionally ReLU'd) into `out`."""

@@ -105,9 +105,13 @@ class TrainStep:
         self.n_active = self.flat_p.numel()
         self.nbytes = g.nbytes
         if use_graph is None:
-            # the collective step is captured too (RCCL calls are stream-ordered work like any kernel); ADDK_GRAPH_DDP=0 keeps
-            # the N>1 step on the eager launch list, and a failed capture falls back to it (step())
-            use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (not has_coll or os.environ.get('ADDK_GRAPH_DDP', '1') == '1')
+            # A step WITHOUT collectives is always captured.  A step with RCCL collectives is captured when the world is this
+            # one process (the forced-exchange rehearsal, covered by tests/test_gpu_train.py) or when ADDK_GRAPH_DDP=1 asks
+            # for it; with world > 1 the default is the eager launch list until a multi-rank capture has been verified on
+            # hardware (no multi-GPU box was available to the builder: DESIGN.md §7).
+            ddp = os.environ.get('ADDK_GRAPH_DDP')
+            ddp_ok = (ddp == '1') if ddp is not None else self.world == 1
+            use_graph = os.environ.get('ADDK_GRAPH', '1') == '1' and (not has_coll or ddp_ok)
         self.has_coll = has_coll
         self.graph = None
         self.use_graph = use_graph
@@ -138,6 +142,36 @@ class TrainStep:
         if self.gsync is not None:
             self.gsync.wait()
 
+    def _capture(self):
+        """Capture one step into a hipGraph.  Returns the graph, or None when the step has collectives and ANY rank's runtime
+        refused the capture (then every rank stays on the eager launch list: the decision is made collectively, so no rank
+        replays a graph while another issues eager collectives).  Nothing is executed here: the caller's eager step stands."""
+        graph, err = torch.cuda.CUDAGraph(), None
+        try:
+            # A step with RCCL exchanges is captured in THREAD-LOCAL error mode: ProcessGroupNCCL's watchdog thread keeps
+            # querying the events of the eager step's collectives, and in the default global mode such a query from another
+            # thread while this one captures is an illegal call.
+            with torch.cuda.graph(graph, capture_error_mode='thread_local' if self.has_coll else 'global'):
+                self._run()
+        except Exception as e:
+            if not self.has_coll:
+                raise
+            err = e
+        if self.has_coll:
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=self.dev)
+            import torch.distributed as dist
+            if self.world > 1 and dist.is_available() and dist.is_initialized():
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if float(ok.item()) < 1.0:
+                import sys
+                why = str(err).splitlines()[0] if err is not None else 'another rank failed'
+                sys.stderr.write('[addk] hipGraph capture of the data-parallel step failed (%s): eager replay on every rank\n' % why)
+                if self.gsync is not None:
+                    del self.gsync.works[:]
+                torch.cuda.synchronize()
+                return None
+        return graph
+
     def load_batch(self, images, targets):
         self.x.copy_(images, non_blocking=True)
         self.target.copy_(targets, non_blocking=True)
@@ -154,28 +188,12 @@ class TrainStep:
             self.set_lr(lr)
         if self.use_graph:
             if self.graph is None:
-                # one eager step first (also warms RCCL), then capture
+                # this call's step runs eagerly (it also warms RCCL); the capture that follows executes nothing
                 self._run()
                 torch.cuda.synchronize()
-                try:
-                    graph = torch.cuda.CUDAGraph()
-                    # A step with RCCL exchanges is captured in THREAD-LOCAL error mode: ProcessGroupNCCL's watchdog thread keeps
-                    # querying the events of the eager step's collectives, and in the default global mode such a query from
-                    # another thread while this one captures is an illegal call that aborts the process (seen as a rare
-                    # SIGABRT of `bench.py --force-sync`, timing dependent).
-                    with torch.cuda.graph(graph, capture_error_mode='thread_local' if self.has_coll else 'global'):
-                        self._run()
-                    self.graph = graph
-                except Exception as e:            # a collective step whose capture the runtime refuses: stay on the eager list
-                    if not self.has_coll:
-                        raise
-                    import sys
-                    sys.stderr.write('[addk] hipGraph capture of the data-parallel step failed (%s): eager replay\n' % (str(e).splitlines()[0],))
-                    self.use_graph, self.graph = False, None
-                    if self.gsync is not None:
-                        del self.gsync.works[:]
-                    torch.cuda.synchronize()
-                    self._run()
+                self.graph = self._capture()
+                if self.graph is None:
+                    self.use_graph = False
             else:
                 self.graph.replay()
         else:

@@ -54,6 +54,19 @@ typedef struct addk_src {
   int32_t _pad;
 } addk_src;
 
+/* BatchNorm statistics -> lazy affine (F.batch_norm training mode, batchnorm.py:51-53): argument block of addk_bn_finalize, also
+ * embedded in the conv launches whose last workgroup does the finalize itself (csrc/bnfin.h). */
+typedef struct addk_bn_finalize_args {
+  const double* partial; /* fp64 [rows][C][2] (sum, sumsq) — or the all-reduced [1][C][2] */
+  int32_t rows, C;
+  double count;          /* number of values per channel (global batch under SyncBN) */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;   /* updated in place (NULL: skip) */
+  float momentum, eps;
+  float* a; float* b;            /* out: lazy affine  a = gamma*invstd, b = beta - mean*a */
+  float* mean; float* invstd;    /* out: saved for backward */
+} addk_bn_finalize_args;
+
 /* ---------------------------------------------------------------------------------------
  * Dense convolution, implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32).
  * Replaces nn.Conv2d(groups=1) call sites: operations.py:24,38,53,57,91-92,109-110;
@@ -182,10 +195,13 @@ int addk_conv_wgrad_batch_run(const void* dev_blob, const int64_t* meta, void* s
 
 /* ---------------------------------------------------------------------------------------
  * Fused SepConv half (reference modeling/operations.py:51-53 and :55-57): ReLU / lazy BatchNorm prologue -> depthwise
- * K x K (stride 1, dilation 1, 'same' padding) -> pointwise 1x1 on the matrix cores -> BatchNorm statistics, ONE launch:
- * the depthwise output never makes a round trip through HBM.  In training `t` receives the depthwise output (the
- * backward pass reads it: pointwise weight gradient, depthwise backward); in inference t = NULL and the epilogue can
- * apply the op's own (frozen) BatchNorm and add the other branches of the cell block (ADD.py:108):
+ * K x K (stride 1, dilation 1, 'same' padding) -> pointwise 1x1 on the matrix cores -> BatchNorm statistics, ONE launch
+ * over 2-D LDS tiles (csrc/sepf.hip): the depthwise output never makes a round trip through HBM.  In training `t` receives
+ * the depthwise output (the backward pass reads it: pointwise weight gradient, depthwise backward) and, when `fin.a` is set,
+ * the LAST workgroup of the launch turns the statistics into the lazy affine (a, b) — no bn_finalize launch (`fin.partial`,
+ * `fin.rows`, `fin.C` are ignored: the launch knows its own slab; `fin_counter` is one zero-initialised 32-bit word owned by
+ * this BatchNorm call, left at zero again by the launch).  In inference t = NULL and the epilogue can apply the op's own
+ * (frozen) BatchNorm and add the other branches of the cell block (ADD.py:108):
  *     y = ea[c]*acc + eb[c] + sum_i relu_i?(a_i*term_i + b_i)        (ea == NULL: plain y = acc)
  * Covered shapes: K in {3,5}, C == Cout in (32, 48] or (64, 80], 16-byte aligned tensors; addk_sep_fwd_supported says so.
  * ------------------------------------------------------------------------------------- */
@@ -198,11 +214,15 @@ typedef struct addk_sep_args {
   const float* pw_w;
   float* y; int32_t ldy;
   int32_t ldt; float* t;            /* depthwise output [P][ldt] or NULL */
-  void* stats; int32_t stats_ld;    /* fp64 (sum, sumsq) partial slab [rows][stats_ld][2] or NULL; rows = addk_conv_rows(P, Cout) */
+  void* stats; int32_t stats_ld;    /* fp64 (sum, sumsq) partial slab [stats_rows][stats_ld][2] or NULL */
+  int32_t stats_rows;               /* rows the caller allocated: >= addk_sep_rows(a); rows no workgroup owns are zero-filled */
   int32_t nterm;                    /* inference epilogue: number of extra terms (0..ADDK_MAX_TERMS) */
   const float* ea; const float* eb; /* inference epilogue: own affine (both NULL = none) */
   addk_src term[ADDK_MAX_TERMS];
+  addk_bn_finalize_args fin;        /* fused finalize of the statistics (fin.a == NULL: none) */
+  void* fin_counter;
 } addk_sep_args;
+int addk_sep_rows(const addk_sep_args* a);               /* slab rows (= workgroups) of the fused launch; 0: not covered */
 int addk_sep_fwd_supported(const addk_sep_args* a);      /* 1: the fused kernel covers this launch */
 int addk_sep_fwd(const addk_sep_args* a, void* stream);
 /* table-driven batch of the fused halves of one dependency level (same protocol as addk_conv_fwd_batch_prepare / addk_conv_batch_run) */
@@ -252,16 +272,6 @@ int addk_dw_rows(int64_t P, int32_t C);
 /* ---------------------------------------------------------------------------------------
  * BatchNorm statistics (F.batch_norm training mode, batchnorm.py:51-53; eps=1e-5, mom=0.1).
  * ------------------------------------------------------------------------------------- */
-typedef struct addk_bn_finalize_args {
-  const double* partial; /* fp64 [rows][C][2] (sum, sumsq) — or the all-reduced [1][C][2] */
-  int32_t rows, C;
-  double count;          /* number of values per channel (global batch under SyncBN) */
-  const float* gamma; const float* beta;
-  float* running_mean; float* running_var;   /* updated in place (NULL: skip) */
-  float momentum, eps;
-  float* a; float* b;            /* out: lazy affine  a = gamma*invstd, b = beta - mean*a */
-  float* mean; float* invstd;    /* out: saved for backward */
-} addk_bn_finalize_args;
 int addk_bn_finalize(const addk_bn_finalize_args* a, void* stream);
 /* n independent BatchNorms in one launch; dev_table = device array of n argument structs, max_C = largest C among them */
 int addk_bn_finalize_batch(const addk_bn_finalize_args* dev_table, int32_t n, int32_t max_C, void* stream);

@@ -162,8 +162,7 @@ def test_f40_frozen_bn_gradients(dev, gname):
     assert max(ours) <= max(3 * max(theirs), 2e-3) and med(ours) <= max(3 * med(theirs), 2e-4)
 
 
-@pytest.mark.parametrize('hw', [(65, 129), pytest.param((64, 128), marks=pytest.mark.skipif(os.environ.get('ADDK_LONG_TESTS') != '1', reason='second size of the spread test: ADDK_LONG_TESTS=1 (2 min of fp64 oracle)'))],
-                         ids=['odd65x129', 'even64x128'])
+@pytest.mark.parametrize('hw', [(65, 129), (64, 128)], ids=['odd65x129', 'even64x128'])
 def test_train_mode_gradient_spread_is_the_references_own(dev, hw):
     """Train-mode whole-network gradients are ill-conditioned in the REFERENCE arithmetic itself: the fp32 oracle sits
     5e-2..1.5e-1 (rel-L2 over all parameters) from an fp64 evaluation of the same graph, at every batch / map size tried
@@ -171,12 +170,20 @@ def test_train_mode_gradient_spread_is_the_references_own(dev, hw):
     exists; the gradient norm grows 300x from the heads to the stems through 12 cells of small-batch BatchNorm).  A
     single input therefore says little (round 1's F4_64 case: addk 6.1e-2 vs fp32 1.5e-2 was one draw from this spread).
     The bound here is on the DISTRIBUTION over several inputs: addk's error against fp64 must look like the fp32
-    oracle's own — median within 2x, maximum within 3x — and the gradient direction must be as good as the fp32 oracle's."""
+    oracle's own — median within 2x, maximum within 3x — and the gradient direction must be as good as the fp32 oracle's.
+
+    The even size is the better-conditioned one (its early resizes have lambda = 0.5 exactly, so the reference's own fp32 error
+    sits at its floor, 1-2e-2) and addk is 1.2-2.9x the oracle there on every draw.  Round 3 traced it layer by layer
+    (tests/tools/even_size_study.py --trace, profiles/r03_even_size_trace.txt): the forward error leaves the oracle's at
+    stem1 (3x3, K = 576: 3.6e-7 vs 1.9e-7) and stays 1.5-1.9x through every later layer, which only inherit it — a k-ordered
+    fp32 accumulation chain (the MFMA's, and the split-bf16 kernel's) against the CPU library's blocked sums; every
+    operator with K <= 400 is at ratio 1.0 in isolation (tests/tools/op_accuracy_probe.py).  It is NOT the lazy-BatchNorm
+    cancellation the r02 verdict suspected: the centred backward form changes no digit of these numbers."""
     from addk.modeling.ADD import ADD
     args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4), 0)
     crit = nn.CrossEntropyLoss(ignore_index=255)
     e32s, eas, coss, cos32 = [], [], [], []
-    ndraw = 4          # ~30 s each, almost all of it the oracle's fp64 pass
+    ndraw = 4 if hw[0] % 2 == 0 else 3          # ~30 s each, almost all of it the oracle's fp64 pass
     for k in range(ndraw):
         mo = oracle.ADD(*args)
         fill_params(mo, 600 + k)

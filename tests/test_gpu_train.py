@@ -268,3 +268,64 @@ def test_syncbn_path_world1_matches_local_bn(dev):
     finally:
         parallel.disable_sync_bn()
         dist.destroy_process_group()
+
+
+def test_syncbn_captured_step_world1_equals_eager_and_capture_failure_applies_one_update(dev, monkeypatch):
+    """The DEFAULT path of a step with collectives at world 1 (forced exchanges): the whole step incl. its RCCL calls captured
+    in one hipGraph in thread-local capture mode (train.TrainStep._capture) — loss and parameters must equal the eager
+    launch list bit for bit over three steps (regression test of the capture abort fixed in round 2).  Then the fallback: a
+    capture that raises must leave exactly ONE update applied by that call (it used to run the step twice)."""
+    import os
+    import torch.distributed as dist
+    from addk import parallel
+    from addk.modeling.ADD import ADD
+    from addk.train import TrainStep
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29612')
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        x, t = _batch(2, (65, 129))
+
+        def build(**kw):
+            args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4, sync_bn=True), 0)
+            m = ADD(*args)
+            fill_params(m, 600)
+            m.to(dev)
+            comm = parallel.init_sync_bn(force=True)
+            ts = TrainStep(m, (2, 3, 65, 129), sync_comm=comm, **kw)
+            ts.load_batch(x.to(dev), t.to(dev))
+            return ts
+        eager = build(use_graph=False)
+        le = [eager.step().item() for _ in range(3)]
+        pe = eager.flat_p.clone()
+        cap = build()                                  # default: captured (world == 1)
+        assert cap.use_graph and cap.has_coll
+        lc = [cap.step().item() for _ in range(3)]
+        assert cap.graph is not None, 'the collective step was not captured'
+        assert lc == le, (lc, le)
+        assert torch.equal(cap.flat_p, pe)
+        # a runtime that refuses the capture: eager replay from then on, ONE update per call
+        one = build(use_graph=False)
+        l1 = one.step().item()
+        p1 = one.flat_p.clone()
+
+        class _Refuse:
+            def __init__(self, *a, **k):
+                pass
+
+            def __enter__(self):
+                raise RuntimeError('capture refused (test stub)')
+
+            def __exit__(self, *a):
+                return False
+        bad = build()
+        monkeypatch.setattr(torch.cuda, 'graph', _Refuse)
+        lb = bad.step().item()
+        monkeypatch.undo()
+        assert not bad.use_graph and bad.graph is None and bad.steps == 1
+        assert lb == l1 and torch.equal(bad.flat_p, p1), 'the fallback applied a second update'
+        assert bad.step().item() == le[1]              # and continues on the eager list
+    finally:
+        parallel.disable_sync_bn()
+        dist.destroy_process_group()

@@ -50,12 +50,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--draws', type=int, default=4)
     ap.add_argument('--F', type=int, default=4)
+    ap.add_argument('--grads', type=int, default=1)
+    ap.add_argument('--detail', type=int, default=0)
+    ap.add_argument('--trace', type=int, default=0)
     a = ap.parse_args()
     from addk.modeling.ADD import ADD
     dev = torch.device('cuda:0')
     addk.load()
     args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(a.F), 0)
-    for hw in ((64, 128), (65, 129)):
+    if a.trace:
+        layer_trace(args, (64, 128), 0, dev)
+        return
+    for hw in (((64, 128), (65, 129)) if a.grads else ()):
         rows = {'o32': [], 'centred': [], 'folded': []}
         for k in range(a.draws):
             mo = oracle.ADD(*args)
@@ -75,28 +81,90 @@ def main():
             print('  %-8s %s   ratio to fp32 oracle: %s' % (name, ' '.join('%.2e' % v for v in rows[name]),
                                                             ' '.join('%.2f' % (v / o) for v, o in zip(rows[name], rows['o32']))))
         sys.stdout.flush()
-    # frozen BatchNorm, even size: per-layer ratio of the conv-weight gradient errors
+    # Where does the FORWARD pass start to differ?  After one train-mode forward every BatchNorm's running_mean / running_var
+    # carries its batch statistics: per layer (network order), the error of those statistics against fp64, addk vs fp32 oracle.
     os.environ['ADDK_BN_CENTERED'] = '1'
-    hw = (64, 128)
-    for k in range(min(2, a.draws)):
-        mo = oracle.ADD(*args)
-        fill_params(mo, 600 + k)
-        m64 = oracle.ADD(*args); m64.load_state_dict(mo.state_dict()); m64.double()
-        ma = ADD(*args); ma.load_state_dict(mo.state_dict()); ma.to(dev)
-        x = rand_tensor(170 + k, 'spread_x', (2, 3) + hw)
-        t = target(hw, 180 + 2 * k)
-        g64, g32, ga = grads_of(m64, x.double(), t, False), grads_of(mo, x, t, False), grads_of(ma, x.to(dev), t.to(dev), False)
-        groups = {}
-        for n in g64:
-            if g64[n].dim() != 4:
-                continue
-            key = '.'.join(n.split('.')[:2]) if n.startswith('cells.') else n.split('.')[0]
-            groups.setdefault(key, []).append((rel_err(ga[n], g64[n]), rel_err(g32[n], g64[n])))
-        print('frozen BatchNorm at %dx%d draw %d: whole-net rel-L2 addk %.2e  fp32 oracle %.2e' % (hw + (k, rel_l2(ga, g64), rel_l2(g32, g64))))
-        for key in sorted(groups):
-            ea, eo = max(v[0] for v in groups[key]), max(v[1] for v in groups[key])
-            print('  %-16s n=%3d  addk %.2e  fp32 oracle %.2e  ratio %.2f' % (key, len(groups[key]), ea, eo, ea / max(eo, 1e-30)))
-        sys.stdout.flush()
+    for hw in ((64, 128), (65, 129)):
+        for k in range(min(2, a.draws)):
+            mo = oracle.ADD(*args)
+            fill_params(mo, 600 + k)
+            m64 = oracle.ADD(*args); m64.load_state_dict(mo.state_dict()); m64.double()
+            ma = ADD(*args); ma.load_state_dict(mo.state_dict()); ma.to(dev)
+            x = rand_tensor(170 + k, 'spread_x', (2, 3) + hw)
+            for m, xx in ((mo, x), (m64, x.double()), (ma, x.to(dev))):
+                m.train()
+                with torch.no_grad():
+                    m(xx)
+            s64, s32, sa = m64.state_dict(), mo.state_dict(), ma.state_dict()
+            print('running statistics after one train-mode forward at %dx%d draw %d (max-abs error / max-abs value, per BatchNorm in module order)' % (hw + (k,)))
+            groups = {}
+            for n in s64:
+                if not n.endswith('running_var'):
+                    continue
+                key = '.'.join(n.split('.')[:2]) if n.startswith('cells.') else n.split('.')[0]
+                groups.setdefault(key, []).append((rel_err(sa[n], s64[n]), rel_err(s32[n], s64[n])))
+            for key in groups:
+                ea = sorted(v[0] for v in groups[key]); eo = sorted(v[1] for v in groups[key])
+                print('  %-16s n=%3d  running_var: addk max %.2e med %.2e | fp32 oracle max %.2e med %.2e | ratio max %.2f med %.2f' % (
+                    key, len(ea), ea[-1], ea[len(ea) // 2], eo[-1], eo[len(eo) // 2], ea[-1] / max(eo[-1], 1e-30), ea[len(ea) // 2] / max(eo[len(eo) // 2], 1e-30)))
+            if a.detail and hw == (64, 128) and k == 0:
+                for n in s64:
+                    if n.endswith('running_var') and (n.startswith('cells.0.') or n.startswith('cells.1.') or n.startswith('cells.2.') or n.startswith('cells.3.')):
+                        nm = n.replace('running_var', 'running_mean')
+                        print('    %-44s var addk %.2e o32 %.2e | mean addk %.2e o32 %.2e' % (
+                            n[:-12], rel_err(sa[n], s64[n]), rel_err(s32[n], s64[n]), rel_err(sa[nm], s64[nm]), rel_err(s32[nm], s64[nm])))
+            sys.stdout.flush()
+            del ma
+
+
+def layer_trace(args, hw, k, dev):
+    """Raw conv outputs (the tensors entering each BatchNorm) of one train-mode forward, addk and fp32 oracle against fp64, in
+    execution order: where does addk's error leave the oracle's?"""
+    import addk.plan as P
+    from addk.modeling.ADD import ADD
+    mo = oracle.ADD(*args)
+    fill_params(mo, 600 + k)
+    m64 = oracle.ADD(*args); m64.load_state_dict(mo.state_dict()); m64.double()
+    ma = ADD(*args); ma.load_state_dict(mo.state_dict()); ma.to(dev)
+    x = rand_tensor(170 + k, 'spread_x', (2, 3) + hw)
+    caps = {}
+    for tag, m in (('o32', mo), ('o64', m64)):
+        names = {mod: n for n, mod in m.named_modules()}
+        store = caps.setdefault(tag, [])
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.register_forward_pre_hook(lambda md, inp, store=store, names=names: store.append((names[md], inp[0].detach().double())))
+        m.train()
+        with torch.no_grad():
+            m(x if tag == 'o32' else x.double())
+    P.TRACE_BN = []
+    ma.train()
+    with torch.no_grad():
+        ma(x.to(dev))
+    torch.cuda.synchronize()
+    names = {mod: n for n, mod in ma.named_modules()}
+    got = [(names[mod], raw.view().permute(0, 3, 1, 2).double().cpu()) for mod, raw in P.TRACE_BN]
+    P.TRACE_BN = None
+    # addk emits in its own order: match by (module name, occurrence)
+    def index(lst):
+        seen, out = {}, {}
+        for n, t in lst:
+            i = seen.get(n, 0); seen[n] = i + 1
+            out[(n, i)] = t
+        return out
+    ia, i32 = index(got), index(caps['o32'])
+    print('raw conv outputs entering each BatchNorm, train-mode forward at %dx%d draw %d: L2-relative error vs fp64' % (hw + (k,)))
+    seen = {}
+    for n, t64 in caps['o64']:
+        i = seen.get(n, 0); seen[n] = i + 1
+        a_, o_ = ia.get((n, i)), i32[(n, i)]
+        if a_ is None or tuple(a_.shape) != tuple(t64.shape):
+            print('  %-44s (no addk match)' % n)
+            continue
+        den = float(t64.norm())
+        ea, eo = float((a_ - t64).norm()) / den, float((o_ - t64).norm()) / den
+        print('  %-44s %-18s addk %.2e  fp32 oracle %.2e  ratio %.2f' % (n, 'x'.join(str(v) for v in t64.shape[1:]), ea, eo, ea / max(eo, 1e-30)))
+    sys.stdout.flush()
 
 
 if __name__ == '__main__':
