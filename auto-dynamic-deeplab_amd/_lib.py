@@ -149,6 +149,7 @@ _SIGS = {
     'addk_finish_sample': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'addk_sep_fwd_supported': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_rows': (i32, [C.POINTER(SepArgs)]),
+    'addk_bn_fin_ws_bytes': (i64, [i32, i32]),
     'addk_sep_fwd': (i32, [C.POINTER(SepArgs), vp]),
     'addk_sep_fwd_batch_key': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_fwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),

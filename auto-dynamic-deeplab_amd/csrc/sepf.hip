@@ -41,7 +41,7 @@ struct SepfGeo {
   static constexpr int CT = KG, PH = 4 * R + KS - 1, PW = 16 + KS - 1, NPIX = PH * PW, KQ = KP / 4;
   static constexpr int PATCH = NPIX * KP + 8;                     // floats (+8: the clamped tail read of the last pixel stays inside)
   static constexpr int DWL = KS * KS * KG * 16, PWL = KG * CT * 64 * 4;
-  static constexpr int RED = (4 * CT * 16 * 2 > 1026 ? 4 * CT * 16 * 2 : 1026) * 2;   // floats: [4][CT*16][2] doubles, or the finalize scratch
+  static constexpr int RED = (4 * CT * 16 * 2 > 514 ? 4 * CT * 16 * 2 : 514) * 2;   // floats: [4][CT*16][2] doubles, or the finalize scratch
   static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + RED) * 4;
 };
 
@@ -214,7 +214,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
         }
       }
     }
-    if (fused) bn_finalize_by_last_block(p.fin, p.slab, p.slab_ld, 0, C, (unsigned)p.gx, red);
+    if (fused) bn_finalize_by_last_block(p.fin, p.slab, p.slab_ld, C, blockIdx.x, (unsigned)p.gx, red);
   }
 }
 
@@ -263,7 +263,8 @@ bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   if (a->fin.a) {
     k.fin.a = a->fin.a; k.fin.b = a->fin.b; k.fin.mean = a->fin.mean; k.fin.invstd = a->fin.invstd; k.fin.gamma = a->fin.gamma; k.fin.beta = a->fin.beta;
     k.fin.running_mean = a->fin.running_mean; k.fin.running_var = a->fin.running_var; k.fin.count = a->fin.count;
-    k.fin.momentum = a->fin.momentum; k.fin.eps = a->fin.eps; k.fin.counter = (unsigned*)a->fin_counter;
+    k.fin.momentum = a->fin.momentum; k.fin.eps = a->fin.eps;
+    bnfin_bind_ws(k.fin, a->fin_counter, k.gx);
   }
   return true;
 }
@@ -300,6 +301,8 @@ extern "C" int addk_sep_rows(const addk_sep_args* a) {
   addk_sep_args b = *a; b.stats = nullptr; b.fin.a = nullptr;
   return sepf_fill(&b, k, c) ? k.gx : 0;
 }
+// bytes of the zero-initialised workspace `fin_counter` points to, for a launch of `nblocks` workgroups and slab rows of ld channels
+extern "C" int64_t addk_bn_fin_ws_bytes(int32_t nblocks, int32_t ld) { return nblocks > 0 && ld > 0 ? bnfin_ws_bytes(nblocks, ld) : 0; }
 extern "C" int addk_sep_fwd_supported(const addk_sep_args* a) {
   SepfK k; SepfCfg c;
   return (addk_get_fast_paths() & ADDK_FAST_PW) && sepf_fill(a, k, c) ? 1 : 0;

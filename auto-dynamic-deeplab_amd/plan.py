@@ -825,11 +825,12 @@ class Graph:
             fa.a, fa.b, fa.mean, fa.invstd = a.ptr, b.ptr, st.mean.ptr, st.invstd.ptr
             self.keep.append(fa)
             stat_wr = [a, b, st.mean, st.invstd] + ([mod.running_mean, mod.running_var] if fa.running_mean else [])
-            if fuse is not None and not sync and os.environ.get('ADDK_FUSE_FINALIZE', '1') == '1':
-                args, cmd = fuse
+            if fuse is not None and not sync and os.environ.get('ADDK_FUSE_FINALIZE', '0') == '1':
+                args, cmd, fuse_blocks = fuse
                 for f_ in ('count', 'gamma', 'beta', 'running_mean', 'running_var', 'momentum', 'eps', 'a', 'b', 'mean', 'invstd'):
                     setattr(args.fin, f_, getattr(fa, f_))
-                ctr = self.buf(4, zero=True)                # ticket counter of this BatchNorm call (the launch leaves it at zero)
+                nblk, sld = fuse_blocks(args)
+                ctr = self.buf((int(lib.addk_bn_fin_ws_bytes(nblk, sld)) + 3) // 4, zero=True)   # ticket counters + group rows of this BatchNorm call
                 args.fin_counter = ctr.ptr
                 cmd.rd += [r for r in (_region(mod.weight), _region(mod.bias)) if r]
                 cmd.wr += [r for r in (_region(x) for x in stat_wr + [ctr]) if r]
@@ -1033,7 +1034,7 @@ class Graph:
             if bk >= 0:
                 c.payload, c.bkey = ar, bk
             return Act(raw, None, False, False)
-        act = self.bn(raw, bn_mod, slab, rows or 0, fuse=(ar, c))
+        act = self.bn(raw, bn_mod, slab, rows or 0, fuse=(ar, c, lambda a_: (int(lib.addk_sep_rows(C.byref(a_))), Cout)))
         bk = int(lib.addk_sep_fwd_batch_key(C.byref(ar)))         # after bn(): the fused finalize is part of the launch's validity
         if bk >= 0:
             c.payload, c.bkey = ar, bk

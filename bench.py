@@ -408,11 +408,15 @@ def main():
             assert rel <= 1e-3, 'first-step loss %.7f differs from the CPU oracle %.7f on the same inputs (rel %.2e)' % (losses[0], ref, rel)
             if len(losses) > 1 and cb.get('second_step_loss') is not None:
                 # the second step's loss has been through one whole backward pass + SGD update of every parameter: the full-size
-                # gradient check of the headline shape (measured 6.8e-5 in round 2)
+                # backward / optimizer check of the headline shape.  The bound is 5e-3, not 1e-3: with random-init weights the
+                # train-mode network amplifies a 3e-8 forward perturbation (another summation order of one BatchNorm's statistics)
+                # to 2e-4 at the decoder and 3e-2 in the gradients (scripts/ab_sep_fwd.py, scripts/ab_sep.py), which moves this
+                # loss by 1e-4 .. 1.3e-3 between builds that are each correct to rounding (measured 6.8e-5, 1.1e-4, 1.24e-3); a
+                # missing or wrong update is 1.8e-2 away (the loss does not move without the step)
                 ref2 = cb['second_step_loss']
                 rel2 = abs(losses[1] - ref2) / abs(ref2)
                 out['first_step_loss_vs_cpu_oracle']['second_step'] = {'gpu': losses[1], 'cpu_oracle': ref2, 'rel_diff': rel2}
-                assert rel2 <= 1e-3, 'second-step loss %.7f differs from the CPU oracle %.7f (rel %.2e): backward / SGD parity' % (losses[1], ref2, rel2)
+                assert rel2 <= 5e-3, 'second-step loss %.7f differs from the CPU oracle %.7f (rel %.2e): backward / SGD parity' % (losses[1], ref2, rel2)
     json_out.write(json.dumps(out) + '\n')
     json_out.flush()
     if comm is not None:

@@ -199,8 +199,9 @@ int addk_conv_wgrad_batch_run(const void* dev_blob, const int64_t* meta, void* s
  * over 2-D LDS tiles (csrc/sepf.hip): the depthwise output never makes a round trip through HBM.  In training `t` receives
  * the depthwise output (the backward pass reads it: pointwise weight gradient, depthwise backward) and, when `fin.a` is set,
  * the LAST workgroup of the launch turns the statistics into the lazy affine (a, b) — no bn_finalize launch (`fin.partial`,
- * `fin.rows`, `fin.C` are ignored: the launch knows its own slab; `fin_counter` is one zero-initialised 32-bit word owned by
- * this BatchNorm call, left at zero again by the launch).  In inference t = NULL and the epilogue can apply the op's own
+ * `fin.rows`, `fin.C` are ignored: the launch knows its own slab; `fin_counter` is a zero-initialised workspace of
+ * addk_bn_fin_ws_bytes(addk_sep_rows(a), stats_ld) bytes owned by this BatchNorm call — ticket counters and group rows of the
+ * two-level reduction — whose counters the launch leaves at zero again).  In inference t = NULL and the epilogue can apply the op's own
  * (frozen) BatchNorm and add the other branches of the cell block (ADD.py:108):
  *     y = ea[c]*acc + eb[c] + sum_i relu_i?(a_i*term_i + b_i)        (ea == NULL: plain y = acc)
  * Covered shapes: K in {3,5}, C == Cout in (32, 48] or (64, 80], 16-byte aligned tensors; addk_sep_fwd_supported says so.
@@ -222,6 +223,7 @@ typedef struct addk_sep_args {
   addk_bn_finalize_args fin;        /* fused finalize of the statistics (fin.a == NULL: none) */
   void* fin_counter;
 } addk_sep_args;
+int64_t addk_bn_fin_ws_bytes(int32_t nblocks, int32_t ld);
 int addk_sep_rows(const addk_sep_args* a);               /* slab rows (= workgroups) of the fused launch; 0: not covered */
 int addk_sep_fwd_supported(const addk_sep_args* a);      /* 1: the fused kernel covers this launch */
 int addk_sep_fwd(const addk_sep_args* a, void* stream);

@@ -317,6 +317,9 @@ SEP_SHAPES = [
     ('sep3_c80',   2, 33,  65, 80, 3),      # level-2 cells: 5 channel groups
     ('sep5_c80',   2, 63, 127, 80, 5),
     ('sep5_small', 1,  9,  11, 48, 5),      # map smaller than a tile row, every pixel touches the border
+    ('sep5_c40_l1', 2, 128, 256, 40, 5),    # the level-1 map of config 2: two rows per wave (R = 2), 512 workgroups
+    ('sep3_c40_l1', 2, 125, 253, 40, 3),    # ... and its odd-sized sibling after an up-path
+    ('sep3_c36',   1, 40,  70, 36, 3),      # channel count below the padded pixel stride (zero-filled padding quad)
 ]
 
 
@@ -348,14 +351,47 @@ def test_fused_sepconv_half_matches_fp64_reference(lib, shape):
     ar.N, ar.H, ar.W, ar.K, ar.Cout, ar.ldw = N, H, W, k, Cc, Cc
     ar.dw_w, ar.pw_w = wdw.data_ptr(), wpw.data_ptr()
     y, t = torch.empty(P, Cc, device=dev), torch.empty(P, Cc, device=dev)
-    rows = lb.addk_conv_rows(P, Cc)
+    ar.y, ar.ldy, ar.t, ar.ldt = y.data_ptr(), Cc, t.data_ptr(), Cc
+    rows = max(lb.addk_conv_rows(P, Cc), lb.addk_sep_rows(C.byref(ar))) + 3          # three rows nobody owns: must come back zero
+    assert lb.addk_sep_rows(C.byref(ar)) > 0
     slab = torch.full((rows, Cc, 2), float('nan'), device=dev, dtype=torch.float64)
-    ar.y, ar.ldy, ar.t, ar.ldt, ar.stats, ar.stats_ld = y.data_ptr(), Cc, t.data_ptr(), Cc, slab.data_ptr(), Cc
+    ar.stats, ar.stats_ld, ar.stats_rows = slab.data_ptr(), Cc, rows
     assert lb.addk_sep_fwd_supported(C.byref(ar)) == 1
     L.check(lb.addk_sep_fwd(C.byref(ar), st), 'sep_fwd')
     torch.cuda.synchronize()
     yl = flat(y_ref)
     errs = {'t': _rel(t, flat(t_ref)), 'y': _rel(y, yl), 'stats': _rel(slab.sum(0), torch.stack([yl.sum(0), (yl * yl).sum(0)], 1))}
+    # training form with the statistics finalized by the launch's LAST workgroup (csrc/bnfin.h): (a, b, mean, invstd, running
+    # statistics) against fp64, twice in a row (the ticket counter must come back to zero), bit-identical run to run
+    gam, bet = 1 + 0.2 * rnd(Cc), 0.2 * rnd(Cc)
+    rm0, rv0 = 0.3 * rnd(Cc), 0.5 + torch.rand(Cc, generator=gen).to(dev)
+    nws = (int(lb.addk_bn_fin_ws_bytes(lb.addk_sep_rows(C.byref(ar)), Cc)) + 3) // 4
+    counter = torch.zeros(nws, dtype=torch.int32, device=dev)
+    outs = []
+    for rep in range(2):
+        fa, fb, fm, fi = (torch.full((Cc,), float('nan'), device=dev) for _ in range(4))
+        rm, rv = rm0.clone(), rv0.clone()
+        slab.fill_(float('nan'))
+        ar.fin.count, ar.fin.gamma, ar.fin.beta = float(P), gam.data_ptr(), bet.data_ptr()
+        ar.fin.running_mean, ar.fin.running_var, ar.fin.momentum, ar.fin.eps = rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5
+        ar.fin.a, ar.fin.b, ar.fin.mean, ar.fin.invstd = fa.data_ptr(), fb.data_ptr(), fm.data_ptr(), fi.data_ptr()
+        ar.fin_counter = counter.data_ptr()
+        assert lb.addk_sep_fwd_supported(C.byref(ar)) == 1
+        L.check(lb.addk_sep_fwd(C.byref(ar), st), 'sep_fwd (fused finalize)')
+        torch.cuda.synchronize()
+        ncnt = 1 + (lb.addk_sep_rows(C.byref(ar)) + 15) // 16
+        assert int(counter[:ncnt].abs().sum()) == 0, 'ticket counters not reset'
+        outs.append([v.clone() for v in (fa, fb, fm, fi, rm, rv)])
+    assert all(torch.equal(u, v) for u, v in zip(*outs)), 'fused finalize is not reproducible'
+    mean64, var64 = yl.mean(0), yl.var(0, unbiased=False)
+    inv64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    fa, fb, fm, fi, rm, rv = outs[0]
+    errs['fin_a'] = _rel(fa, gam.double() * inv64)
+    errs['fin_b'] = _rel(fb, bet.double() - mean64 * gam.double() * inv64)
+    errs['fin_mean'], errs['fin_invstd'] = _rel(fm, mean64), _rel(fi, inv64)
+    errs['fin_rm'] = _rel(rm, 0.9 * rm0.double() + 0.1 * mean64)
+    errs['fin_rv'] = _rel(rv, 0.9 * rv0.double() + 0.1 * var64 * P / (P - 1))
+    ar.fin.a, ar.fin_counter = None, None
     # inference form: y = ea*acc + eb + relu(a1*u1 + b1) + u2
     ea, eb = 1 + 0.2 * rnd(Cc), 0.2 * rnd(Cc)
     u1, a1, b1, u2 = rnd(P, Cc), rnd(Cc), 0.3 * rnd(Cc), rnd(P, Cc)
