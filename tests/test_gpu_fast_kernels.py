@@ -27,7 +27,13 @@ SHAPES = [
     ('cell_dil5_80',   2, 63, 127, (80,), 80, 2, 5),       # level 2 (5 column tiles)
     ('cell_dil3_40',   1, 70, 125, (40,), 40, 2, 3),       # dil_conv_3x3
     ('cell_dil3_160',  2, 40, 104, (32,), 160, 2, 3),      # two 5-tile column blocks
+    # the wide pointwise heads on the split kernel as a plain GEMM (KS = 1, conv3.hip c3_geometry_ok): ASPP 1x1 400 -> 256 and the
+    # 1280 -> 256 concat conv, whose image-pool branch enters as a per-image bias (aspp_train.py:44-58)
+    ('pw_aspp_400',    2, 64, 128, (400,), 256, 1, 1),
+    ('pw_cat_1024',    1, 64, 128, (256, 256, 256, 256), 256, 1, 1),
+    ('pw_odd_208',     2, 33,  65, (208,), 192, 1, 1),     # odd map, 192 output channels (the narrowest shape that takes this path)
 ]
+BIAS_N = {'pw_cat_1024', 'pw_odd_208'}
 
 
 @pytest.fixture(scope='module')
@@ -76,8 +82,10 @@ def _run(L, fast, shape, data, prec='fp32'):
     rows = lib.addk_conv_rows(P, Cout)
     slab = torch.zeros(rows, Cout, 2, device=dev, dtype=torch.float64)
     ar.w, ar.y, ar.stats, ar.stats_ld = data['w'].data_ptr(), y.data_ptr(), slab.data_ptr(), Cout
+    if 'bias_n' in data:
+        ar.bias_n = data['bias_n'].data_ptr()
     npk = int(lib.addk_conv_fwd_pack_floats(C.byref(ar)))
-    assert (npk > 0) == bool(fast & 2), 'forward: halo-patch kernel coverage (%d floats, mask %d)' % (npk, fast)
+    assert (npk > 0) == (bool(fast & 2) and not (ks == 1 and prec == 'fp32')), 'forward: halo-patch kernel coverage (%d floats, mask %d)' % (npk, fast)
     if npk:
         wp = torch.empty(npk, device=dev); keep.append(wp)
         ar.wpack, ar.wpack_floats = wp.data_ptr(), npk
@@ -129,6 +137,8 @@ def _reference(shape, data):
     z = torch.cat([F.relu(a.view(1, -1, 1, 1) * x + b.view(1, -1, 1, 1)) for x, a, b in zip(xs, as_, bs)], 1)
     w = data['w'].double().view(Cout, ks, ks, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
     y = F.conv2d(z, w, padding=dil * (ks // 2), dilation=dil)
+    if 'bias_n' in data:
+        y = y + data['bias_n'].double().view(N, Cout, 1, 1)
     dy = data['dy'].double().view(N, H, W, Cout).permute(0, 3, 1, 2)
     y.backward(dy)
     yl = y.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
@@ -150,6 +160,8 @@ def test_halo_patch_kernels_match_fp64_reference_and_generic(lib, shape, prec):
     P = N * H * W
     data = {'x': [rnd(P, c) for c in Cs], 'a': [rnd(c) for c in Cs], 'b': [0.3 * rnd(c) for c in Cs],
             'w': 0.1 * rnd(Cout, ks * ks * sum(Cs)), 'dy': rnd(P, Cout)}
+    if name in BIAS_N:
+        data['bias_n'] = rnd(N, Cout)
     ref = _reference(shape, data)
     fast = _run(lib, FAST_ALL, shape, data, prec)
     slow = _run(lib, 0, shape, data)

@@ -1,0 +1,261 @@
+"""GPU parity added in round 3:
+
+ * stem0_kernel (3-channel stride-2 conv of the image, ADD.py:153-157) directly through the C ABI against fp64;
+ * config 2 at its real shape with BatchNorm FROZEN: conv-weight gradients of a sentinel set (stems, one cell per level, ASPP,
+   decoder) against an fp64 evaluation of the oracle — the backward check at the headline shape without train-mode amplification;
+ * mIoU parity on fixed weights (north_star: "mIoU within 0.05"; utils/metrics.py:18-23, eval.py:183-193,218-224): addk and oracle
+   predictions through `Evaluator`, config 2 static (both exits) and config 4 dynamic at 0 / 50 / 100 % early exits;
+ * the O1-like fast arithmetic `bf16x3` at network level (F=40 genotype_1: eval logits, frozen-BN gradients, one train step);
+ * config 5's architecture (F=40) at 2x1024x2048: eval logits and first-step training loss against the CPU oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import oracle                       # noqa: E402  (the checker)
+from _util import ARCH_C2, GENOTYPE_AUTODEEPLAB, fill_params, make_args, rand_tensor, rel_err   # noqa: E402
+from test_gpu_configs import _build, _geno, _target, _bench_model   # noqa: E402
+
+REPORT = []
+
+
+def _log(fmt, *a):
+    REPORT.append(fmt % a)
+
+
+def teardown_module(module):
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/parity_report_round3.txt', 'w') as f:
+        f.write('\n'.join(REPORT) + '\n')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    import addk
+    addk.load()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('shape', [(2, 70, 126), (1, 65, 129), (2, 33, 34)], ids=['even', 'odd', 'small'])
+def test_stem0_kernel_matches_fp64_reference(dev, shape):
+    """conv3x3 stride 2 pad 1, 3 -> 64 channels, pixel stride 4 (the staged image), statistics slab: the stem0_kernel path of
+    addk_conv_fwd against F.conv2d in fp64, and bit-identical to itself run to run."""
+    import addk._lib as L
+    lb = L.load()
+    N, H, W = shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    gen = torch.Generator().manual_seed(N * 1000 + H)
+    x = torch.randn(N, H, W, 4, generator=gen).to(dev)
+    x[..., 3] = float('nan')                                   # the padding channel must never be read into the sum
+    w = (0.3 * torch.randn(64, 3, 3, 3, generator=gen)).to(dev)           # [O][KH][KW][I]
+    ar = L.ConvArgs()
+    ar.src[0].x, ar.src[0].ld, ar.src[0].C = x.data_ptr(), 4, 3
+    ar.nsrc, ar.N, ar.H, ar.W, ar.OH, ar.OW, ar.KH, ar.KW, ar.stride, ar.pad, ar.dil = 1, N, H, W, OH, OW, 3, 3, 2, 1, 1
+    ar.Cout, ar.ldw, ar.cin_total, ar.ldy, ar.w = 64, 27, 3, 64, w.data_ptr()
+    P = N * OH * OW
+    rows = lb.addk_conv_rows(P, 64)
+    outs = []
+    for rep in range(2):
+        y = torch.full((P, 64), float('nan'), device=dev)
+        slab = torch.full((rows, 64, 2), float('nan'), device=dev, dtype=torch.float64)
+        ar.y, ar.stats, ar.stats_ld = y.data_ptr(), slab.data_ptr(), 64
+        L.check(lb.addk_conv_fwd(C.byref(ar), torch.cuda.current_stream().cuda_stream), 'conv_fwd(stem0)')
+        torch.cuda.synchronize()
+        outs.append((y, slab.sum(0)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = F.conv2d(x[..., :3].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=2, padding=1)
+    yl = ref.permute(0, 2, 3, 1).reshape(P, 64)
+    e_y = float((outs[0][0].double() - yl).abs().max() / yl.abs().max())
+    st = torch.stack([yl.sum(0), (yl * yl).sum(0)], 1)
+    e_s = float((outs[0][1] - st).abs().max() / st.abs().max())
+    _log('stem0_kernel %s: y %.2e  statistics %.2e', shape, e_y, e_s)
+    assert e_y <= 2e-6 and e_s <= 2e-6
+
+
+def test_full_size_frozen_bn_gradients_on_sentinel_convs(dev):
+    """BASELINE config 2 at 2x1024x2048, BatchNorm frozen (eval mode), CE loss over both exits, backward: the conv-weight
+    gradients of a sentinel set spread over the network against an fp64 evaluation of the oracle, relative to the fp32 oracle's
+    own error (frozen BatchNorm removes the train-mode amplification, so this is a meaningful elementwise check)."""
+    hw = (1024, 2048)
+    ma, mo = _bench_model(dev, seed=3)
+    sentinels = ['stem1.0.weight', 'stem2.1.weight', 'cells.0._ops.1.op.2.weight', 'cells.0._ops.0.op.1.weight',
+                 'cells.3._ops.6.op.1.weight', 'cells.4.preprocess.conv_1.weight', 'cells.7.pre_preprocess_1x1.op.1.weight',
+                 'cells.11._ops.9.op.6.weight', 'low_level_conv.1.weight', 'aspp.aspp3.weight', 'aspp.conv1.weight',
+                 'decoder._conv.1.weight', 'decoder._conv.4.weight', 'decoder._conv.7.weight']
+    x = rand_tensor(203, 'full_frozen_x', (2, 3) + hw)
+    tgt = _target(hw, seed=66)
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    ma.eval(); mo.eval()
+    (sum(crit(y, tgt.to(dev)) for y in ma(x.to(dev))) / 2).backward()
+    torch.cuda.synchronize()
+    ga = {k: p.grad.detach().double().cpu() for k, p in ma.named_parameters() if k in sentinels}
+    del ma
+    torch.cuda.empty_cache()
+    for p in mo.parameters():
+        p.requires_grad_(False)
+    po = dict(mo.named_parameters())
+    for k in sentinels:
+        po[k].requires_grad_(True)
+    (sum(crit(y, tgt) for y in mo(x)) / 2).backward()
+    g32 = {k: po[k].grad.detach().double() for k in sentinels}
+    m64 = mo.double()
+    for k in sentinels:
+        po[k].grad = None
+    (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
+    worst = 0.0
+    for k in sentinels:
+        g64 = po[k].grad.detach()
+        ea, eo = rel_err(ga[k], g64), rel_err(g32[k], g64)
+        worst = max(worst, ea / max(eo, 1e-30))
+        _log('config2 2x1024x2048 frozen-BN gradient %-44s addk %.2e  fp32 oracle %.2e  ratio %.2f', k, ea, eo, ea / max(eo, 1e-30))
+        assert ea <= max(4 * eo, 1e-3), (k, ea, eo)
+    _log('config2 2x1024x2048 frozen-BN sentinel gradients: worst ratio to the fp32 oracle %.2f', worst)
+
+
+def _structured_images(n, hw, seed):
+    """Smooth random fields + a little noise: predictions get spatial structure (regions), like a street scene, not salt-and-pepper."""
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.randn(n, 3, hw[0] // 32 + 2, hw[1] // 32 + 2, generator=g)
+    x = F.interpolate(lo, size=hw, mode='bilinear', align_corners=False) * 1.5 + 0.15 * torch.randn(n, 3, *hw, generator=g)
+    return x
+
+
+def test_miou_parity_static_and_dynamic(dev):
+    """mIoU of addk's predictions equals the oracle's on fixed weights (north_star: within 0.05).  Labels are the oracle's own
+    final-exit argmax with 5 % ignore pixels and a band of wrong labels, so that neither exit scores a trivial 1.0."""
+    from addk.metrics import Evaluator, argmax_logits
+    from addk.modeling.ADD import EDM
+    ma, mo = _bench_model(dev, seed=4)
+    ma.eval(); mo.eval()
+    hw = (513, 1025)
+    imgs = _structured_images(8, hw, 77)
+    ev = {k: Evaluator(19, device=dev) for k in ('addk0', 'addk1', 'orc0', 'orc1')}
+    labels = []
+    agree = [0, 0, 0]
+    with torch.no_grad():
+        for b in range(0, 8, 2):
+            x = imgs[b:b + 2]
+            yo = mo(x)
+            ya = ma(x.to(dev))
+            lab = yo[-1].argmax(1)
+            r = np.random.default_rng(500 + b)
+            lab[torch.from_numpy(r.random(lab.shape) < 0.05)] = 255
+            lab[:, 100:140, :] = (lab[:, 100:140, :] + 3) % 19            # a band of wrong labels
+            labels.append(lab)
+            for i in range(2):
+                pa, po = argmax_logits(ya[i]), yo[i].argmax(1).to(dev)
+                ev['addk%d' % i].add_batch(lab.to(dev), pa)
+                ev['orc%d' % i].add_batch(lab.to(dev), po)
+                agree[i] += int((pa == po).sum())
+            agree[2] += lab.numel()
+    for i in range(2):
+        ma_, mo_ = ev['addk%d' % i].Mean_Intersection_over_Union(), ev['orc%d' % i].Mean_Intersection_over_Union()
+        _log('mIoU config 2 static exit %d over 8 images %dx%d: addk %.6f  oracle %.6f  |diff| %.2e  argmax agreement %.6f', i, hw[0], hw[1],
+             ma_, mo_, abs(ma_ - mo_), agree[i] / agree[2])
+        assert abs(ma_ - mo_) <= 5e-4, (i, ma_, mo_)                      # 0.05 mIoU points; north_star's bound is 0.05
+        assert 0.02 < mo_ < 0.999
+    # config 4: EDM-gated dynamic inference, bs = 1, thresholds that send 0 %, 50 %, 100 % of the images to the early exit
+    eo = oracle.EDM(); fill_params(eo, 701)
+    ea = EDM(); ea.load_state_dict(eo.state_dict()); ea.to(dev).eval(); eo.eval()
+    confs = []
+    with torch.no_grad():
+        for k in range(8):
+            confs.append(float(mo.dynamic_inference(imgs[k:k + 1], threshold=1e9, confidence='edm', edm=eo)[3]))
+    srt = sorted(confs)
+    for frac, thr in (('0%', srt[0] - 1.0), ('50%', 0.5 * (srt[3] + srt[4])), ('100%', srt[-1] + 1.0)):
+        e_a, e_o = Evaluator(19, device=dev), Evaluator(19, device=dev)
+        n_early = [0, 0]
+        with torch.no_grad():
+            for k in range(8):
+                x = imgs[k:k + 1]
+                lab = labels[k // 2][k % 2:k % 2 + 1].to(dev)
+                ya, ea_, _, _ = ma.dynamic_inference(x.to(dev), threshold=thr, confidence='edm', edm=ea)
+                yo, eo_, _, _ = mo.dynamic_inference(x, threshold=thr, confidence='edm', edm=eo)
+                assert ea_ == eo_, 'gate decisions differ at threshold %r (image %d)' % (thr, k)
+                n_early[0] += ea_; n_early[1] += eo_
+                e_a.add_batch(lab, argmax_logits(ya)); e_o.add_batch(lab, yo.argmax(1).to(dev))
+        ma_, mo_ = e_a.Mean_Intersection_over_Union(), e_o.Mean_Intersection_over_Union()
+        _log('mIoU config 4 dynamic, %s early exits (%d of 8): addk %.6f  oracle %.6f  |diff| %.2e', frac, n_early[0], ma_, mo_, abs(ma_ - mo_))
+        assert abs(ma_ - mo_) <= 5e-4, (frac, ma_, mo_)
+    assert True
+
+
+def test_bf16x3_whole_network_parity(dev):
+    """The 3-term split-bf16 mode (`bf16x3`: the O1 analogue of train.py:145-165 — 16-bit products on the matrix pipe, fp32
+    accumulation and BatchNorm statistics, fp32 master weights) at NETWORK level on config 5's architecture: eval logits within
+    1e-3 of the oracle, frozen-BN conv-weight gradients at 2x256x512 within 6x the fp32 oracle's own error against fp64, one
+    train-mode step's loss within 1e-4 of the oracle's."""
+    import addk
+    try:
+        addk.set_precision('bf16x3')
+        hw = (256, 512)
+        ma, mo, _, args = _build(dev, 40, ARCH_C2, _geno('genotype_1'), seed=900)
+        x = rand_tensor(61, 'f40_frozen_x', (2, 3) + hw)
+        tgt = _target(hw)
+        crit = nn.CrossEntropyLoss(ignore_index=255)
+        ma.eval(); mo.eval()
+        ya, yo = ma(x.to(dev)), mo(x)
+        for i, (a, o) in enumerate(zip(ya, yo)):
+            e = rel_err(a, o)
+            _log('bf16x3 F40_g1 256x512 eval exit %d vs oracle %.3e', i, e)
+            assert e <= 1e-3
+        (sum(crit(y, tgt.to(dev)) for y in ya) / 2).backward()
+        (sum(crit(y, tgt) for y in yo) / 2).backward()
+        m64 = oracle.ADD(*args).double()
+        m64.load_state_dict(mo.state_dict()); m64.eval()
+        (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
+        torch.cuda.synchronize()
+        pa, p64 = dict(ma.named_parameters()), dict(m64.named_parameters())
+        ours, theirs = [], []
+        for k, p in mo.named_parameters():
+            if p.dim() == 4 and p.grad is not None:
+                ours.append(rel_err(pa[k].grad.cpu().double(), p64[k].grad))
+                theirs.append(rel_err(p.grad.double(), p64[k].grad))
+        med = lambda v: sorted(v)[len(v) // 2]
+        _log('bf16x3 F40_g1 frozen-BN 256x512, %d conv-weight gradients vs fp64: addk max %.2e median %.2e | fp32 oracle max %.2e median %.2e',
+             len(ours), max(ours), med(ours), max(theirs), med(theirs))
+        assert max(ours) <= max(6 * max(theirs), 5e-3) and med(ours) <= max(6 * med(theirs), 5e-4)
+        # one train-mode step (fresh parameters: the gradient buffers above belong to the eval plan)
+        ma2, mo2, _, _ = _build(dev, 40, ARCH_C2, _geno('genotype_1'), seed=901)
+        ma2.train(); mo2.train()
+        with torch.no_grad():
+            la = sum(crit(y, tgt.to(dev)) for y in ma2(x.to(dev))) / 2
+            lo = sum(crit(y, tgt) for y in mo2(x)) / 2
+        _log('bf16x3 F40_g1 256x512 train-mode loss: addk %.7f  oracle %.7f', float(la), float(lo))
+        assert abs(float(la) - float(lo)) <= 1e-4 * abs(float(lo))
+    finally:
+        addk.set_precision('bf16x6')
+
+
+def test_config5_architecture_full_size_logits_and_first_step_loss(dev):
+    """BASELINE config 5's network (F=40, searched_arch/40_5e_38_lr/genotype_1) at its real shape 2x1024x2048 on one GPU: eval
+    logits of both exits (every 8th pixel) and the first training step's loss against the CPU oracle."""
+    hw = (1024, 2048)
+    ma, mo, _, _ = _build(dev, 40, ARCH_C2, _geno('genotype_1'), seed=910)
+    x = rand_tensor(204, 'c5_full_x', (2, 3) + hw)
+    ma.eval(); mo.eval()
+    with torch.no_grad():
+        ya = [y[:, :, ::8, ::8].cpu() for y in ma(x.to(dev))]
+        yo = [y[:, :, ::8, ::8] for y in mo(x)]
+    for i, (a, o) in enumerate(zip(ya, yo)):
+        e = rel_err(a, o)
+        _log('config5 architecture (F=40 g1) 2x1024x2048 eval logits exit %d (sub8) vs oracle %.3e', i, e)
+        assert e <= 1e-3
+    ma.train(); mo.train()
+    tgt = _target(hw, seed=68)
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    from addk.loss import CrossEntropyLoss
+    ca = CrossEntropyLoss(ignore_index=255)
+    with torch.no_grad():
+        lo = sum(crit(y, tgt) for y in mo(x)) / 2
+        la = sum(ca(y, tgt.to(dev)) for y in ma(x.to(dev))) / 2
+    _log('config5 architecture (F=40 g1) 2x1024x2048 train-mode first-step loss: oracle %.7f addk %.7f', float(lo), float(la))
+    assert abs(float(la) - float(lo)) <= 1e-4 * abs(float(lo))
