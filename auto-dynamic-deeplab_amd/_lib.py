@@ -50,6 +50,11 @@ class SepArgs(C.Structure):
                 ('term', Src * MAX_TERMS), ('fin', BnFinalizeArgs), ('fin_counter', vp)]
 
 
+class SepBwdArgs(C.Structure):
+    _fields_ = [('dy', vp), ('lddy', i32), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('src', Src), ('Cout', i32), ('ldw', i32),
+                ('dw_w', vp), ('pw_w', vp), ('g', vp), ('ldg', i32), ('accumulate', i32), ('dab', vp), ('ws', vp)]
+
+
 class CeUpsampleArgs(C.Structure):
     _fields_ = [('logits', vp), ('ld', i32), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('OH', i32), ('OW', i32),
                 ('target', vp), ('class_w', vp), ('ignore_index', i32), ('wsum', vp), ('scale', f32), ('loss_out', vp),
@@ -150,6 +155,11 @@ _SIGS = {
     'addk_sep_fwd_supported': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_rows': (i32, [C.POINTER(SepArgs)]),
     'addk_bn_fin_ws_bytes': (i64, [i32, i32]),
+    'addk_sep_bwd_rows': (i32, [C.POINTER(SepBwdArgs)]),
+    'addk_sep_bwd': (i32, [C.POINTER(SepBwdArgs), vp]),
+    'addk_sep_bwd_batch_key': (i32, [C.POINTER(SepBwdArgs)]),
+    'addk_sep_bwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),
+    'addk_sep_bwd_batch_run': (i32, [vp, vp, vp]),
     'addk_sep_fwd': (i32, [C.POINTER(SepArgs), vp]),
     'addk_sep_fwd_batch_key': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_fwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),

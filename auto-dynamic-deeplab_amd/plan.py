@@ -365,6 +365,7 @@ class Graph:
                 'conv_fwd': ('addk_conv_fwd_batch_prepare', 'addk_conv_batch_run'), 'conv_dgrad': ('addk_conv_dgrad_batch_prepare', 'addk_conv_batch_run'),
                 'dw_fwd': ('addk_dw_fwd_batch_prepare', 'addk_dw_batch_run'), 'dw_bwd': ('addk_dw_bwd_batch_prepare', 'addk_dw_batch_run'),
                 'sep_fwd': ('addk_sep_fwd_batch_prepare', 'addk_sep_batch_run'),
+                'sep_bwd': ('addk_sep_bwd_batch_prepare', 'addk_sep_bwd_batch_run'),
                 'allreduce': (None, None)}
 
     @staticmethod
@@ -979,6 +980,66 @@ class Graph:
             self._bwd_emitters.append(emit_bwd)
         return act
 
+    def _sep_bwd(self, src, dw_mod, pw_mod, raw, t=None, probe=False):
+        """Backward of one SepConv half as ONE launch (addk_sep_bwd, csrc/sepb.hip): data gradient of the pointwise conv and the
+        whole depthwise backward, the gradient between them staying on chip; the pointwise WEIGHT gradient joins the deferred
+        weight-gradient batches.  probe=True only asks whether the kernel covers the shape."""
+        lib = self.lib
+        k = dw_mod.kernel_size[0]
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        Cout = pw_mod.out_channels
+
+        def fill(ba, dy_ptr, dy_ld):
+            ba.dy, ba.lddy = dy_ptr, dy_ld
+            ba.N, ba.H, ba.W, ba.K = N, H, W, k
+            ba.src = self.src(src, True)
+            ba.Cout, ba.ldw = Cout, Cc
+            ba.dw_w, ba.pw_w = self.param(dw_mod.weight), self.param(pw_mod.weight)
+        if probe:
+            ba = L.SepBwdArgs()
+            fill(ba, raw.ptr, raw.ld)
+            return int(lib.addk_sep_bwd_rows(C.byref(ba))) > 0
+
+        def emit_bwd():
+            if not self.grad_ready(raw):
+                return
+            dy = self.grad(raw)
+            # pointwise weight gradient: dW[co][ci] = sum_p dy[p][co] t[p][ci]
+            wa = L.ConvWgradArgs()
+            wa.dy, wa.lddy, wa.Cout = dy.ptr, dy.ld, Cout
+            wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, H, W, 1, 1, 1, 0, 1
+            wa.src = self.src(t)
+            gp, acc = self.param_grad(pw_mod.weight, (0, Cc))
+            wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = gp, Cc, Cc, 0, acc
+            wa.ws_floats = lib.addk_conv_wgrad_ws(N * H * W, Cout, Cc, 1)
+            self._wgrads.append((wa, [dy] + self.lz(t), self.pgrad[pw_mod.weight], (id(pw_mod.weight), 0, Cc)))
+            # fused data gradient + depthwise backward
+            ba = L.SepBwdArgs()
+            fill(ba, dy.ptr, dy.ld)
+            rows = int(lib.addk_sep_bwd_rows(C.byref(ba)))
+            gs = slab = None
+            if src.needs_grad:
+                gs = self.grad(src.raw)
+                ba.g, ba.ldg, ba.accumulate = gs.ptr, gs.ld, self.acc_flag(gs)
+                slab = self._dab(src, rows)
+                if slab is not None:
+                    ba.dab = slab.ptr
+                    src.bn.slabs.append((slab, rows))
+            gpw, accw = self.param_grad(dw_mod.weight)
+            ws = self.buf(rows * Cc * k * k)
+            ba.ws = ws.ptr
+            it = L.DwWreduceItem()
+            it.ws, it.dw, it.rows, it.n, it.accumulate = ws.ptr, gpw, rows, Cc * k * k, accw
+            self._dwreds.append((it, ws, self.pgrad[dw_mod.weight]))
+            self.keep.append(ba)
+            cb = self._add(self.bwd, 'sep_bwd', lib.addk_sep_bwd, C.byref(ba), rd=[dy, dw_mod.weight, pw_mod.weight] + self.lz(src),
+                           wr=[gs, slab, ws])
+            bk = int(lib.addk_sep_bwd_batch_key(C.byref(ba)))
+            if bk >= 0:
+                cb.payload, cb.bkey = ba, bk
+        self._bwd_emitters.append(emit_bwd)
+        return True
+
     def sep_half(self, src, dw_mod, pw_mod, bn_mod, sum_terms=None, out=None):
         """One half of SepConv (operations.py:51-54 / 55-58): ReLU -> depthwise k x k -> pointwise 1x1 -> BN (lazy), as ONE
         launch where the fused kernel covers the shape (addk_sep_fwd, csrc/sepf.hip: the depthwise output stays on chip; in
@@ -1004,14 +1065,19 @@ class Graph:
             t = self.dwconv(src, dw_mod, relu_in=True)
             act = self.conv_bn([t], pw_mod, bn_mod, relu_in=False)
             return act if sum_terms is None else self.affine_sum(list(sum_terms) + [act], out=out)
-        t = self.dwconv(src, dw_mod, relu_in=True, fwd=False) if self.want_grad else None
+        t = None
         slab = rows = None
         if training:
             rows = max(int(lib.addk_sep_rows(C.byref(ar))), int(lib.addk_conv_rows(N * H * W, Cout)))
             slab = self.buf(rows * Cout * 4)
             ar.stats_rows = rows
-        if t is not None:
-            self.conv([t], pw_mod.weight, Cout, 1, out=raw, stats=slab, fwd=False)       # backward of the pointwise half
+        if self.want_grad:
+            if os.environ.get('ADDK_FUSE_SEP_BWD', '1') == '1' and self._sep_bwd(src, dw_mod, pw_mod, raw, probe=True):
+                t = Act(self.tensor(N, H, W, Cc), None, False, True)           # depthwise output: written by the fused forward, read by the pointwise weight gradient
+                self._sep_bwd(src, dw_mod, pw_mod, raw, t=t)
+            else:
+                t = self.dwconv(src, dw_mod, relu_in=True, fwd=False)
+                self.conv([t], pw_mod.weight, Cout, 1, out=raw, stats=slab, fwd=False)       # backward of the pointwise half
             ar.t, ar.ldt = t.raw.ptr, t.raw.ld
         ar.stats = slab.ptr if slab is not None else None
         ar.stats_ld = 0

@@ -232,6 +232,27 @@ int addk_sep_fwd_batch_key(const addk_sep_args* a);
 int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
 int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 
+/* Fused BACKWARD of a SepConv half (csrc/sepb.hip): pointwise data gradient (dt = W^T dy, matrix cores) and depthwise backward
+ * (dx, depthwise weight-gradient partials, (dA, dB) of the input's lazy BatchNorm) in one launch; dt stays on chip.  dy is the
+ * gradient wrt the pointwise output with the BatchNorm backward already applied (addk_bn_bwd_apply).  The pointwise WEIGHT
+ * gradient is not part of it (addk_conv_wgrad on dy and the stored depthwise output).  `ws` ([rows][C][K*K] floats) and `dab`
+ * ([rows][C][2] fp64) get one row per workgroup, rows = addk_sep_bwd_rows(a); ws is reduced by addk_dw_wreduce_batch. */
+typedef struct addk_sep_bwd_args {
+  const float* dy; int32_t lddy;
+  int32_t N, H, W, K;               /* stride 1, dilation 1, pad K/2: output size == input size */
+  addk_src src;                     /* forward input of the depthwise conv (x, a, b, relu) */
+  int32_t Cout; int32_t ldw;        /* pointwise weights [Cout][src.C], row stride ldw; Cout == src.C */
+  const float* dw_w; const float* pw_w;
+  float* g; int32_t ldg; int32_t accumulate;   /* gradient wrt src.x (NULL: skip) */
+  double* dab;                      /* or NULL */
+  float* ws;
+} addk_sep_bwd_args;
+int addk_sep_bwd_rows(const addk_sep_bwd_args* a);
+int addk_sep_bwd(const addk_sep_bwd_args* a, void* stream);
+int addk_sep_bwd_batch_key(const addk_sep_bwd_args* a);
+int64_t addk_sep_bwd_batch_prepare(const addk_sep_bwd_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int addk_sep_bwd_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Depthwise k x k convolution (groups == C), stride 1 or 2, pad k/2*dil: the depthwise
  * halves of SepConv (operations.py:52,56).  w is [C][KH*KW] (torch [C,1,KH,KW]).

@@ -429,3 +429,51 @@ def test_fused_sepconv_half_matches_fp64_reference(lib, shape):
     errs['t_vs_unfused'] = _rel(t, t2)
     bad = ['%s %.2e' % kv for kv in errs.items() if not kv[1] <= TOL]
     assert not bad, '%s beyond %.0e: %s' % (name, TOL, ', '.join(bad))
+
+
+@pytest.mark.parametrize('shape', SEP_SHAPES, ids=[s[0] for s in SEP_SHAPES])
+def test_fused_sepconv_half_backward_matches_fp64_autograd(lib, shape):
+    """addk_sep_bwd (pointwise data gradient on the matrix cores -> LDS -> depthwise backward, ONE launch) through the C ABI
+    against fp64 autograd of y = pw(dw(relu(a*x + b))): gradient wrt x (first touch and accumulate), the (dA, dB) sums of the
+    input's lazy BatchNorm, the depthwise weight gradient from the per-workgroup workspace rows; bit-identical run to run."""
+    L = lib
+    lb = L.load()
+    lb.addk_set_fast_paths(FAST_ALL)
+    name, N, H, W, Cc, k = shape
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(7 + sum(map(ord, name)))
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    P = N * H * W
+    x, a, b = rnd(P, Cc), rnd(Cc), 0.3 * rnd(Cc)
+    wdw, wpw, dy = 0.3 * rnd(Cc, k * k), 0.2 * rnd(Cc, Cc), rnd(P, Cc)
+    g0 = rnd(P, Cc)
+    # fp64 autograd
+    xr = x.double().view(N, H, W, Cc).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ar_, br_ = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    wd = wdw.double().view(Cc, 1, k, k).requires_grad_(True)
+    z = F.relu(ar_.view(1, -1, 1, 1) * xr + br_.view(1, -1, 1, 1))
+    y = F.conv2d(F.conv2d(z, wd, padding=k // 2, groups=Cc), wpw.double().view(Cc, Cc, 1, 1))
+    y.backward(dy.double().view(N, H, W, Cc).permute(0, 3, 1, 2))
+    flat = lambda v: v.permute(0, 2, 3, 1).reshape(P, Cc)
+    ba = L.SepBwdArgs()
+    ba.dy, ba.lddy, ba.N, ba.H, ba.W, ba.K = dy.data_ptr(), Cc, N, H, W, k
+    ba.src.x, ba.src.a, ba.src.b, ba.src.ld, ba.src.C, ba.src.relu = x.data_ptr(), a.data_ptr(), b.data_ptr(), Cc, Cc, 1
+    ba.Cout, ba.ldw, ba.dw_w, ba.pw_w = Cc, Cc, wdw.data_ptr(), wpw.data_ptr()
+    rows = lb.addk_sep_bwd_rows(C.byref(ba))
+    assert rows > 0
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for acc in (0, 1, 0):
+        g = g0.clone() if acc else torch.full((P, Cc), float('nan'), device=dev)
+        dab = torch.full((rows, Cc, 2), float('nan'), device=dev, dtype=torch.float64)
+        ws = torch.full((rows, Cc, k * k), float('nan'), device=dev)
+        ba.g, ba.ldg, ba.accumulate, ba.dab, ba.ws = g.data_ptr(), Cc, acc, dab.data_ptr(), ws.data_ptr()
+        L.check(lb.addk_sep_bwd(C.byref(ba), st), 'sep_bwd')
+        torch.cuda.synchronize()
+        outs.append((g, dab.sum(0), ws.double().sum(0)))
+    assert all(torch.equal(u, v) for u, v in zip(outs[0], outs[2])), 'not reproducible'
+    gx = flat(xr.grad)
+    errs = {'dx': _rel(outs[0][0], gx), 'dx_acc': _rel(outs[1][0], gx + g0.double()),
+            'dab': _rel(outs[0][1], torch.stack([ar_.grad, br_.grad], 1)), 'dw': _rel(outs[0][2], wd.grad.view(Cc, k * k))}
+    bad = ['%s %.2e' % kv for kv in errs.items() if not kv[1] <= TOL]
+    assert not bad, '%s beyond %.0e: %s' % (name, TOL, ', '.join(bad))
