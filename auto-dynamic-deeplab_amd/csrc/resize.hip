@@ -319,6 +319,110 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
   }
 }
 
+// Table-driven backward for resizes of at most x2 up-sampling (every in-network resize of the path: /4, /2, x2 and the
+// 63 <-> 64 / 125 <-> 128 fits of even-sized inputs).  The kernel above re-derives, in EVERY (pixel, channel quad) thread, the
+// candidate output range of its input pixel and trims it with up to ten tap_weight evaluations per axis before it can issue a
+// load: 28 us per launch at 1.1 TB/s.  Here a workgroup walks row segments of `tw` input pixels; per segment it builds the
+// per-axis tables (first output index, tap count <= 5, weights — the very same fp32 expressions, so results are bit-identical)
+// ONCE in LDS, tw + 1 threads busy for a few dozen cycles, and every thread then issues its nh*nw independent 16-byte loads
+// straight from the table.  Statistics ((dA, dB) of a ReLU'd lazy source) as above: registers across segments, one row per workgroup.
+constexpr int RT_MAXW = 128;
+__global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int tiles_per_row, int ntiles, int tw) {
+  extern __shared__ double redt[];       // [npl][C4][2]
+  __shared__ float wt_w[RT_MAXW][5], wt_h[5];
+  __shared__ int lo_w[RT_MAXW], n_w[RT_MAXW], lo_h, n_h;
+  const int C = p.src.C;
+  const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
+  const bool active = pl < p.npl;
+  const int c = 4 * q;
+  const float sh = (float)p.H / (float)p.OH, sw = (float)p.W / (float)p.OW;
+  const float gs = p.dy_scale ? *p.dy_scale : 1.f;
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
+  if (active && p.src.a) { av = ld4(p.src.a + c); bv = ld4(p.src.b + c); }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int rowid = tile / tiles_per_row, seg = tile - rowid * tiles_per_row;
+    const int n = rowid / p.H, ih = rowid - n * p.H, iw0 = seg * tw;
+    __syncthreads();                                   // the previous segment's readers are done with the tables
+    if ((int)threadIdx.x <= tw) {
+      const bool isw = (int)threadIdx.x < tw;
+      const int i = isw ? iw0 + (int)threadIdx.x : ih, lim = isw ? p.W : p.H, in = lim, out = isw ? p.OW : p.OH;
+      const float sc = isw ? sw : sh;
+      int lo = 0, cnt = 0; float wv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      if (i < lim) {
+        int hi; out_range(i, sc, out, lo, hi);
+        while (lo < hi && tap_weight(lo, i, sc, in) == 0.f) ++lo;
+        while (hi > lo && tap_weight(hi, i, sc, in) == 0.f) --hi;
+        cnt = hi - lo + 1;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wv[k] = k < cnt ? tap_weight(lo + k, i, sc, in) : 0.f;
+      }
+      if (isw) { lo_w[threadIdx.x] = lo; n_w[threadIdx.x] = cnt;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wt_w[threadIdx.x][k] = wv[k]; }
+      else { lo_h = lo; n_h = cnt;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wt_h[k] = wv[k]; }
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int nh = n_h, hlo = lo_h;
+    for (int px = pl; px < tw; px += p.npl) {
+      const int iw = iw0 + px;
+      if (iw >= p.W) break;
+      const int nw = n_w[px], wlo = lo_w[px];
+      const long pp = (long)rowid * p.W + iw;
+      float4 dz = zero4();
+      float ww5[5]; int wo5[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { ww5[k] = wt_w[px][k]; wo5[k] = (k < nw ? wlo + k : wlo) * p.lddy; }
+      for (int a = 0; a < nh; ++a) {
+        const float wh = wt_h[a];
+        const float* rowp = p.dy + (long)(n * p.OH + hlo + a) * p.OW * p.lddy + c;
+        float4 d5[5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) d5[b] = ld4(rowp + wo5[b]);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          const float k = wh * ww5[b];
+          dz.x = fmaf(k, d5[b].x, dz.x); dz.y = fmaf(k, d5[b].y, dz.y); dz.z = fmaf(k, d5[b].z, dz.z); dz.w = fmaf(k, d5[b].w, dz.w);
+        }
+      }
+      dz.x *= gs; dz.y *= gs; dz.z *= gs; dz.w *= gs;
+      if (p.src.relu || p.dab) {
+        const float4 x = ld4(p.src.x + pp * p.src.ld + c);
+        if (p.src.relu) {
+          if (!(fmaf(av.x, x.x, bv.x) > 0.f)) dz.x = 0.f;
+          if (!(fmaf(av.y, x.y, bv.y) > 0.f)) dz.y = 0.f;
+          if (!(fmaf(av.z, x.z, bv.z) > 0.f)) dz.z = 0.f;
+          if (!(fmaf(av.w, x.w, bv.w) > 0.f)) dz.w = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sA[e] += (double)get4(dz, e) * (double)get4(x, e); sB[e] += (double)get4(dz, e); }
+      }
+      float4 gv = make_float4(dz.x * av.x, dz.y * av.y, dz.z * av.z, dz.w * av.w);
+      float* gp = p.g + pp * p.ldg + c;
+      if (p.accumulate) { const float4 o = ld4(gp); gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
+      st4(gp, gv);
+    }
+  }
+  if (p.dab) {
+    const int C4 = p.nq * 4;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { redt[((pl * C4) + c + e) * 2] = sA[e]; redt[((pl * C4) + c + e) * 2 + 1] = sB[e]; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * 2; k += 256) {
+      const int ch = k >> 1, ab = k & 1;
+      double acc = 0.0;
+      for (int r = 0; r < p.npl; ++r) acc += redt[((r * C4) + ch) * 2 + ab];
+      p.dab[(long)blockIdx.x * C * 2 + k] = acc;
+    }
+  }
+}
+
 int rs_rows(long P, int C) {
   EwMap m = ew_map(C);
   long r = P / ((long)m.npl * 2);
@@ -405,6 +509,14 @@ extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
             (!a->src.x || src_vec_ok(a->src));
     int rows = rs_rows(k.P, a->src.C);
     size_t sh = (size_t)m.npl * m.nq * 4 * 2 * sizeof(double);
+    // at most x2 up-sampling (<= 5 taps per axis), vector-aligned, a few pixel lanes per workgroup: the table-driven kernel
+    if (k.vec && a->src.C == m.nq * 4 && m.npl >= 4 && a->OH <= 2 * a->H + 1 && a->OW <= 2 * a->W + 1 && (addk_get_fast_paths() & ADDK_FAST_DWTILE) &&
+        (long)a->N * a->H * a->W < (1L << 30)) {
+      int tw = m.npl * 4; if (tw > RT_MAXW) tw = RT_MAXW; if (tw > a->W) tw = a->W;
+      const int tpr = cdiv(a->W, tw), ntiles = a->N * a->H * tpr;
+      hipLaunchKernelGGL(resize_bwd_tab_kernel, dim3(rows), dim3(256), sh, st, k, tpr, ntiles, tw);
+      return addk_check_launch("resize_bwd_tab");
+    }
     hipLaunchKernelGGL(resize_bwd_kernel<false>, dim3(rows), dim3(256), sh, st, k);
   }
   return addk_check_launch("resize_bwd");

@@ -259,3 +259,48 @@ def test_config5_architecture_full_size_logits_and_first_step_loss(dev):
         la = sum(ca(y, tgt.to(dev)) for y in ma(x.to(dev))) / 2
     _log('config5 architecture (F=40 g1) 2x1024x2048 train-mode first-step loss: oracle %.7f addk %.7f', float(lo), float(la))
     assert abs(float(la) - float(lo)) <= 1e-4 * abs(float(lo))
+
+
+@pytest.mark.parametrize('shape', [(2, 40, 32, 64, 63, 127), (1, 40, 63, 127, 64, 128), (2, 64, 64, 128, 16, 32), (1, 80, 64, 128, 32, 64),
+                                   (2, 256, 16, 32, 32, 64), (1, 40, 128, 256, 125, 253)],
+                         ids=['up_32_63', 'fit_63_64', 'down4', 'down2', 'up2_c256', 'fit_128_125'])
+def test_table_driven_resize_backward_matches_fp64_autograd(dev, shape):
+    """addk_resize_bwd on the table-driven kernel (csrc/resize.hip: resizes of at most x2 up-sampling) through the C ABI against
+    fp64 autograd of F.interpolate(relu(a*x + b)): gradient wrt x (first touch and accumulate) and the (dA, dB) sums; and
+    bit-identical to the per-thread kernel it replaces (fast path off)."""
+    import addk._lib as L
+    lb = L.load()
+    N, Cc, H, W, OH, OW = shape
+    gen = torch.Generator().manual_seed(H * 7 + OW)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    P = N * H * W
+    x, a, b, dy, g0 = rnd(P, Cc), rnd(Cc), 0.3 * rnd(Cc), rnd(N * OH * OW, Cc), rnd(P, Cc)
+    xr = x.double().view(N, H, W, Cc).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ar_, br_ = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    y = F.interpolate(F.relu(ar_.view(1, -1, 1, 1) * xr + br_.view(1, -1, 1, 1)), size=(OH, OW), mode='bilinear', align_corners=False)
+    y.backward(dy.double().view(N, OH, OW, Cc).permute(0, 3, 1, 2))
+    gx = xr.grad.permute(0, 2, 3, 1).reshape(P, Cc)
+    ba = L.ResizeBwdArgs()
+    ba.dy, ba.lddy, ba.nchw_in = dy.data_ptr(), Cc, 0
+    ba.src.x, ba.src.a, ba.src.b, ba.src.ld, ba.src.C, ba.src.relu = x.data_ptr(), a.data_ptr(), b.data_ptr(), Cc, Cc, 1
+    ba.N, ba.H, ba.W, ba.OH, ba.OW = N, H, W, OH, OW
+    rows = lb.addk_ew_rows(P, Cc)
+    res = {}
+    try:
+        for fast in (31, 0):
+            lb.addk_set_fast_paths(fast)
+            for acc in (0, 1):
+                g = g0.clone() if acc else torch.full((P, Cc), float('nan'), device=dev)
+                dab = torch.full((rows, Cc, 2), float('nan'), device=dev, dtype=torch.float64)
+                ba.g, ba.ldg, ba.accumulate, ba.dab = g.data_ptr(), Cc, acc, dab.data_ptr()
+                L.check(lb.addk_resize_bwd(C.byref(ba), torch.cuda.current_stream().cuda_stream), 'resize_bwd')
+                torch.cuda.synchronize()
+                res[(fast, acc)] = (g, dab.sum(0))
+    finally:
+        lb.addk_set_fast_paths(31)
+    rel = lambda u, v: float((u.double() - v).abs().max() / v.abs().max())
+    e = {'dx': rel(res[(31, 0)][0], gx), 'dx_acc': rel(res[(31, 1)][0], gx + g0.double()),
+         'dab': rel(res[(31, 0)][1], torch.stack([ar_.grad, br_.grad], 1))}
+    _log('resize_bwd table kernel %s: %s', shape, ' '.join('%s %.1e' % kv for kv in e.items()))
+    assert all(v <= 5e-5 for v in e.values()), e          # fp32 source coordinates: ~1e-5 at scale 128/125 (the per-thread kernel and ATen alike)
+    assert torch.equal(res[(31, 0)][0], res[(0, 0)][0]) and torch.equal(res[(31, 1)][0], res[(0, 1)][0]), 'differs from the per-thread kernel'
