@@ -51,6 +51,10 @@ class DynamicPlan:
         self.segs = {}            # (begin, end) -> that segment's launch list, level-ordered / batched / scheduled on two streams
         g.nstreams = 2
         self.calls = 0
+        # the gate scalar travels through pinned host memory: an asynchronous 4-byte copy + an event the host waits on, instead of
+        # a blocking read that idles the host until the whole device has drained (ADD.py:421 does `if confidence_value > threshold`)
+        self._conf_host = torch.empty(max(1, x.shape[0]), dtype=torch.float32).pin_memory()
+        self._conf_evt = torch.cuda.Event()
 
     def check_params(self):
         return all(p.data_ptr() == q for p, q in zip(self.params, self.ptrs))
@@ -93,7 +97,10 @@ class DynamicPlan:
                 self._seg(pos, end)
                 conf = self.conf[k].y.reshape(x.shape[0], -1)
                 h0, h1 = self.head_rng[k]
-                if bool(conf > threshold):                            # D2H sync: the gate (ADD.py:421)
+                self._conf_host[:x.shape[0]].copy_(conf.reshape(-1), non_blocking=True)
+                self._conf_evt.record()
+                self._conf_evt.synchronize()                          # the host waits for this one scalar only
+                if bool(self._conf_host[0] > threshold):              # the gate (ADD.py:421); bs = 1 as in eval.py:195-230
                     pos = h1
                     continue
                 self._seg(h0, h1)

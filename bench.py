@@ -117,8 +117,26 @@ def _cpu_baseline_child(genotype, n, h, w):
     for _ in range(k):
         step()
     dt = (time.perf_counter() - t0) / k
-    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port', 'first_step_loss': losses[0], 'second_step_loss': losses[1],
-            'sample': '%d steps fwd+bwd+SGD after 1 warm-up step, bs=%d %dx%d, torch-CPU oracle, %.1f s per step' % (k, n, h, w, dt)}
+    res = {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port', 'first_step_loss': losses[0], 'second_step_loss': losses[1],
+           'sample': '%d steps fwd+bwd+SGD after 1 warm-up step, bs=%d %dx%d, torch-CPU oracle, %.1f s per step' % (k, n, h, w, dt)}
+    if (h, w) == (1024, 2048):
+        # config 4 beside it: the oracle's own EDM-gated dynamic inference, early and final exit, bs = 1 (the early exit is the
+        # SLOWER one in the reference itself: get_feature / dynamic_inference up-sample the gated feature 4x per side before ASPP,
+        # SURVEY Q5, so ASPP runs on 16x the pixels)
+        edm = oracle.EDM()
+        from addk.synth import fill_params
+        fill_params(edm, 701)
+        m.eval(); edm.eval()
+        x1 = x[:1]
+        tt = {}
+        with torch.no_grad():
+            for name, thr in (('early', 1e9), ('final', -1e9)):
+                m.dynamic_inference(x1, threshold=thr, confidence='edm', edm=edm)
+                t0 = time.perf_counter()
+                m.dynamic_inference(x1, threshold=thr, confidence='edm', edm=edm)
+                tt[name + '_exit_s'] = time.perf_counter() - t0
+        res['dynamic_inference_cpu'] = tt
+    return res
 
 
 def time_launch(cmd, reps=20):
@@ -253,6 +271,43 @@ def drop_in_step(model, x, t, steps=5):
     dt = (time.perf_counter() - t0) / steps
     return {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'steps': steps,
             'what': 'outputs = model(image); loss = mean_i CE(outputs[i], target); loss.backward(); torch.optim.SGD.step()'}
+
+
+def ddp_path_world1(genotype, a, x, t, dev, steps=10):
+    """The N > 1 code path timed on this one GPU: SynchronizedBatchNorm2d + every statistics exchange and the bucketed gradient
+    all-reduce issued through RCCL at world_size 1 (zero link time: what remains is the launch structure the exchanges force
+    on the step), captured in the hipGraph like the local step.  The driver's multi-GPU runs measure the real thing."""
+    import torch.distributed as dist
+    from addk import parallel
+    from addk.modeling.ADD import ADD
+    from addk.train import TrainStep
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+    dist.init_process_group(backend='nccl', init_method='env://')
+    try:
+        comm = parallel.init_sync_bn(force=True)
+        m = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=True), 0)
+        init_weights(m)
+        m.to(dev)
+        ts = TrainStep(m, tuple(x.shape), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm)
+        ts.load_batch(x, t)
+        for _ in range(3):
+            ts.step()
+        calls0 = comm.calls
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        nall = sum(getattr(c, 'members', 1) for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed'))
+        ncmd = sum(1 for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed', 'grad_allreduce'))
+        return {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'hip_graph': ts.graph is not None,
+                'collectives_per_step': ncmd, 'exchanged_statistics_vectors': nall,
+                'what': 'world_size 1, exchanges forced: SyncBN statistics all-reduces (one per dependency level) + bucketed gradient all-reduce'}
+    finally:
+        parallel.disable_sync_bn()
+        dist.destroy_process_group()
 
 
 def main():
@@ -398,9 +453,17 @@ def main():
                            'frac': seg['eval']['frac_hbm']}
         out['per_exit_ms'] = per_exit_latency(model, dev)
         out['drop_in'] = drop_in_step(model, x, t)
+        try:
+            out['ddp_path_world1'] = ddp_path_world1(genotype, a, x, t, dev)
+        except Exception as e:                   # the extra must never cost the headline line
+            out['ddp_path_world1'] = {'error': str(e).splitlines()[0] if str(e) else repr(e)}
     if not a.no_cpu_baseline and world == 1 and default_cfg:
         cb = cpu_baseline(n, h, w)
         out['cpu_baseline'] = cb
+        if cb.get('dynamic_inference_cpu') and 'per_exit_ms' in out:
+            d = cb.pop('dynamic_inference_cpu')
+            out['per_exit_ms']['cpu_oracle_1024x2048'] = {'early_exit_ms': 1e3 * d['early_exit_s'], 'final_exit_ms': 1e3 * d['final_exit_s'],
+                                                         'note': 'the reference arithmetic itself: its early exit costs more than its final exit (SURVEY Q5: 4x up-sampling per side before ASPP)'}
         ref = cb.get('first_step_loss')
         if ref is not None and losses:
             rel = abs(losses[0] - ref) / abs(ref)
