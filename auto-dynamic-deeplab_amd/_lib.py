@@ -47,7 +47,7 @@ class BnFinalizeArgs(C.Structure):
 class SepArgs(C.Structure):
     _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('Cout', i32), ('ldw', i32), ('dw_w', vp), ('pw_w', vp),
                 ('y', vp), ('ldy', i32), ('ldt', i32), ('t', vp), ('stats', vp), ('stats_ld', i32), ('stats_rows', i32), ('nterm', i32), ('ea', vp), ('eb', vp),
-                ('term', Src * MAX_TERMS), ('fin', BnFinalizeArgs), ('fin_counter', vp)]
+                ('term', Src * MAX_TERMS), ('fin', BnFinalizeArgs), ('fin_counter', vp), ('io16', i32), ('_pad', i32)]
 
 
 class SepBwdArgs(C.Structure):

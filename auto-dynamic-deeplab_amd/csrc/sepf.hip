@@ -36,6 +36,26 @@ __device__ __forceinline__ float4 fma4(float4 w, float4 v, float4 a) {
   return make_float4(fmaf(w.x, v.x, a.x), fmaf(w.y, v.y, a.y), fmaf(w.z, v.z, a.z), fmaf(w.w, v.w, a.w));
 }
 
+// Storage experiment: the activation tensors of the launch (input, output, depthwise output, sum terms) as
+// bf16 in HBM, fp32 arithmetic and statistics.  IO16 = false is the product path.
+template <bool IO16> __device__ __forceinline__ float4 ldx(const float* base, long off) {
+  if (!IO16) return ld4(base + off);
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 r = *(const __attribute__((address_space(1))) u32x2*)((const unsigned short*)base + off);
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+template <bool IO16> __device__ __forceinline__ void stx(float* base, long off, float4 v) {
+  if (!IO16) { st4(base + off, v); return; }
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const f32x2_ lo = {v.x, v.y}, hi = {v.z, v.w};
+  u32x2 r;
+  r.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2_));
+  r.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2_));
+  *(__attribute__((address_space(1))) u32x2*)((unsigned short*)base + off) = r;
+}
+
 template <int KS, int KG, int KP, int R>
 struct SepfGeo {
   static constexpr int CT = KG, PH = 4 * R + KS - 1, PW = 16 + KS - 1, NPIX = PH * PW, KQ = KP / 4;
@@ -45,7 +65,7 @@ struct SepfGeo {
   static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + RED) * 4;
 };
 
-template <int KS, int KG, int KP, int R>
+template <int KS, int KG, int KP, int R, bool IO16 = false>
 __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   typedef SepfGeo<KS, KG, KP, R> G;
   constexpr int CT = G::CT, PH = G::PH, PW = G::PW, NPIX = G::NPIX, KQ = G::KQ, HK = KS / 2;
@@ -82,7 +102,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
     float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
     if (p.src.a && qact) { av = ld4(p.src.a + 4 * q); bv = ld4(p.src.b + 4 * q); }
     const bool relu = p.src.relu != 0;
-    const float* xb = p.src.x + (qact ? 4 * q : 0);
+    const long xq = qact ? 4 * q : 0;
     const int ih0 = oh0 - HK, iw0 = ow0 - HK;
     if (pl < npl) {
       constexpr int UN = 6;
@@ -94,7 +114,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
           const int pr = pix / PW, pc = pix - pr * PW;
           const int ih = ih0 + pr, iw = iw0 + pc;
           ok[u] = qact && pix < NPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-          v[u] = ld4(xb + (ok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
+          v[u] = ldx<IO16>(p.src.x, xq + (ok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -147,7 +167,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
       }
     if (p.t && 4 * q < C) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) if (pin[r]) st4(p.t + (long)pp[r] * p.ldt + 4 * q, acc[r]);
+      for (int r = 0; r < R; ++r) if (pin[r]) stx<IO16>(p.t, (long)pp[r] * p.ldt + 4 * q, acc[r]);
     }
     float4 wf[CT];
 #pragma unroll
@@ -180,10 +200,10 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
       if (p.ea) v = fma4(ea, v, eb);
       for (int ti = 0; ti < p.nterm; ++ti) {
         const addk_src& T = p.term[ti];
-        const float4 u = prologue4(ld4(T.x + (long)pp[r] * T.ld + c), T.a, T.b, c, 4, T.relu != 0, true);
+        const float4 u = prologue4(ldx<IO16>(T.x, (long)pp[r] * T.ld + c), T.a, T.b, c, 4, T.relu != 0, true);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
-      st4(p.y + (long)pp[r] * p.ldy + c, v);
+      stx<IO16>(p.y, (long)pp[r] * p.ldy + c, v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float f = get4(v, e); s1[i][e] += f; s2[i][e] = fmaf(f, f, s2[i][e]); }
     }
@@ -218,10 +238,10 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   }
 }
 
-template <int KS, int KG, int KP, int R>
+template <int KS, int KG, int KP, int R, bool IO16 = false>
 __global__ void __launch_bounds__(256, 2) sepf_kernel(const SepfK p) {
   extern __shared__ __attribute__((aligned(16))) float sepf_sm[];
-  sepf_body<KS, KG, KP, R>(p, sepf_sm);
+  sepf_body<KS, KG, KP, R, IO16>(p, sepf_sm);
 }
 template <int KS, int KG, int KP, int R>
 __global__ void __launch_bounds__(256, 2) sepf_batch_kernel(const SepfK* __restrict__ tab) {
@@ -231,8 +251,8 @@ __global__ void __launch_bounds__(256, 2) sepf_batch_kernel(const SepfK* __restr
   sepf_body<KS, KG, KP, R>(p, sepf_sm);
 }
 
-struct SepfCfg { int ks, kg, kp, r; };
-inline int sepf_key(const SepfCfg& c) { return (c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r; }
+struct SepfCfg { int ks, kg, kp, r, io16; };
+inline int sepf_key(const SepfCfg& c) { return c.io16 ? -1 : ((c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r); }
 
 bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   if (!a || !(a->K == 3 || a->K == 5) || a->N <= 0 || a->H <= 0 || a->W <= 0) return false;
@@ -256,7 +276,7 @@ bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   for (int i = 0; i < a->nterm; ++i) k.term[i] = a->term[i];
   // two rows per wave where that still gives the chip >= 1.5 workgroups per CU (the LDS patch of a KG = 5 tile is 56 KB at R = 1)
   const long blocks2 = (long)a->N * cdiv(a->H, 8) * cdiv(a->W, 16);
-  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1;
+  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1; c.io16 = a->io16 ? 1 : 0;
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
   k.rows = a->stats_rows;
   if (k.slab && k.gx > k.rows) return false;             // the caller sizes the slab with addk_sep_rows
@@ -283,7 +303,25 @@ int sepf_go(bool batch, dim3 grid, hipStream_t st, const SepfK* one, const SepfK
   return addk_check_launch("sep_fwd");
 }
 
+template <int KS, int KG, int KP, int R>
+int sepf_go16(dim3 grid, hipStream_t st, const SepfK* one) {
+  typedef SepfGeo<KS, KG, KP, R> G;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepf_kernel<KS, KG, KP, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS); attr = true; }
+  hipLaunchKernelGGL((sepf_kernel<KS, KG, KP, R, true>), grid, dim3(256), G::LDS, st, *one);
+  return addk_check_launch("sep_fwd(bf16 storage)");
+}
+
 int sepf_dispatch(const SepfCfg& c, bool batch, dim3 grid, hipStream_t st, const SepfK* one, const SepfK* tab) {
+  if (c.io16) {          // storage experiment: the four cell shapes of config 2, single launches only
+    if (batch) { addk_set_error("sep_fwd: the bf16-storage experiment has no batched form"); return ADDK_ERR_UNSUPPORTED; }
+    if (c.ks == 3 && c.kg == 3 && c.kp == 40 && c.r == 2) return sepf_go16<3, 3, 40, 2>(grid, st, one);
+    if (c.ks == 5 && c.kg == 3 && c.kp == 40 && c.r == 2) return sepf_go16<5, 3, 40, 2>(grid, st, one);
+    if (c.ks == 3 && c.kg == 5 && c.kp == 88 && c.r == 1) return sepf_go16<3, 5, 88, 1>(grid, st, one);
+    if (c.ks == 5 && c.kg == 5 && c.kp == 88 && c.r == 1) return sepf_go16<5, 5, 88, 1>(grid, st, one);
+    addk_set_error("sep_fwd: the bf16-storage experiment covers C = 40 / 80 at config-2 map sizes only");
+    return ADDK_ERR_UNSUPPORTED;
+  }
 #define ADDK_SEPF(KS_, KG_, KP_, R_) if (c.ks == KS_ && c.kg == KG_ && c.kp == KP_ && c.r == R_) return sepf_go<KS_, KG_, KP_, R_>(batch, grid, st, one, tab);
   ADDK_SEPF(3, 3, 40, 1) ADDK_SEPF(3, 3, 40, 2) ADDK_SEPF(5, 3, 40, 1) ADDK_SEPF(5, 3, 40, 2)
   ADDK_SEPF(3, 3, 56, 1) ADDK_SEPF(3, 3, 56, 2) ADDK_SEPF(5, 3, 56, 1) ADDK_SEPF(5, 3, 56, 2)
@@ -338,6 +376,6 @@ extern "C" int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n,
 extern "C" int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
   ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "sep_batch_run: bad args");
   const int key = (int)meta[0];
-  SepfCfg c{key >> 16, (key >> 12) & 15, (key >> 4) & 255, key & 15};
+  SepfCfg c{key >> 16, (key >> 12) & 15, (key >> 4) & 255, key & 15, 0};
   return sepf_dispatch(c, true, dim3((unsigned)meta[2], 1, (unsigned)meta[1]), (hipStream_t)stream, nullptr, reinterpret_cast<const SepfK*>(dev_blob));
 }

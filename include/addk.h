@@ -222,6 +222,7 @@ typedef struct addk_sep_args {
   addk_src term[ADDK_MAX_TERMS];
   addk_bn_finalize_args fin;        /* fused finalize of the statistics (fin.a == NULL: none) */
   void* fin_counter;
+  int32_t io16; int32_t _pad;       /* 1: storage experiment — src.x, y, t and the terms are bf16 arrays (same element strides), single launches of the config-2 cell shapes only */
 } addk_sep_args;
 int64_t addk_bn_fin_ws_bytes(int32_t nblocks, int32_t ld);
 int addk_sep_rows(const addk_sep_args* a);               /* slab rows (= workgroups) of the fused launch; 0: not covered */
