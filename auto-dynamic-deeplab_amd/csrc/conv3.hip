@@ -465,6 +465,18 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
     for (int j = 0; j < PT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    // Blocked accumulation (the <= 64-channel launches: stem1, the cells' 40-channel dilated convs — the layers every later layer
+    // inherits its error from): the running sums are flushed into a second accumulator set after every 16-channel chunk, so a
+    // rounding error grows with sqrt(MFMAs per chunk) + sqrt(chunks) instead of sqrt(all MFMAs) (stem1: 54 + 4 instead of 216) —
+    // what a CPU library's blocked partial sums do (the even-size gradient deficit starts at stem1's K = 576 chain).
+    constexpr bool BLK = PH == 2 && KS == 3 && !BIGD;          // (the 5x5 and wide-dilation variants have no registers left: 256 + scratch with a second set)
+    f32x16 acc2[BLK ? PT : 1];
+    if (BLK) {
+#pragma unroll
+      for (int j = 0; j < PT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
+    }
 
     float4 ra[NS];
     float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4();
@@ -580,11 +592,21 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
 #pragma unroll
         for (int m = 0; m < NP; ++m) { wr[0][m] = t0[m]; wr[1][m] = t1[m]; }
       }
+      if (BLK) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { acc2[j][e] += acc[j][e]; acc[j][e] = 0.f; }
+      }
       __syncthreads();
       if (!more) break;
       s = s2; c0 = c2;
       store_patch();
       __syncthreads();
+    }
+    if (BLK) {
+#pragma unroll
+      for (int j = 0; j < PT; ++j) acc[j] = acc2[j];
     }
 
     // ---- epilogue: lane holds pixel (32 j + lane%32), channels n0 + 32 wave + 8 g + 4 (lane/32) + {0..3}, g = 0..3 ----

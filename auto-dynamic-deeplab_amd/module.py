@@ -1,5 +1,7 @@
 """nn.Module front end of the plan runtime: any addk module's forward(x) builds (once per input
 signature) and replays a static plan of HIP kernel launches; autograd sees one Function."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -118,9 +120,12 @@ class Plan:
             self.g.run_parallel(self.g.fwd, None)
         self.nbt.bump()
         self.serial += 1
+        # outputs are COPIES of the plan-owned buffers: a caller written for the reference may keep the result of one forward()
+        # across the next one (ADDK_OUTPUT_VIEWS=1 hands out views and saves the 0.1 ms copy per full-resolution logits tensor)
+        views = os.environ.get('ADDK_OUTPUT_VIEWS', '0') == '1'
         outs = []
         for kind, o in self.outs:
-            outs.append(inputs[o] if kind == 'in' else o.y.view_as(o.y))
+            outs.append(inputs[o] if kind == 'in' else (o.y.view_as(o.y) if views else o.y.clone()))
         return outs
 
     def backward(self, gouts):

@@ -53,11 +53,16 @@ def main():
     ap.add_argument('--grads', type=int, default=1)
     ap.add_argument('--detail', type=int, default=0)
     ap.add_argument('--trace', type=int, default=0)
+    ap.add_argument('--gradtrace', type=int, default=-1)
     a = ap.parse_args()
     from addk.modeling.ADD import ADD
     dev = torch.device('cuda:0')
     addk.load()
     args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(a.F), 0)
+    if a.gradtrace >= 0:
+        layer_trace(args, (64, 128), a.gradtrace, dev)
+        grad_trace(args, (64, 128), a.gradtrace, dev)
+        return
     if a.trace:
         layer_trace(args, (64, 128), 0, dev)
         return
@@ -164,6 +169,34 @@ def layer_trace(args, hw, k, dev):
         den = float(t64.norm())
         ea, eo = float((a_ - t64).norm()) / den, float((o_ - t64).norm()) / den
         print('  %-44s %-18s addk %.2e  fp32 oracle %.2e  ratio %.2f' % (n, 'x'.join(str(v) for v in t64.shape[1:]), ea, eo, ea / max(eo, 1e-30)))
+    sys.stdout.flush()
+
+
+def grad_trace(args, hw, k, dev):
+    """Per-parameter gradient error (rel-L2 of that parameter's gradient vs fp64), addk and fp32 oracle, train mode, listed in
+    BACKWARD order (decoder first): where does addk's backward leave the oracle's?"""
+    from addk.modeling.ADD import ADD
+    mo = oracle.ADD(*args)
+    fill_params(mo, 600 + k)
+    m64 = oracle.ADD(*args); m64.load_state_dict(mo.state_dict()); m64.double()
+    ma = ADD(*args); ma.load_state_dict(mo.state_dict()); ma.to(dev)
+    x = rand_tensor(170 + k, 'spread_x', (2, 3) + hw)
+    t = target(hw, 180 + 2 * k)
+    g64, g32, ga = grads_of(m64, x.double(), t, True), grads_of(mo, x, t, True), grads_of(ma, x.to(dev), t.to(dev), True)
+    print('train-mode gradients at %dx%d draw %d: whole-net rel-L2 addk %.2e  fp32 oracle %.2e' % (hw + (k, rel_l2(ga, g64), rel_l2(g32, g64))))
+    names = [n for n, _ in mo.named_parameters() if n in g64]
+    def key(n):
+        if n.startswith('stem'):
+            return (0, int(n[4]), n)
+        if n.startswith('cells.'):
+            return (1, int(n.split('.')[1]), n)
+        return (2, 0, n)
+    for n in sorted(names, key=key, reverse=True):
+        if g64[n].dim() != 4:
+            continue
+        den = float(g64[n].norm())
+        ea, eo = float((ga[n] - g64[n]).norm()) / den, float((g32[n] - g64[n]).norm()) / den
+        print('  %-48s |g| %.2e  addk %.2e  fp32 oracle %.2e  ratio %.2f' % (n, den, ea, eo, ea / max(eo, 1e-30)))
     sys.stdout.flush()
 
 
