@@ -574,6 +574,10 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
   }
   ADDK_REQUIRE(a->w_choff + ctot <= a->cin_total, "conv_fwd: sources exceed cin_total");
   ADDK_REQUIRE(a->ldw >= a->KH * a->KW * a->cin_total, "conv_fwd: ldw too small");
+  if (a->wpack && a->KH == 1 && a->KW == 1) {             // a 1x1 conv whose caller set up the split kernel's weight pack: that path first
+    int r = addk_c3_try_fwd(a, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), stream);
+    if (r <= 0) return r;
+  }
   if (pw_enabled()) {      // small pointwise shapes: register-stationary kernel (pw.hip)
     int r = addk_pw_try_fwd(a, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), stream);
     if (r <= 0) return r;

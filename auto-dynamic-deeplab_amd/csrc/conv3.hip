@@ -737,9 +737,15 @@ long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
   const int bct = c3_bct(Cn, P);
   return (long)cdiv(Cn, 16 * bct) * nchunks * taps * bct * 256;
 }
-bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn) {
+inline int c3b_narrow_k() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_NARROW_K"); v = e ? atoi(e) : 0; } return v; }
+bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn, int ktot = 0) {
   if (KH == 1 && KW == 1) {      // wide pointwise heads (ASPP 1x1, the 1280 -> 256 concat conv): the split kernel as a plain GEMM (KS = 1)
-    return c3_enabled() && c3b_pointwise_enabled() && stride == 1 && dil == 1 && pad == 0 && OH == H && OW == W && Cn >= 192 && c3_planes(Cn, 1) != 0 &&
+    // [r3] and the FORWARD of the cells' glue convs with many input channels (dense-connection preprocess: K = 200..800 -> 40..160): ktot
+    // is the forward reduction length (0 for data gradients), ADDK_C3B_NARROW_K the smallest K that takes this path.  Measured and left OFF
+    // (default 0): 28.6 vs 29.4 us per launch at 40 output channels, 41.6 vs 25.7 us at 80 — the streaming-K fp32 kernel (pwk_kernel) is
+    // memory-bound on these shapes, the 6-term matrix work is not what they wait for
+    const bool wide = Cn >= 192, narrow = c3b_narrow_k() > 0 && ktot >= c3b_narrow_k() && Cn >= 32 && Cn <= 160;
+    return c3_enabled() && c3b_pointwise_enabled() && stride == 1 && dil == 1 && pad == 0 && OH == H && OW == W && (wide || narrow) && c3_planes(Cn, 1) != 0 &&
            W >= 48 && P >= 2048;
   }
   if (!c3_enabled() || KH != KW || !(KH == 3 || KH == 5) || stride != 1 || dil < 1 || dil > c3_maxdil(KH)) return false;
@@ -787,7 +793,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   ADDK_C3B(3, 3, true) ADDK_C3B(4, 3, true) ADDK_C3B(5, 3, true) ADDK_C3B(2, 3, true)
   ADDK_C3B(2, 5, false) ADDK_C3B(3, 5, false) ADDK_C3B(4, 5, false) ADDK_C3B(5, 5, false)
   ADDK_C3BX(3, 3, false, 64) ADDK_C3BX(3, 5, false, 64) ADDK_C3BX(4, 3, false, 64) ADDK_C3BX(4, 3, true, 64)
-  ADDK_C3B(4, 1, false) ADDK_C3B(3, 1, false) ADDK_C3B(5, 1, false) ADDK_C3BX(4, 1, false, 64)
+  ADDK_C3B(4, 1, false) ADDK_C3B(3, 1, false) ADDK_C3B(5, 1, false) ADDK_C3BX(4, 1, false, 64) ADDK_C3B(2, 1, false)
 #undef ADDK_C3B
 #undef ADDK_C3BX
 #undef ADDK_C3B_
@@ -828,7 +834,9 @@ int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed
 // number of floats the packed-weight workspace of this launch needs; 0 = the halo-patch kernel does not apply
 extern "C" int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a) {
   if (!a || a->nsrc < 1 || a->nsrc > ADDK_MAX_SRC) return 0;
-  if (!c3_geometry_ok(a->KH, a->KW, a->stride, a->pad, a->dil, a->H, a->W, a->OH, a->OW, (long)a->N * a->OH * a->OW, a->Cout)) return 0;
+  int ktot = 0;
+  for (int i = 0; i < a->nsrc; ++i) ktot += a->src[i].C;
+  if (!c3_geometry_ok(a->KH, a->KW, a->stride, a->pad, a->dil, a->H, a->W, a->OH, a->OW, (long)a->N * a->OH * a->OW, a->Cout, ktot)) return 0;
   int nch = 0;
   for (int i = 0; i < a->nsrc; ++i) { if (a->src[i].C % 4 || a->src[i].ld % 4) return 0; nch += cdiv(a->src[i].C, C3_BK); }
   if (nch > C3_MAXCH || a->ldy % 4) return 0;
