@@ -273,7 +273,8 @@ def test_syncbn_path_world1_matches_local_bn(dev):
 def test_syncbn_captured_step_world1_equals_eager_and_capture_failure_applies_one_update(dev, monkeypatch):
     """The DEFAULT path of a step with collectives at world 1 (forced exchanges): the whole step incl. its RCCL calls captured
     in one hipGraph in thread-local capture mode (train.TrainStep._capture) — loss and parameters must equal the eager
-    launch list bit for bit over three steps (regression test of the capture abort fixed in round 2).  Then the fallback: a
+    launch list bit for bit over three steps (regression test of the capture abort fixed in round 2); the same for the N > 1
+    default, the step as hipGraph segments between eager collectives.  Then the fallback: a
     capture that raises must leave exactly ONE update applied by that call (it used to run the step twice)."""
     import os
     import torch.distributed as dist
@@ -305,6 +306,15 @@ def test_syncbn_captured_step_world1_equals_eager_and_capture_failure_applies_on
         assert cap.graph is not None, 'the collective step was not captured'
         assert lc == le, (lc, le)
         assert torch.equal(cap.flat_p, pe)
+        # the N > 1 default: hipGraph SEGMENTS between eagerly issued collectives (no RCCL call inside any capture)
+        seg = build(use_graph='seg')
+        assert seg.segmented and not seg.use_graph
+        ls = [seg.step().item() for _ in range(3)]
+        ngraphs = sum(1 for k, _ in seg.segs if k == 'graph')
+        ncalls = sum(1 for k, _ in seg.segs if k == 'call')
+        assert ngraphs > 100 and ncalls > 100, (ngraphs, ncalls)
+        assert ls == le, (ls, le)
+        assert torch.equal(seg.flat_p, pe)
         # a runtime that refuses the capture: eager replay from then on, ONE update per call
         one = build(use_graph=False)
         l1 = one.step().item()
