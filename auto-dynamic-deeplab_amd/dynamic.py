@@ -53,8 +53,11 @@ class DynamicPlan:
         self.calls = 0
         # the gate scalar travels through pinned host memory: an asynchronous 4-byte copy + an event the host waits on, instead of
         # a blocking read that idles the host until the whole device has drained (ADD.py:421 does `if confidence_value > threshold`)
-        self._conf_host = torch.empty(max(1, x.shape[0]), dtype=torch.float32).pin_memory()
-        self._conf_evt = torch.cuda.Event()
+        self._conf_host = torch.empty(max(1, x.shape[0]), dtype=torch.float32)
+        self._conf_evt = None
+        if x.is_cuda:                                   # (dry-run planning on CPU in tests/test_plan_dryrun.py builds plans without a device)
+            self._conf_host = self._conf_host.pin_memory()
+            self._conf_evt = torch.cuda.Event()
 
     def check_params(self):
         return all(p.data_ptr() == q for p, q in zip(self.params, self.ptrs))
@@ -98,8 +101,9 @@ class DynamicPlan:
                 conf = self.conf[k].y.reshape(x.shape[0], -1)
                 h0, h1 = self.head_rng[k]
                 self._conf_host[:x.shape[0]].copy_(conf.reshape(-1), non_blocking=True)
-                self._conf_evt.record()
-                self._conf_evt.synchronize()                          # the host waits for this one scalar only
+                if self._conf_evt is not None:
+                    self._conf_evt.record()
+                    self._conf_evt.synchronize()                      # the host waits for this one scalar only
                 if bool(self._conf_host[0] > threshold):              # the gate (ADD.py:421); bs = 1 as in eval.py:195-230
                     pos = h1
                     continue
