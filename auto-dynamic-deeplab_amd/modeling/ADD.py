@@ -304,7 +304,7 @@ class ADD(AddkModule):
 
     def _dynamic_plan(self, x, edm):
         from ..dynamic import DynamicPlan
-        key = ('dyn', tuple(x.shape), id(edm))
+        key = ('dyn', tuple(x.shape), id(edm), int(L.load().addk_get_conv_precision()))
         plans = self._plans()
         p = plans.get(key)
         if p is None or not p.check_params():

@@ -186,7 +186,7 @@ class AddkModule(nn.Module):
         want_grad = torch.is_grad_enabled() and (any(x.requires_grad for x in flat) or
                                                  any(p.requires_grad for p in self.parameters()))
         key = (tag, tuple(tuple(x.shape) for x in flat), tuple(bool(x.requires_grad) for x in flat), self.training,
-               want_grad, id(_world))
+               want_grad, id(_world), int(L.load().addk_get_conv_precision()))     # a plan belongs to the arithmetic mode it was built in
         plans = self._plans()
         plan = plans.get(key)
         if plan is not None and not plan.check_params():

@@ -250,6 +250,9 @@ class Graph:
         self._packs, self._pack_cmd = [], None   # hoisted weight packs of the halo-patch conv launches (descriptor bytes)
         self.meta = []                # per-launch algorithmic work of the dense convs (bench / roofline)
         self.grad_sync = None         # parallel.GradSync of a data-parallel train step (set before finalize)
+        # the arithmetic mode the packed weights and kernel choices of this plan were built for: replaying the launch list under
+        # another mode would hand bf16-plane packs to the fp32 kernel — run() / run_parallel() refuse it
+        self.precision = int(self.lib.addk_get_conv_precision())
 
     # ---------------- memory ----------------
     def buf(self, n, zero=False):
@@ -582,8 +585,15 @@ class Graph:
         lst.append(c)
         return c
 
+    def _check_mode(self):
+        if int(self.lib.addk_get_conv_precision()) != self.precision:
+            raise L.AddkError('this plan was built under arithmetic mode %d and cannot be replayed under mode %d: its packed weights and '
+                              'kernel choices belong to the mode it was built in (rebuild the plan after addk.set_precision)'
+                              % (self.precision, int(self.lib.addk_get_conv_precision())))
+
     def run(self, cmds, stream):
         """Sequential replay on one stream."""
+        self._check_mode()
         for name, fn, args in cmds:
             rc = fn(*args, stream)
             if rc:
@@ -596,6 +606,7 @@ class Graph:
         ns = self.nstreams
         if self.device.type != 'cuda':          # dry-run planning on CPU (tests): launches are stubbed
             return self.run(cmds, current_stream())
+        self._check_mode()
         if main is None:
             main = torch.cuda.current_stream()
         if ns == 1:

@@ -479,10 +479,12 @@ def main():
     # HBM-side traffic of that launch: PMC passes cannot run inside this process; the committed rocprofv3 --pmc measurement of the
     # same kernel and shape (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes: scripts/refresh_profiles_r02.sh) is quoted, labelled
     traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_decoder_conv3b.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_decoder_conv3b.json')
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_decoder_conv3b.json')
     if halo and math == 'bf16x6' and (n, h, w, a.F, a.genotype) == (2, 1024, 2048, 20, 'autodeeplab/genotype') and os.path.exists(tpath):
         try:
-            traffic, tsrc = json.load(open(tpath)).get('traffic_bytes_per_launch'), 'profiles/r02_pmc_traffic_decoder_conv3b.json (not measured in this run)'
+            traffic, tsrc = json.load(open(tpath)).get('traffic_bytes_per_launch'), 'profiles/%s (rocprofv3 --pmc passes of the same kernel and shape; not measured in this run)' % os.path.basename(tpath)
         except Exception:
             pass
     roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
