@@ -276,6 +276,10 @@ bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   for (int i = 0; i < a->nterm; ++i) k.term[i] = a->term[i];
   // two rows per wave where that still gives the chip >= 1.5 workgroups per CU (the LDS patch of a KG = 5 tile is 56 KB at R = 1)
   const long blocks2 = (long)a->N * cdiv(a->H, 8) * cdiv(a->W, 16);
+  // 80-channel tiles need 100-127 KB of LDS: one workgroup per CU.  That is fine while the launch has at most two rounds of them
+  // (config 2: 256 workgroups at 64x128) and LOSES to the separate depthwise / pointwise launches beyond (F = 40, 80 channels at
+  // 128x256 = 1024 workgroups: step 72.2 ms fused vs 66.5 ms unfused) — those shapes stay on the unfused kernels
+  if (kg == 5 && (long)a->N * cdiv(a->H, 4) * cdiv(a->W, 16) > 512) return false;
   c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1; c.io16 = a->io16 ? 1 : 0;
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
   k.rows = a->stats_rows;
