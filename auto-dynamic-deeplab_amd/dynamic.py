@@ -49,7 +49,8 @@ class DynamicPlan:
         self.inref.bind(self.x_static)
         self.graphs = {}          # (begin, end) -> hipGraph of that launch-list segment
         self.segs = {}            # (begin, end) -> that segment's launch list, level-ordered / batched / scheduled on two streams
-        g.nstreams = 2
+        import os
+        g.nstreams = int(os.environ.get('ADDK_STREAMS', '2'))
         self.calls = 0
         # the gate scalar travels through pinned host memory: an asynchronous 4-byte copy + an event the host waits on, instead of
         # a blocking read that idles the host until the whole device has drained (ADD.py:421 does `if confidence_value > threshold`)

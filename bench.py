@@ -199,7 +199,7 @@ def segment_roofline(model, x, mode, reps=8):
     inref2.bind(x)
     model.emit(g2, act2)
     g2.reorder = True
-    g2.finalize(2)
+    g2.finalize(int(os.environ.get('ADDK_STREAMS', '2')))
     for _ in range(2):
         g2.run_parallel(g2.fwd, None)
     whole2 = _events_ms(lambda: g2.run_parallel(g2.fwd, None), reps)
