@@ -31,7 +31,8 @@ constexpr int c3_maxdil(int ks) { return ks == 3 ? 18 : 2; }
 struct C3K {
   addk_src src[ADDK_MAX_SRC];
   int nsrc;
-  int N, H, W, dil;
+  int N, H, W, dil;       // H, W: the OUTPUT map (tiles, epilogue)
+  int IH, IW;               // the input map (= H, W for the stride-1 launches)
   int Cn, ldy;
   float* y;
   const float* wp;          // packed weights of this launch
@@ -42,6 +43,8 @@ struct C3K {
   addk_src dst; int accumulate;
   int vecY, red32;
   long P; int ntiles, spr;
+  int st;                   // stride (host-side dispatch; 2 = the de-interleaved 3x3 forward of conv3b_kernel)
+  int om, oro, oco, OHo, OWo;   // output pixel of tile-grid position (oh, ow): (om oh + oro, om ow + oco) in an OHo x OWo map (om = 1: the grid itself)
 };
 
 struct PackK {
@@ -54,7 +57,9 @@ struct PackK {
   int cvalid[C3_MAXCH];     // valid K entries in the chunk (<= 16)
   float* out;
   int planes;               // 0: fp32 fragments for conv3_kernel; 2 / 3: bf16 planes (h, m[, l]) in 32-row fragment order for conv3b_kernel
-  int dil_odd;              // conv3b: odd dilation -> taps with odd (kh + kw) carry a minus sign (checkerboard accumulation, see conv3b_kernel)
+  int dil_odd;              // conv3b checkerboard accumulation (see conv3b_kernel): 1 = odd dilation, taps with odd (kh + kw) carry a minus sign;
+                            // 2 = stride 2, the taps of kernel column 2 carry it
+  int s2d;                  // conv3b: 1 = the four parity-class packs of the stride-2 data gradient (c3b_pack_s2d_body)
 };
 
 // out[colblk][T = chunk*taps + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
@@ -347,7 +352,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CB_PT = 4;                   // 32-pixel tiles per wave (128 pixels)
-constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP) { return ks == 1 ? bpx : ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
+constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP, int st = 1) { return st == 2 ? 2 * bpx + 16 : ks > 10 ? bpx + 4 : ks == 1 ? bpx : ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
 
 __device__ __forceinline__ unsigned bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b << 16); }
@@ -368,7 +373,45 @@ __device__ __forceinline__ void split4(const float4 v, uint2 (&pl)[NP]) {
 
 // packed weights: out (16-byte units) [colblk][T = chunk*taps + tap][tile (wave) i][plane][lane] = 8 bf16:
 //   W(row = colblk*32*bct + i*32 + (lane & 31), tap, k = 8*(lane >> 5) + j), j = 0..7       (bct = 32-row tiles per block)
+// Stride-2 data gradient (3x3, pad 1): input pixel (2a + pi, 2b + pj) collects dy(a + th, b + tw) W[kh][kw] over th <= pi, tw <= pj with
+// kh = 1 for pi = 0, else {2, 0}[th] (same for columns) — 1, 2, 2, 4 of the nine taps per parity class.  Four packs back to back, class
+// c = 2 pi + pj at (taps of the classes before) * unit, each [colblk][chunk * tc + tap][tile][plane][lane]; tap (th, tw) carries
+// (-1)^(th + tw), its share of the checkerboard sign over the class grid (a, b).
+__device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, long stride) {
+  const int BC = 32 * p.bct, NP = p.planes;
+  const long unit = (long)((p.Cn + BC - 1) / BC) * p.nchunks * p.bct * 64;          // lanes per tap
+  uint4* out = reinterpret_cast<uint4*>(p.out);
+  for (long idx = first; idx < 9 * unit; idx += stride) {
+    const int u = (int)(idx / unit);
+    const int cls = u < 1 ? 0 : u < 3 ? 1 : u < 5 ? 2 : 3, pre = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
+    const int pi = cls >> 1, pj = cls & 1, twn = 1 + pj, tc = (1 + pi) * twn;
+    long r = idx - pre * unit;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int i = (int)(r % p.bct); r /= p.bct;
+    const int nT = p.nchunks * tc;
+    const int T = (int)(r % nT); const int blk = (int)(r / nT);
+    const int chunk = T / tc, tap = T - chunk * tc;
+    const int th = tap / twn, tw = tap - th * twn;
+    const int kh = pi ? (th ? 0 : 2) : 1, kw = pj ? (tw ? 0 : 2) : 1;
+    const int row = blk * BC + i * 32 + (lane & 31), k0 = 8 * (lane >> 5);
+    unsigned b[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      const int kk = k0 + j;
+      if (row < p.Cn && kk < p.cvalid[chunk]) v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(kh * 3 + kw) * p.cin_total + p.w_choff + row];
+      if ((th + tw) & 1) v = -v;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
+    }
+    uint4* o = out + pre * unit * NP + (((long)blk * nT + T) * p.bct + i) * NP * 64 + lane;
+    for (int k = 0; k < NP; ++k)
+      o[k * 64] = make_uint4(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16), b[k][4] | (b[k][5] << 16), b[k][6] | (b[k][7] << 16));
+  }
+}
+
 __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride) {
+  if (p.s2d) { c3b_pack_s2d_body(p, first, stride); return; }
   const int BC = 32 * p.bct, NP = p.planes;
   const int nT = p.nchunks * p.taps;
   const long per_blk = (long)nT * p.bct * 64;
@@ -382,7 +425,8 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
     const int chunk = T / p.taps, tap = T - chunk * p.taps;
     const int row = blk * BC + i * 32 + (lane & 31), k0 = 8 * (lane >> 5);
     const int ks = p.taps == 9 ? 3 : 5;
-    const bool flip = p.dil_odd && (((tap / ks) + (tap % ks)) & 1);      // (-1)^((kh+kw) d): the tap's share of the checkerboard sign
+    const bool flip = p.dil_odd == 1 ? (((tap / ks) + (tap % ks)) & 1) != 0      // (-1)^((kh+kw) d): the tap's share of the checkerboard sign
+                    : p.dil_odd == 2 ? (tap % ks) == 2 : false;
     unsigned b[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -407,14 +451,25 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
 // a 64-channel block (2-wave blocks staged 13-22 slots per thread and spilled).
 // BPX = 64: half-width pixel tiles (two accumulator tiles per wave) for launches that would otherwise put fewer than ~1.5
 // blocks on a CU (ASPP at 64x128, the 80-channel cell convs at 63x127: 126-256 blocks of 128 pixels = one wave per SIMD or less).
-template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP>
-__global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
+// ST = 2 (stem2: 3x3, stride 2, pad 1, forward): output pixel ow reads input columns 2 ow - 1 + kw.  The patch row is staged
+// DE-INTERLEAVED — even patch columns pj = 2 e at LDS position e (0..BPX), odd ones pj = 2 o + 1 at position OB + o — so that
+// the fragment of tap kw is again 32 CONSECUTIVE positions (kw = 0: e = lp, kw = 1: o = lp, kw = 2: e = lp + 1) and the
+// swizzle / bank picture of the stride-1 kernel holds unchanged.  Checkerboard: position idx carries the sign (-1)^(oh+ow0+idx),
+// which is the output pixel's for kw = 0, 1 and its negative for kw = 2 — that tap's weights are packed negated.
+template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1>
+__device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const int gx) {      // workgroup bx of gx along x (tiles, slab row)
+  static_assert(ST == 1 || (ST == 2 && KS == 3 && !BIGD && MODE == MODE_FWD), "stride 2: 3x3 forward only");
+  // KS = 12 / 21 / 22: a 1x2 / 2x1 / 2x2 tap set anchored at its first tap (no centring) — the parity classes of the stride-2 data
+  // gradient (c3b_s2_dgrad below); 1, 3, 5: the centred square kernels
+  constexpr int KH_ = KS > 10 ? KS / 10 : KS, KW_ = KS > 10 ? KS % 10 : KS;
+  static_assert(KS < 10 || (MODE == MODE_DGRAD && !BIGD && ST == 1), "anchored tap sets: data gradient only");
+  constexpr int OB = BPX + 16;                                      // ST = 2: LDS position of the first odd patch column
   constexpr int BC = 32 * WC, NTHR = 64 * WC * PH, PT = BPX / 32 / PH;
-  constexpr int TAPS = KS * KS, HK = KS / 2;
-  constexpr int PWP = cb_pwmax(KS, BIGD, BPX);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
-  constexpr int NS = (KS * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
+  constexpr int TAPS = KH_ * KW_, HK = KS > 10 ? 0 : KS / 2;
+  constexpr int PWP = cb_pwmax(KS, BIGD, BPX, ST);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
+  constexpr int NS = (KH_ * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
   static_assert(NS <= 32, "slot mask is 32 bits");
-  constexpr int PLANE = KS * PWP * 2;                             // uint4 units per plane
+  constexpr int PLANE = KH_ * PWP * 2;                             // uint4 units per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* red = reinterpret_cast<double*>(smem);                  // [PH][BC][2] running statistics of this block (per pixel half)
   uint4* Pl = reinterpret_cast<uint4*>(smem + ((PH * BC * 16 + 15) & ~15));   // [NP][KS][PWP][2] 16-byte halves
@@ -422,41 +477,48 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wave = wv % WC, wpx = wv / WC, lp32 = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.y * BC;
-  const int d = p.dil, PW = BPX + (KS - 1) * d;
+  const int d = p.dil;
   for (int i = t; i < PH * BC * 2; i += NTHR) red[i] = 0.0;
 
   const int q = t & 3;
+  // patch slot -> (patch row r, LDS position sp in the row, patch column pj = input column - first input column of the tile)
+  auto slot_geo = [&](int k, int& r, int& sp, int& pj, bool& live) {
+    const int pix = (t + NTHR * k) >> 2;
+    r = pix / PWP; sp = pix - r * PWP;
+    if (ST == 1) { pj = sp; live = r < KH_ && pj < BPX + (KW_ - 1) * p.dil; }
+    else { const bool odd = sp >= OB; const int idx = odd ? sp - OB : sp; pj = 2 * idx + (odd ? 1 : 0); live = r < KH_ && (odd ? idx < BPX : idx <= BPX); }
+  };
   // fragment read base per kernel column: pixel lane%32 + kw*d of patch row 0, the 16-byte half swizzled by bit 3 of the pixel
   // (tile j adds 32 pixels: bit 3 unchanged); patch row kh and tile j are immediate offsets
-  int xb[KS];
+  int xb[KW_];
 #pragma unroll
-  for (int kw = 0; kw < KS; ++kw) { const int pj = lp32 + kw * d; xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)); }
+  for (int kw = 0; kw < KW_; ++kw) { const int pj = ST == 2 ? (kw == 1 ? OB + lp32 : lp32 + (kw >> 1)) : lp32 + kw * d; xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)); }
   const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)blockIdx.y * p.wp_blk + (long)wave * NP * 64 + lane);
   const int nT = p.nT;
   unsigned pmask = 0;                         // bit k: parity of (r*d + pj) of this thread's patch slot k (checkerboard sign, below)
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    const int pix = (t + NTHR * k) >> 2;
-    const int r = pix / PWP, pj = pix - r * PWP;
-    pmask |= (unsigned)((r * d + pj) & 1) << k;
+    int r, sp, pj; bool live;
+    slot_geo(k, r, sp, pj, live);
+    pmask |= (unsigned)((ST == 2 ? sp : r * d + pj) & 1) << k;
   }
 
   const int tpx = p.ntiles >> 3;
   const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
-  for (int tlin = blockIdx.x; tlin < p.ntiles; tlin += gridDim.x) {
+  for (int tlin = bx; tlin < p.ntiles; tlin += gx) {
     const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
     const int rowid = tile / p.spr, sx = tile - rowid * p.spr;
     const int n = rowid / p.H, oh = rowid - n * p.H;
     const int ow0 = sx * BPX;
     unsigned vmask = 0;
-    const int pbase = (n * p.H + oh - HK * d) * p.W + ow0 - HK * d;
+    const int pbase = (n * p.IH + oh * ST - HK * d) * p.IW + ow0 * ST - HK * d;
     const unsigned par0 = (unsigned)(oh + ow0);                 // parity of (ih + iw) of patch element (r, pj) = par0 + r*d + pj (the -2 HK d is even)
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      const int pix = (t + NTHR * k) >> 2;
-      const int r = pix / PWP, pj = pix - r * PWP;
-      const int ih = oh + (r - HK) * d, iw = ow0 - HK * d + pj;
-      const bool ok = r < KS && pj < PW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      int r, sp, pj; bool live;
+      slot_geo(k, r, sp, pj, live);
+      const int ih = oh * ST + (r - HK) * d, iw = ow0 * ST - HK * d + pj;
+      const bool ok = live && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
       vmask |= (ok ? 1u : 0u) << k;
     }
 
@@ -469,7 +531,7 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
     // inherits its error from): the running sums are flushed into a second accumulator set after every 16-channel chunk, so a
     // rounding error grows with sqrt(MFMAs per chunk) + sqrt(chunks) instead of sqrt(all MFMAs) (stem1: 54 + 4 instead of 216) —
     // what a CPU library's blocked partial sums do (the even-size gradient deficit starts at stem1's K = 576 chain).
-    constexpr bool BLK = PH == 2 && KS == 3 && !BIGD;          // (the 5x5 and wide-dilation variants have no registers left: 256 + scratch with a second set)
+    constexpr bool BLK = PH == 2 && (KS == 3 || KS > 10) && !BIGD;          // (the 5x5 and wide-dilation variants have no registers left: 256 + scratch with a second set)
     f32x16 acc2[BLK ? PT : 1];
     if (BLK) {
 #pragma unroll
@@ -491,9 +553,9 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
       const float* sb = S.x + (pch ? c : 0);
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        const int pix = (t + NTHR * k) >> 2;
-        const int r = pix / PWP, pj = pix - r * PWP;
-        const int po = ((vmask >> k) & 1u) ? pbase + r * d * p.W + pj : 0;
+        int r, sp, pj; bool live;
+        slot_geo(k, r, sp, pj, live);
+        const int po = ((vmask >> k) & 1u) ? pbase + r * d * p.IW + pj : 0;
         ra[k] = ld4(sb + (long)po * S.ld);
       }
     };
@@ -507,12 +569,12 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
         const bool ok = pch && ((vmask >> k) & 1u);
         const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
-        const int pix = (t + NTHR * k) >> 2;
-        const int r = pix / PWP, pj = pix - r * PWP;
-        if (r < KS) {
+        int r, sp, pj; bool live;
+        slot_geo(k, r, sp, pj, live);
+        if (r < KH_) {
           uint2 pl[NP];
           split4<NP>(v, pl);
-          const int slot = (r * PWP + pj) * 2 + ((q >> 1) ^ ((pj >> 3) & 1));
+          const int slot = (r * PWP + sp) * 2 + ((q >> 1) ^ ((sp >> 3) & 1));
 #pragma unroll
           for (int m = 0; m < NP; ++m) Pl2[(m * PLANE + slot) * 2 + (q & 1)] = pl[m];
         }
@@ -527,7 +589,7 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
     };
     // pixel fragment of (tap, tile j): lane reads 16 bytes of pixel (32 j + lane%32 + kw*d) in patch row kh, k half lane/32
     auto read_x = [&](int tap, int j, uint4* x) {
-      const int kh = tap / KS, kw = tap - kh * KS;
+      const int kh = tap / KW_, kw = tap - kh * KW_;
       const uint4* b = Pl + xb[kw];
 #pragma unroll
       for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + (kh * PWP + (wpx * PT + j) * 32) * 2];
@@ -619,7 +681,8 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       const int lp = (wpx * PT + j) * 32 + lp32;
-      const long pp = (long)rowid * p.W + ow0 + lp;
+      // output pixel: the tile grid's (oh, ow) itself, or (stride-2 data gradient) pixel (om oh + oro, om ow + oco) of the OHo x OWo map
+      const long pp = p.om == 1 ? (long)rowid * p.W + ow0 + lp : ((long)n * p.OHo + oh * p.om + p.oro) * p.OWo + (long)(ow0 + lp) * p.om + p.oco;
       const bool pin = ow0 + lp < p.W;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -672,10 +735,25 @@ __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
   if (p.slab) {
     __syncthreads();
     if (t < BC && n0 + t < p.Cn) {
-      double* o = p.slab + ((long)blockIdx.x * p.slab_ld + n0 + t) * 2;
+      double* o = p.slab + ((long)bx * p.slab_ld + n0 + t) * 2;
       o[0] = red[2 * t] + (PH > 1 ? red[2 * (BC + t)] : 0.0); o[1] = red[2 * t + 1] + (PH > 1 ? red[2 * (BC + t) + 1] : 0.0);
     }
   }
+}
+
+template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1>
+__global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
+  conv3b_body<WC, KS, MODE, NP, BIGD, PH, BPX, ST>(p, blockIdx.x, gridDim.x);
+}
+// the four parity classes of the stride-2 data gradient in ONE launch: workgroups [row0[c], row0[c + 1]) run class c
+struct C3K4 { C3K c[4]; int row0[5]; };
+template <int NP>
+__global__ void __launch_bounds__(256, 2) conv3b_s2d_kernel(const C3K4 q) {
+  const int bx = blockIdx.x;
+  if (bx < q.row0[1])      conv3b_body<2, 1,  MODE_DGRAD, NP, false, 2>(q.c[0], bx, q.row0[1]);
+  else if (bx < q.row0[2]) conv3b_body<2, 12, MODE_DGRAD, NP, false, 2>(q.c[1], bx - q.row0[1], q.row0[2] - q.row0[1]);
+  else if (bx < q.row0[3]) conv3b_body<2, 21, MODE_DGRAD, NP, false, 2>(q.c[2], bx - q.row0[2], q.row0[3] - q.row0[2]);
+  else                     conv3b_body<2, 22, MODE_DGRAD, NP, false, 2>(q.c[3], bx - q.row0[3], q.row0[4] - q.row0[3]);
 }
 
 // 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 3..5 that pads the channel count least (ties: the wider)
@@ -738,7 +816,7 @@ long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
   return (long)cdiv(Cn, 16 * bct) * nchunks * taps * bct * 256;
 }
 inline int c3b_narrow_k() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_NARROW_K"); v = e ? atoi(e) : 0; } return v; }
-bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn, int ktot = 0) {
+bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn, int ktot = 0, bool fwd = false) {
   if (KH == 1 && KW == 1) {      // wide pointwise heads (ASPP 1x1, the 1280 -> 256 concat conv): the split kernel as a plain GEMM (KS = 1)
     // [r3] and the FORWARD of the cells' glue convs with many input channels (dense-connection preprocess: K = 200..800 -> 40..160): ktot
     // is the forward reduction length (0 for data gradients), ADDK_C3B_NARROW_K the smallest K that takes this path.  Measured and left OFF
@@ -748,6 +826,12 @@ bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, 
     return c3_enabled() && c3b_pointwise_enabled() && stride == 1 && dil == 1 && pad == 0 && OH == H && OW == W && (wide || narrow) && c3_planes(Cn, 1) != 0 &&
            W >= 48 && P >= 2048;
   }
+  if (stride == 2) {             // [r3] stem2 (3x3, stride 2, pad 1) forward on the split kernel: 128-channel blocks of 4 waves, de-interleaved patch rows
+    static int s2 = -1; if (s2 < 0) { const char* e = getenv("ADDK_C3B_STRIDE2"); s2 = (e && e[0] == '0') ? 0 : 1; }
+    if (!(s2 && c3_enabled() && KH == 3 && KW == 3 && dil == 1 && pad == 1 && OH == (H - 1) / 2 + 1 && OW == (W - 1) / 2 + 1 && c3_planes(Cn, 9) != 0 && OW >= 96)) return false;
+    if (fwd) return Cn >= 96 && c3b_wc(Cn, (long)P) == 4 && P >= 8192;
+    return Cn >= 32 && Cn <= 64 && P >= 32768;      // data gradient: the four parity classes as 2-tile blocks (c3b_s2_dgrad)
+  }
   if (!c3_enabled() || KH != KW || !(KH == 3 || KH == 5) || stride != 1 || dil < 1 || dil > c3_maxdil(KH)) return false;
   if (!(pad == dil * (KH / 2) && OH == H && OW == W && Cn >= 32)) return false;
   // the split kernel has half-width (64-pixel) tiles and also takes the 32x64 maps of level 3 (dil_conv at 160 channels: 152 us on
@@ -756,9 +840,47 @@ bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, 
   return W >= 100 && P >= 8192;
 }
 
+// stride-2 data gradient: one launch per parity class of the input pixel (each a stride-1 gather over dy with 1 / 2 / 2 / 4 taps and a
+// strided scatter of its outputs); the statistics-slab rows (= workgroups) are shared out in proportion to the tap counts
+int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
+  const int wc = 2;
+  pk.bct = wc; pk.mode = MODE_DGRAD; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = 0; pk.s2d = 1;
+  if (desc_out) { *desc_out = pk; return ADDK_OK; }
+  if (rows < 9) return 1;
+  const long unit = (long)cdiv(k.Cn, 32 * wc) * pk.nchunks * wc * 64;
+  if (!packed) { int pb = cdiv(9 * unit, 256); if (pb > 4096) pb = 4096; hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk); }
+  C3K4 q;
+  int row0 = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int pi = cls >> 1, pj = cls & 1, tc = (1 + pi) * (1 + pj), pre = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
+    const int rc = cls == 3 ? rows - row0 : (rows * tc) / 9;
+    C3K& c = q.c[cls];
+    c = k;
+    c.H = (k.OHo - pi + 1) / 2; c.W = (k.OWo - pj + 1) / 2;
+    c.om = 2; c.oro = pi; c.oco = pj;
+    c.nT = pk.nchunks * tc;
+    c.wp = pk.out + pre * unit * np * 4;
+    c.wp_blk = (long)pk.nchunks * tc * wc * np * 64;
+    c.spr = cdiv(c.W, C3_BP);
+    c.ntiles = c.N * c.H * c.spr;
+    c.red32 = 1;
+    if (c.slab) c.slab += (long)row0 * c.slab_ld * 2;
+    q.row0[cls] = row0;
+    row0 += rc;
+  }
+  q.row0[4] = rows;
+  const size_t lds = (size_t)((2 * 32 * wc * 16 + 15) & ~15) + (size_t)np * 2 * cb_pwmax(22, false, C3_BP) * 32;
+  dim3 grid(rows, cdiv(k.Cn, 32 * wc));
+  if (np == 3) hipLaunchKernelGGL(conv3b_s2d_kernel<3>, grid, dim3(256), lds, st, q);
+  else hipLaunchKernelGGL(conv3b_s2d_kernel<2>, grid, dim3(256), lds, st, q);
+  return addk_check_launch("conv3b stride-2 data gradient");
+}
+
 int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
+  pk.s2d = 0;
+  if (k.st == 2 && mode == MODE_DGRAD) return c3b_s2_dgrad(k, pk, rows, st, packed, desc_out, np);
   const int wc = c3b_wc(k.Cn, k.P);
-  pk.bct = wc; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = k.dil & 1;
+  pk.bct = wc; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = k.st == 2 ? 2 : (k.dil & 1);
   k.nT = pk.nchunks * pk.taps;
   k.wp = pk.out;
   k.wp_blk = (long)pk.nchunks * pk.taps * wc * np * 64;          // 16-byte units per column block
@@ -767,8 +889,9 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const int ph = wc == 2 ? 2 : 1;                                  // <= 64 channels: 4 waves = 2 channel tiles x 2 pixel halves
   // half-width tiles where 128-pixel tiles leave the chip short of blocks (instantiated for 3- and 4-wave blocks)
   const long blocks128 = (long)k.N * k.H * cdiv(k.W, C3_BP) * cdiv(k.Cn, 32 * wc);
-  const bool half = ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && !(wc == 3 && ks == 1) && blocks128 < 384 && c3b_half_enabled();      // (rows of <= 64 pixels land here too)
-  const int bpx = half ? 64 : C3_BP;
+  const bool half = k.st == 1 && ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && !(wc == 3 && ks == 1) && blocks128 < 384 && c3b_half_enabled();      // (rows of <= 64 pixels land here too)
+  static int s2bpx = -1; if (s2bpx < 0) { const char* e = getenv("ADDK_C3B_S2_BPX"); s2bpx = e ? atoi(e) : 64; }
+  const int bpx = k.st == 2 ? (s2bpx == 128 ? 128 : 64) : half ? 64 : C3_BP;
   k.spr = cdiv(k.W, bpx);
   k.ntiles = k.N * k.H * k.spr;
   k.red32 = 1;
@@ -776,7 +899,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const long total = (long)cdiv(k.Cn, 32 * wc) * k.nT * wc * 64;   // pack threads: one per (tile, lane)
   int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
   if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
-  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd, bpx) * 32;
+  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd, bpx, k.st) * 32;
   dim3 grid(rows, cdiv(k.Cn, 32 * wc));
   bool done = false;
 #define ADDK_C3B_(W_, K_, M_, P_, D_, X_) { \
@@ -789,11 +912,24 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
     if (mode == MODE_FWD) { if (np == 3) ADDK_C3B_(W_, K_, MODE_FWD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_FWD, 2, D_, X_) } \
     else { if (np == 3) ADDK_C3B_(W_, K_, MODE_DGRAD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_DGRAD, 2, D_, X_) } }
 #define ADDK_C3B(W_, K_, D_) ADDK_C3BX(W_, K_, D_, C3_BP)
+  if (k.st == 2) {               // stem2 forward
+    if (wc == 4 && ks == 3 && mode == MODE_FWD) {
+#define ADDK_C3S2(P_, X_) { \
+      static bool attr = false; \
+      auto fn = &conv3b_kernel<4, 3, MODE_FWD, P_, false, 1, X_, 2>; \
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+      hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k); done = true; }
+      if (bpx == 64) { if (np == 3) ADDK_C3S2(3, 64) else ADDK_C3S2(2, 64) }
+      else { if (np == 3) ADDK_C3S2(3, C3_BP) else ADDK_C3S2(2, C3_BP) }
+#undef ADDK_C3S2
+    }
+  } else {
   ADDK_C3B(2, 3, false) ADDK_C3B(3, 3, false) ADDK_C3B(4, 3, false) ADDK_C3B(5, 3, false)
   ADDK_C3B(3, 3, true) ADDK_C3B(4, 3, true) ADDK_C3B(5, 3, true) ADDK_C3B(2, 3, true)
   ADDK_C3B(2, 5, false) ADDK_C3B(3, 5, false) ADDK_C3B(4, 5, false) ADDK_C3B(5, 5, false)
   ADDK_C3BX(3, 3, false, 64) ADDK_C3BX(3, 5, false, 64) ADDK_C3BX(4, 3, false, 64) ADDK_C3BX(4, 3, true, 64)
   ADDK_C3B(4, 1, false) ADDK_C3B(3, 1, false) ADDK_C3B(5, 1, false) ADDK_C3BX(4, 1, false, 64) ADDK_C3B(2, 1, false)
+  }
 #undef ADDK_C3B
 #undef ADDK_C3BX
 #undef ADDK_C3B_
@@ -802,7 +938,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
 }
 
 int c3_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out = nullptr) {
-  pk.planes = 0; pk.dil_odd = 0;
+  pk.planes = 0; pk.dil_odd = 0; pk.s2d = 0;
   if (const int np = c3_planes(k.Cn, pk.taps)) return c3b_launch(k, pk, mode, rows, st, packed, desc_out, np);
   const int bct = c3_bct(k.Cn, k.P);
   pk.bct = bct; pk.mode = mode; pk.Cn = k.Cn;
@@ -836,11 +972,11 @@ extern "C" int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a) {
   if (!a || a->nsrc < 1 || a->nsrc > ADDK_MAX_SRC) return 0;
   int ktot = 0;
   for (int i = 0; i < a->nsrc; ++i) ktot += a->src[i].C;
-  if (!c3_geometry_ok(a->KH, a->KW, a->stride, a->pad, a->dil, a->H, a->W, a->OH, a->OW, (long)a->N * a->OH * a->OW, a->Cout, ktot)) return 0;
+  if (!c3_geometry_ok(a->KH, a->KW, a->stride, a->pad, a->dil, a->H, a->W, a->OH, a->OW, (long)a->N * a->OH * a->OW, a->Cout, ktot, true)) return 0;
   int nch = 0;
   for (int i = 0; i < a->nsrc; ++i) { if (a->src[i].C % 4 || a->src[i].ld % 4) return 0; nch += cdiv(a->src[i].C, C3_BK); }
   if (nch > C3_MAXCH || a->ldy % 4) return 0;
-  return c3_pack_floats(a->Cout, nch, (long)a->N * a->H * a->W, a->KH * a->KW);
+  return c3_pack_floats(a->Cout, nch, (long)a->N * a->OH * a->OW, a->KH * a->KW);
 }
 extern "C" int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a) {
   if (!a) return 0;
@@ -870,12 +1006,13 @@ static int c3_fwd(const addk_conv_args* a, int rows, void* stream, PackK* desc_o
     choff += a->src[i].C;
   }
   pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = 0; pk.out = a->wpack;
-  k.N = a->N; k.H = a->H; k.W = a->W; k.dil = a->dil;
+  k.N = a->N; k.H = a->OH; k.W = a->OW; k.IH = a->H; k.IW = a->W; k.dil = a->dil; k.st = a->stride;
+  k.om = 1; k.oro = k.oco = 0; k.OHo = a->OH; k.OWo = a->OW;
   k.Cn = a->Cout; k.ldy = a->ldy; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n;
   k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
   k.dst = addk_src{nullptr, nullptr, nullptr, 0, 0, 0, 0}; k.accumulate = 0;
   k.vecY = 1;
-  k.P = (long)a->N * a->H * a->W;
+  k.P = (long)a->N * a->OH * a->OW;
   return c3_launch(k, pk, MODE_FWD, rows, (hipStream_t)stream, a->wpack_ready != 0, desc_out);
 }
 
@@ -893,7 +1030,8 @@ static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK
     ++nch;
   }
   pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = a->w_choff; pk.out = a->wpack;
-  k.N = a->N; k.H = a->H; k.W = a->W; k.dil = a->dil;
+  k.N = a->N; k.H = a->H; k.W = a->W; k.IH = a->OH; k.IW = a->OW; k.dil = a->dil; k.st = a->stride;      // the gather runs over dy (OH x OW)
+  k.om = 1; k.oro = k.oco = 0; k.OHo = a->H; k.OWo = a->W;
   k.Cn = a->dst.C; k.ldy = a->ldg; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr;
   k.slab = (double*)a->dab; k.slab_ld = a->dst.C;
   k.dst = a->dst; k.accumulate = a->accumulate;

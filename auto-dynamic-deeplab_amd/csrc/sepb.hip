@@ -15,6 +15,7 @@
 //     [C][2] of the (dA, dB) slab per workgroup.
 // The pointwise WEIGHT gradient stays with the batched register-streaming kernel (wgrad.hip), which reads dy and the stored
 // depthwise output.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -263,6 +264,7 @@ bool sepb_fill(const addk_sep_bwd_args* a, SepbK& k, SepbCfg& c) {
   // 128x256 = 1024 workgroups: step 72.2 ms fused vs 66.5 ms unfused) — those shapes stay on the unfused kernels
   if (kg == 5 && (long)a->N * cdiv(a->H, 4) * cdiv(a->W, 16) > 512) return false;
   c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1;
+  { static int fr = -1; if (fr < 0) { const char* e = getenv("ADDK_SEP_R"); fr = e ? atoi(e) : 0; } if (fr == 1 || (fr == 2 && kg == 3)) c.r = fr; }   // tuning aid
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
   return true;
 }

@@ -17,6 +17,7 @@
 //   * training epilogue: raw store, depthwise output stored for the backward pass, BatchNorm (sum, sumsq) partials ->
 //     slab row -> the LAST workgroup finalizes the statistics (bnfin.h): no bn_finalize launch;
 //     inference epilogue: own frozen BatchNorm + the other branches of the cell block (ADD.py:108).
+#include <stdlib.h>
 #include "common.h"
 #include "bnfin.h"
 
@@ -280,7 +281,9 @@ bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   // (config 2: 256 workgroups at 64x128) and LOSES to the separate depthwise / pointwise launches beyond (F = 40, 80 channels at
   // 128x256 = 1024 workgroups: step 72.2 ms fused vs 66.5 ms unfused) — those shapes stay on the unfused kernels
   if (kg == 5 && (long)a->N * cdiv(a->H, 4) * cdiv(a->W, 16) > 512) return false;
-  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1; c.io16 = a->io16 ? 1 : 0;
+  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1;
+  { static int fr = -1; if (fr < 0) { const char* e = getenv("ADDK_SEP_R"); fr = e ? atoi(e) : 0; } if (fr == 1 || (fr == 2 && kg == 3)) c.r = fr; }   // tuning aid
+  c.io16 = a->io16 ? 1 : 0;
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
   k.rows = a->stats_rows;
   if (k.slab && k.gx > k.rows) return false;             // the caller sizes the slab with addk_sep_rows

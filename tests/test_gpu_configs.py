@@ -130,7 +130,14 @@ def test_add_configs_eval_and_train_step(dev, golden, tag):
 @pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])
 def test_f40_frozen_bn_gradients(dev, gname):
     """Config 5's architecture, backward included, at 2x256x512 (cell maps >= 8k pixels: the large-map kernels engage):
-    BatchNorm frozen, every conv-weight gradient held against the fp64 oracle relative to the fp32 oracle's own error."""
+    BatchNorm frozen, every conv-weight gradient held against the fp64 oracle relative to the fp32 oracle's own error.
+
+    The statistic is the DISTRIBUTION over the ~500 gradients (median, 90th percentile, maximum), each against the fp32 oracle's own.
+    The maximum alone is not a stable quantity even with BatchNorm frozen: the fp32 oracle's own maximum moves from 3.5e-3 to 1.1e-2
+    (x3.1, p90 x1.9) when its INPUT is nudged by one ulp (tests/tools/f40_frozen_probe.py, profiles/r03_f40_frozen_bn_sensitivity_probe.txt:
+    ReLU / max-pool decisions near ties flip and a cluster of level-1 cells moves together), and addk showed the same cluster —
+    max 1.3e-2 with stem2 on the generic fp32-MFMA kernel, 2.2e-3 (below the oracle) with stem2 on the split kernel, both kernels
+    individually within 2e-5 of fp64 per launch (test_gpu_fast_kernels.py).  A wrong kernel moves its layers by O(1), not by x3."""
     hw = (256, 512)
     ma, mo, _, args = _build(dev, 40, ARCH_C2, _geno(gname), seed=900)
     ma.eval(); mo.eval()
@@ -157,9 +164,10 @@ def test_f40_frozen_bn_gradients(dev, gname):
             theirs.append(rel_err(p.grad.double(), p64[k].grad))
     assert len(ours) > 400
     med = lambda v: sorted(v)[len(v) // 2]
-    _log('F40_%s frozen-BN 256x512, %d conv-weight gradients vs fp64: addk max %.2e median %.2e | fp32 oracle max %.2e median %.2e',
-         gname, len(ours), max(ours), med(ours), max(theirs), med(theirs))
-    assert max(ours) <= max(3 * max(theirs), 2e-3) and med(ours) <= max(3 * med(theirs), 2e-4)
+    p90 = lambda v: sorted(v)[int(len(v) * 0.9)]
+    _log('F40_%s frozen-BN 256x512, %d conv-weight gradients vs fp64: addk max %.2e p90 %.2e median %.2e | fp32 oracle max %.2e p90 %.2e median %.2e',
+         gname, len(ours), max(ours), p90(ours), med(ours), max(theirs), p90(theirs), med(theirs))
+    assert med(ours) <= max(2 * med(theirs), 2e-4) and p90(ours) <= max(5 * p90(theirs), 1e-3) and max(ours) <= max(10 * max(theirs), 2e-3)
 
 
 @pytest.mark.parametrize('hw', [(65, 129), (64, 128)], ids=['odd65x129', 'even64x128'])

@@ -477,3 +477,93 @@ def test_fused_sepconv_half_backward_matches_fp64_autograd(lib, shape):
             'dab': _rel(outs[0][1], torch.stack([ar_.grad, br_.grad], 1)), 'dw': _rel(outs[0][2], wd.grad.view(Cc, k * k))}
     bad = ['%s %.2e' % kv for kv in errs.items() if not kv[1] <= TOL]
     assert not bad, '%s beyond %.0e: %s' % (name, TOL, ', '.join(bad))
+
+
+S2_SHAPES = [
+    # name,        N,   H,   W, source channels, Cout
+    ('stem2_even', 2,  66, 258, (64,), 128),
+    ('stem2_odd',  1, 129, 257, (64,), 128),              # odd input: the last output row / column reads the image edge, no padding row below
+    ('s2_two_src', 1,  96, 400, (24, 8), 128),            # K tail (8 of 16 channels in the last chunk), 200 = 128 + 72 output columns
+]
+
+
+@pytest.mark.parametrize('prec', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('shape', S2_SHAPES, ids=[s[0] for s in S2_SHAPES])
+def test_stride2_conv_on_split_kernel_matches_fp64_reference(lib, shape, prec):
+    """stem2 (ADD.py:140-144: ReLU, 3x3 stride-2 conv 64 -> 128, BatchNorm) on the split-bf16 kernel: the forward as
+    conv3b_kernel<ST = 2> (de-interleaved patch rows), the data gradient as four parity-class launches (1 / 2 / 2 / 4 taps, strided
+    scatter).  Output, batch statistics, data gradient and its (dA, dB) sums against fp64 autograd and against the generic kernel."""
+    name, N, H, W, Cs, Cout = shape
+    lb = lib.load()
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    P, ctot = N * OH * OW, sum(Cs)
+    xs, as_, bs = [rnd(N * H * W, c) for c in Cs], [rnd(c) for c in Cs], [0.3 * rnd(c) for c in Cs]
+    w = 0.1 * rnd(Cout, 9 * ctot)
+    dy = rnd(P, Cout)
+    x64 = [x.double().view(N, H, W, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True) for x in xs]
+    a64, b64 = [a.double().requires_grad_(True) for a in as_], [b.double().requires_grad_(True) for b in bs]
+    z = torch.cat([F.relu(a.view(1, -1, 1, 1) * x + b.view(1, -1, 1, 1)) for x, a, b in zip(x64, a64, b64)], 1)
+    y64 = F.conv2d(z, w.double().view(Cout, 3, 3, ctot).permute(0, 3, 1, 2), stride=2, padding=1)
+    y64.backward(dy.double().view(N, OH, OW, Cout).permute(0, 3, 1, 2))
+    ref = y64.detach().permute(0, 2, 3, 1).reshape(P, Cout)
+    gref = [x.grad.permute(0, 2, 3, 1).reshape(N * H * W, -1) for x in x64]
+    dabref = [torch.stack([a.grad, b.grad], 1) for a, b in zip(a64, b64)]
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for tag, fast in (('split', FAST_ALL), ('generic', 0)):
+        lb.addk_set_fast_paths(fast)
+        lib.check(lb.addk_set_conv_precision(PREC[prec]), 'set_conv_precision')
+        lb.addk_set_split_min_channels(0)
+        ar = lib.ConvArgs()
+        for i, Ci in enumerate(Cs):
+            ar.src[i].x, ar.src[i].a, ar.src[i].b = xs[i].data_ptr(), as_[i].data_ptr(), bs[i].data_ptr()
+            ar.src[i].ld, ar.src[i].C, ar.src[i].relu = Ci, Ci, 1
+        ar.nsrc = len(Cs)
+        ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
+        ar.KH = ar.KW = 3
+        ar.stride, ar.pad, ar.dil, ar.Cout = 2, 1, 1, Cout
+        ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = 9 * ctot, ctot, 0, Cout
+        y = torch.full((P, Cout), float('nan'), device=dev)
+        rows = lb.addk_conv_rows(P, Cout)
+        slab = torch.zeros(rows, Cout, 2, device=dev, dtype=torch.float64)
+        ar.w, ar.y, ar.stats, ar.stats_ld = w.data_ptr(), y.data_ptr(), slab.data_ptr(), Cout
+        npk = int(lb.addk_conv_fwd_pack_floats(C.byref(ar)))
+        assert (npk > 0) == (tag == 'split'), 'stride-2 forward: split-kernel coverage (%d floats)' % npk
+        keep = [torch.empty(max(npk, 1), device=dev)]
+        if npk:
+            ar.wpack, ar.wpack_floats = keep[0].data_ptr(), npk
+        lib.check(lb.addk_conv_fwd(C.byref(ar), st), 'conv_fwd')
+        gs, dabs = [], []
+        choff = 0
+        for i, Ci in enumerate(Cs):
+            da = lib.ConvDgradArgs()
+            da.dy, da.lddy, da.Cout = dy.data_ptr(), Cout, Cout
+            da.N, da.H, da.W, da.OH, da.OW, da.KH, da.KW, da.stride, da.pad, da.dil = N, H, W, OH, OW, 3, 3, 2, 1, 1
+            da.w, da.ldw, da.cin_total, da.w_choff = w.data_ptr(), 9 * ctot, ctot, choff
+            da.dst = ar.src[i]
+            g = torch.full((N * H * W, Ci), float('nan'), device=dev)
+            r2 = lb.addk_conv_rows(N * H * W, Ci)
+            dab = torch.zeros(r2, Ci, 2, device=dev, dtype=torch.float64)
+            da.g, da.ldg, da.accumulate, da.dab = g.data_ptr(), Ci, 0, dab.data_ptr()
+            npk = int(lb.addk_conv_dgrad_pack_floats(C.byref(da)))
+            assert (npk > 0) == (tag == 'split' and 32 <= Ci <= 64), 'stride-2 data gradient: split-kernel coverage (%d floats, %d channels)' % (npk, Ci)
+            if npk:
+                keep.append(torch.empty(npk, device=dev))
+                da.wpack, da.wpack_floats = keep[-1].data_ptr(), npk
+            lib.check(lb.addk_conv_dgrad(C.byref(da), st), 'conv_dgrad')
+            gs.append(g); dabs.append(dab)
+            choff += Ci
+        torch.cuda.synchronize()
+        outs[tag] = (y, slab.sum(0), gs, [d.sum(0) for d in dabs])
+    tol = 2e-4 if prec == 'bf16x3' else TOL
+    rs = torch.stack([ref.sum(0), (ref * ref).sum(0)], 1)
+    for tag, (y, s, gs, dabs) in outs.items():
+        errs = {'y': _rel(y, ref), 'stats': _rel(s, rs)}
+        for i in range(len(Cs)):
+            errs['g%d' % i] = _rel(gs[i], gref[i])
+            errs['dab%d' % i] = _rel(dabs[i], dabref[i])
+        bad = ['%s %.2e' % kv for kv in errs.items() if not kv[1] <= (tol if tag == 'split' else TOL)]
+        assert not bad, '%s[%s] %s: %s' % (name, prec, tag, ', '.join(bad))
