@@ -15,6 +15,8 @@
 // Reference call sites: decoder.py:17-27 (3x3 conv+BN+ReLU x2), aspp_train.py:20-41 (dilated 3x3 branches),
 // ADD.py:220-232 (stem1); autograd of nn.Conv2d for the data gradient.
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 #include "common.h"
 
 namespace {
@@ -456,8 +458,16 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
 // the fragment of tap kw is again 32 CONSECUTIVE positions (kw = 0: e = lp, kw = 1: o = lp, kw = 2: e = lp + 1) and the
 // swizzle / bank picture of the stride-1 kernel holds unchanged.  Checkerboard: position idx carries the sign (-1)^(oh+ow0+idx),
 // which is the output pixel's for kw = 0, 1 and its negative for kw = 2 — that tap's weights are packed negated.
+#ifdef ADDK_C3B_DIAG
+// diagnostic build (make CXXFLAGS+=-DADDK_C3B_DIAG, scripts/c3b_clock.sh): every workgroup adds its lifetime in shader-clock ticks (s_memtime)
+// and in 100 MHz reference ticks (s_memrealtime): their ratio is the clock the CUs ran at INSIDE this kernel
+__device__ unsigned long long g_c3b_diag[64][4];        // 64 slots: the workgroups' atomics do not queue on one L2 line
+#endif
 template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1>
 __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const int gx) {      // workgroup bx of gx along x (tiles, slab row)
+#ifdef ADDK_C3B_DIAG
+  const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   static_assert(ST == 1 || (ST == 2 && KS == 3 && !BIGD && MODE == MODE_FWD), "stride 2: 3x3 forward only");
   // KS = 12 / 21 / 22: a 1x2 / 2x1 / 2x2 tap set anchored at its first tap (no centring) — the parity classes of the stride-2 data
   // gradient (c3b_s2_dgrad below); 1, 3, 5: the centred square kernels
@@ -732,6 +742,13 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
         }
     }
   }
+#ifdef ADDK_C3B_DIAG
+  if (t == 0) {
+    unsigned long long* dslot = g_c3b_diag[(bx + 7 * blockIdx.y) & 63];
+    atomicAdd(&dslot[0], __builtin_amdgcn_s_memtime() - diag_c0); atomicAdd(&dslot[1], __builtin_amdgcn_s_memrealtime() - diag_r0);
+    atomicAdd(&dslot[2], 1ull);
+  }
+#endif
   if (p.slab) {
     __syncthreads();
     if (t < BC && n0 + t < p.Cn) {
@@ -851,9 +868,18 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
   if (!packed) { int pb = cdiv(9 * unit, 256); if (pb > 4096) pb = 4096; hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk); }
   C3K4 q;
   int row0 = 0;
+  // share of the workgroups per class: a tile costs (staging + barriers) + taps * MFMA time, not taps alone
+  static int share[4] = {0, 0, 0, 0};
+  if (!share[3]) {
+    const char* e = getenv("ADDK_C3B_S2D_SPLIT");
+    if (!e || sscanf(e, "%d,%d,%d,%d", &share[0], &share[1], &share[2], &share[3]) != 4 || share[0] < 1 || share[1] < 1 || share[2] < 1 || share[3] < 1) {
+      share[0] = 3; share[1] = 4; share[2] = 4; share[3] = 6;      // measured at stem2's shape: 0.481 ms against 0.494 for 1:2:2:4
+    }
+  }
+  const int shsum = share[0] + share[1] + share[2] + share[3];
   for (int cls = 0; cls < 4; ++cls) {
     const int pi = cls >> 1, pj = cls & 1, tc = (1 + pi) * (1 + pj), pre = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
-    const int rc = cls == 3 ? rows - row0 : (rows * tc) / 9;
+    const int rc = cls == 3 ? rows - row0 : (rows * share[cls]) / shsum;
     C3K& c = q.c[cls];
     c = k;
     c.H = (k.OHo - pi + 1) / 2; c.W = (k.OWo - pj + 1) / 2;
@@ -1040,6 +1066,16 @@ static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK
   return c3_launch(k, pk, MODE_DGRAD, rows, (hipStream_t)stream, a->wpack_ready != 0, desc_out);
 }
 
+#ifdef ADDK_C3B_DIAG
+// (shader ticks, reference ticks, workgroups, 0) summed since the last call; resets the counters
+extern "C" int addk_c3b_diag(unsigned long long* out4) {
+  unsigned long long h[64][4];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c3b_diag), sizeof h) != hipSuccess) return ADDK_ERR_INVALID;
+  for (int k = 0; k < 4; ++k) { out4[k] = 0; for (int i = 0; i < 64; ++i) out4[k] += h[i][k]; }
+  memset(h, 0, sizeof h);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_c3b_diag), h, sizeof h) == hipSuccess ? ADDK_OK : ADDK_ERR_INVALID;
+}
+#endif
 extern "C" int addk_set_split_min_channels(int c) { g_c3b_minc = c < 0 ? 0 : c; return ADDK_OK; }
 int addk_c3_try_fwd(const addk_conv_args* a, int rows, void* stream) { return c3_fwd(a, rows, stream, nullptr); }
 int addk_c3_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) { return c3_dgrad(a, rows, stream, nullptr); }

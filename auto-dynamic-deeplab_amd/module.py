@@ -81,9 +81,9 @@ class Plan:
         self.nbt = NbtCounter(g.nbt)
         # inference plans (no autograd) are replayed as one hipGraph launch from the 3rd call on: at ~900 launches per
         # forward the Python/ctypes launch loop (~15 us per command) costs more than the kernels themselves
-        self.graph = None
+        self.graph = self.bgraph = None
         self.calls = 0
-        self.static_in = None
+        self.static_in = self.static_gy = None
 
     def check_params(self):
         for p, ptr in zip(self.params, self.param_ptrs):
@@ -91,9 +91,24 @@ class Plan:
                 return False
         return True
 
+    _COLLECTIVES = ('allreduce', 'allreduce_packed', 'grad_allreduce')
+
+    def _graph_allowed(self, inputs):
+        """Inference plans always (ADDK_GRAPH_INFER=0 disables); training / autograd plans — the reference's own call pattern
+        model(x); loss.backward() — as TWO hipGraphs, forward list and backward list (ADDK_GRAPH_MODULE=0 disables), unless the
+        lists hold RCCL calls (SyncBN at world > 1: those steps belong to train.TrainStep, which decides capture collectively)."""
+        if not inputs[0].is_cuda:
+            return False
+        if not (self.g.want_grad or self.g.training):
+            return os.environ.get('ADDK_GRAPH_INFER', '1') == '1'
+        if os.environ.get('ADDK_GRAPH_MODULE', '1') != '1':
+            return False
+        if getattr(self, '_has_coll', None) is None:
+            self._has_coll = any(c.name in self._COLLECTIVES for c in list(self.g.fwd) + list(self.g.bwd))
+        return not self._has_coll
+
     def _forward_graphed(self, inputs):
-        import os
-        if os.environ.get('ADDK_GRAPH_INFER', '1') != '1' or self.g.want_grad or self.g.training or not inputs[0].is_cuda:
+        if not self._graph_allowed(inputs):
             return False
         self.calls += 1
         if self.calls < 3:
@@ -105,11 +120,40 @@ class Plan:
                 r.bind(xs)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self.g.run_parallel(self.g.fwd, None)
         for xs, x in zip(self.static_in, inputs):
             xs.copy_(x)
         self.graph.replay()
+        return True
+
+    def _backward_graphed(self, gouts):
+        """Replay of the backward list as one hipGraph: the incoming gradients are copied into plan-owned buffers (fixed addresses).
+        Captured on the first backward that follows a graphed forward (the lists have run eagerly at least twice by then)."""
+        if self.graph is None or not self.g.want_grad:
+            return False
+        if self.bgraph is None:
+            self.static_gy = []
+            for kind, o in self.outs:
+                if kind == 'in':
+                    self.static_gy.append(None)
+                    continue
+                buf = torch.zeros_like(o.y, memory_format=torch.contiguous_format)
+                o.set_grad(buf)
+                self.static_gy.append(buf)
+        for (kind, o), gy, buf in zip(self.outs, gouts, self.static_gy):
+            if buf is None:
+                continue
+            if gy is None:
+                buf.zero_()
+            else:
+                buf.copy_(gy)
+        if self.bgraph is None:
+            torch.cuda.synchronize()
+            self.bgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bgraph, capture_error_mode='thread_local'):
+                self.g.run_parallel(self.g.bwd, None)
+        self.bgraph.replay()
         return True
 
     def forward(self, inputs):
@@ -129,15 +173,15 @@ class Plan:
         return outs
 
     def backward(self, gouts):
-        k = 0
-        hold = []
-        for (kind, o), gy in zip(self.outs, gouts):
-            if kind == 'in':
-                continue
-            if gy is None:
-                gy = torch.zeros_like(o.y)
-            hold.append(o.set_grad(gy))
-        self.g.run_parallel(self.g.bwd, None)
+        if not self._backward_graphed(gouts):
+            hold = []
+            for (kind, o), gy in zip(self.outs, gouts):
+                if kind == 'in':
+                    continue
+                if gy is None:
+                    gy = torch.zeros_like(o.y)
+                hold.append(o.set_grad(gy))
+            self.g.run_parallel(self.g.bwd, None)
         gin = [r.grad for r in self.inrefs]
         # passthrough outputs route their gradient straight back to the input
         for (kind, o), gy in zip(self.outs, gouts):

@@ -38,6 +38,7 @@ NETWORK_ARCH = [1, 2, 2, 2, 3, 2, 2, 1, 1, 1, 1, 2]      # train.py:75-79 (searc
 C_INDEX = [5]
 PEAK_MFMA_F32_TFLOPS = 157.3                              # MI355X_MICROARCH.md: fp32 matrix peak (spec)
 PEAK_MFMA_BF16_TFLOPS = 2500.0                            # dense bf16 peak (spec)
+SUSTAINED_MFMA_BF16_TFLOPS = 1950.0                       # measured on this pool: register-resident 32x32x16 bf16 loop, toggling operands (profiles/r03_mfma_clock_probe.txt)
 PEAK_HBM_GBS = 8000.0
 WEIGHT_SEED = 1001
 # SURVEY §8(d), per image, fp32, 1024x2048: inference algorithmic bytes / training-forward extra / forward conv FLOPs per segment
@@ -493,6 +494,13 @@ def main():
             'kernel': kern, 'launch_ms': tk * 1e3,
             'launch_shape_NHWCinCoutKSD': list(top['shape']), 'algorithmic_gflop_per_launch': top['flops'] / 1e9,
             'algorithmic_bytes_per_launch': top['bytes']}
+    if terms > 1:
+        # what this part SUSTAINS on a register-resident v_mfma_f32_32x32x16_bf16 loop (no memory traffic, every SIMD busy): the shader
+        # clock drops from 2.4 to ~1.95-2.05 GHz under that load (s_memtime / s_memrealtime, scripts/mfma_clock_probe.hip) — reported
+        # beside `frac`, which stays priced against the guide's nominal peak
+        roof['measured_sustained_matrix_TFLOPs'] = SUSTAINED_MFMA_BF16_TFLOPS
+        roof['frac_of_measured_sustained'] = ach * terms / SUSTAINED_MFMA_BF16_TFLOPS
+        roof['sustained_source'] = 'profiles/r03_mfma_clock_probe.txt (1.90-2.07 PFLOP/s at 1.95-2.05 GHz; operands toggling every iteration: 1.93)'
     step_tflops = 3 * fwd_flops / (dt / a.steps) / 1e12
     out = contract_line(dt, ts.graph is not None and ts.use_graph)
     out.update({'ms_per_step_by_mode': modes,

@@ -1,6 +1,7 @@
 // Stand-alone timing of addk_conv_fwd / addk_conv_dgrad / wgrad on the heavy shapes of config 2 (through the C ABI).
 // hipcc -O2 --offload-arch=gfx950 -Iinclude scripts/conv_bench.cpp -Lauto-dynamic-deeplab_amd -laddk -Wl,-rpath,$PWD/auto-dynamic-deeplab_amd -o /tmp/conv_bench
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -116,6 +117,13 @@ int main(int argc, char** argv) {
       }
       double mb = 4.0 * (P * s.Cin + PO * s.Cout) * 1e-6;
       printf("%-34s %-5s %8.1f us  %6.1f TFLOP/s (%.1f GF)  %6.0f GB/s of min traffic\n", s.name, mode == 0 ? "fwd" : mode == 1 ? "dgrad" : "wgrad", ms * 1e3, gf / ms, gf, mb / ms);
+      // diagnostic library (built with -DADDK_C3B_DIAG): the clock inside the split kernel's workgroups
+      typedef int (*diag_fn)(unsigned long long*);
+      static diag_fn diag = (diag_fn)dlsym(RTLD_DEFAULT, "addk_c3b_diag");
+      unsigned long long dv[4];
+      if (diag && mode < 2 && diag(dv) == 0 && dv[1])
+        printf("      in-kernel clock: %.0f MHz (s_memtime / s_memrealtime over %llu workgroups, mean workgroup life %.1f us)\n",
+               100.0 * (double)dv[0] / (double)dv[1], dv[2], (double)dv[1] / (double)dv[2] / 100.0);
     }
     hipFree(x); hipFree(a); hipFree(b); hipFree(w); hipFree(y); hipFree(g); hipFree(slab); hipFree(dab); hipFree(wg.dw); hipFree(wg.ws);
   }

@@ -186,6 +186,35 @@ def test_train_step_hipgraph_equals_eager(dev):
     assert losses[True][-1] < losses[True][0]                                # and the loss goes down
 
 
+def test_drop_in_step_replays_two_hipgraphs_and_equals_eager(dev, monkeypatch):
+    """The reference's own call pattern (train.py:227-240: outputs = model(image); loss.backward(); optimizer.step()) on the addk
+    modules: from the third call on the forward list and the backward list of the plan are replayed as two hipGraphs (module.Plan).
+    Losses of five SGD steps and the final parameters are bitwise those of the eager launch loop (ADDK_GRAPH_MODULE=0); a batch
+    whose data changes between steps goes through the plan-owned input / gradient buffers correctly."""
+    from addk.loss import CrossEntropyLoss
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('ADDK_GRAPH_MODULE', mode)
+        ma, _ = _models(dev)
+        ma.train()
+        crit = CrossEntropyLoss(ignore_index=255)
+        opt = torch.optim.SGD(ma.parameters(), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True)
+        ls = []
+        for i in range(5):
+            x, t = _batch(2, (33, 65), seed=5 + (i % 2))          # two alternating batches: replay must pick up new input data
+            ys = ma(x.to(dev))
+            loss = sum(crit(y, t.to(dev)) for y in ys) / len(ys)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            ls.append(loss.item())
+        plans = [p for m in ma.modules() for p in getattr(m, '__dict__', {}).get('_addk_plans', {}).values()]
+        assert plans and all((p.graph is not None and p.bgraph is not None) == (mode == '1') for p in plans if p.g.want_grad)
+        res[mode] = (ls, torch.cat([p.detach().reshape(-1) for p in ma.parameters()]).cpu())
+    assert res['1'][0] == res['0'][0], (res['1'][0], res['0'][0])
+    assert torch.equal(res['1'][1], res['0'][1])
+
+
 @pytest.mark.parametrize('size', [(33, 65), (256, 512)], ids=['33x65', '256x512'])
 def test_schedule_and_batching_do_not_change_a_bit(dev, size, monkeypatch):
     """The same step as (a) the plain sequential launch list on one stream and (b) the level-ordered list with table-driven
