@@ -324,9 +324,11 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
     LDS-tiled kernels inside the real network.  Even there the network amplifies any 1e-7 perturbation of the stems to
     1e-4..1e-3 in the gradients (the fp32 oracle sits 2e-4 median .. 3e-3 from fp64), and how a given arithmetic fares is
     a matter of the input draw (profiles/r02_split_threshold_study.txt): the large case therefore runs TWO draws and holds the
-    maximum / median error to 5x / 4x the fp32 oracle's own distance to fp64 per draw and to 3x / 2.5x in the geometric mean
-    (measured 2.96 / 2.69 and 1.37 / 1.08; the oracle's own figures move by ~10 % from run to run with the CPU's thread
-    scheduling, ours are bit-reproducible)."""
+    maximum / median error to 3x / 2.5x the fp32 oracle's own distance to fp64 per draw, to 2x / 1.75x in the geometric mean and every
+    gradient elementwise to 1e-2 — round 1's bounds again, which round 2's kernels needed loosened to 5x / 4x / 2e-2:
+    with blocked accumulation in the <= 64-channel split kernel and the generic kernel, and stem2 on the split kernel, the default
+    bf16x6 mode measures 1.36 / 1.13 and 0.65 / 0.83 (round 2: 2.8 / 2.2 and 0.96 / 0.72).  The oracle's own figures move by ~10 % from
+    run to run with the CPU's thread scheduling, ours are bit-reproducible."""
     big = hw[0] >= 512
     crit = nn.CrossEntropyLoss(ignore_index=255)
     ratios = []
@@ -351,7 +353,7 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
             if p.dim() == 4 and p.grad is not None:
                 assert pa[k].grad is not None, k
                 if big:
-                    ours.append(_chk('frozen_bn%d.%d/g:%s' % (hw[0], draw, k), pa[k].grad.cpu().double(), p64[k].grad, 2e-2))
+                    ours.append(_chk('frozen_bn%d.%d/g:%s' % (hw[0], draw, k), pa[k].grad.cpu().double(), p64[k].grad, 1e-2))
                     theirs.append(rel_err(p.grad.double(), p64[k].grad))
                     grp = '.'.join(k.split('.')[:2]) if k.startswith('cells.') else k.split('.')[0]
                     groups.setdefault(grp, []).append((ours[-1], theirs[-1]))
@@ -367,12 +369,12 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
                 REPORT.append('frozen_bn512 draw %d per-layer %-22s n=%3d  addk %.2e  fp32 oracle %.2e  ratio %.2f' % (
                     draw, grp, len(v), med([a for a, _ in v]), med([b for _, b in v]), med([a for a, _ in v]) / max(med([b for _, b in v]), 1e-30)))
             ratios.append((max(ours) / max(theirs), med(ours) / med(theirs)))
-            assert ratios[-1][0] <= 5 and ratios[-1][1] <= 4, ratios
+            assert ratios[-1][0] <= 3 and ratios[-1][1] <= 2.5, ratios
         del ma, mo
         torch.cuda.empty_cache()
     if big:
         gm = lambda v: float(np.exp(np.mean(np.log(v))))
-        assert gm([r[0] for r in ratios]) <= 3 and gm([r[1] for r in ratios]) <= 2.5, ratios
+        assert gm([r[0] for r in ratios]) <= 2 and gm([r[1] for r in ratios]) <= 1.75, ratios
 
 
 @pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])
