@@ -551,6 +551,10 @@ extern "C" int addk_selftest_mfma(float* out256, void* stream) {
 extern "C" int addk_conv_rows(int64_t P, int32_t Cout) {
   (void)Cout;
   int nt = cdiv(P, 64);           // one slab row per workgroup; every conv kernel launches exactly this many in x
+  // [r3] small maps (the 63x127 and 32x64 levels: 251 / 64 rows) left most of the 256 CUs with one workgroup or none: one row per 32 pixels
+  // up to 512 rows (ADDK_CONV_ROWS_SMALL=0 restores one per 64)
+  static int small = -1; if (small < 0) { const char* e = getenv("ADDK_CONV_ROWS_SMALL"); small = (e && e[0] == '0') ? 0 : 1; }
+  if (small && nt < 512) { nt = cdiv(P, 32); if (nt > 512) nt = 512; }
   return nt < 1024 ? nt : 1024;
 }
 

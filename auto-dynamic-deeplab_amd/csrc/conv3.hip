@@ -650,9 +650,10 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
           const int nj = (j + 1) % PT, ntap = tap + (j + 1) / PT;
-          if (ntap < TAPS) read_x(ntap, nj, xr[(j + 1) & 1]);
+          const int cur = (tap * PT + j) & 1;                       // the two fragment buffers alternate over the (tap, tile) sequence (PT may be odd: 32-pixel tiles)
+          if (ntap < TAPS) read_x(ntap, nj, xr[cur ^ 1]);
           __builtin_amdgcn_sched_barrier(0);
-          mma(acc[j], wr[tap % 3], xr[j & 1]);
+          mma(acc[j], wr[tap % 3], xr[cur]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -917,7 +918,12 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const long blocks128 = (long)k.N * k.H * cdiv(k.W, C3_BP) * cdiv(k.Cn, 32 * wc);
   const bool half = k.st == 1 && ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && !(wc == 3 && ks == 1) && blocks128 < 384 && c3b_half_enabled();      // (rows of <= 64 pixels land here too)
   static int s2bpx = -1; if (s2bpx < 0) { const char* e = getenv("ADDK_C3B_S2_BPX"); s2bpx = e ? atoi(e) : 64; }
-  const int bpx = k.st == 2 ? (s2bpx == 128 ? 128 : 64) : half ? 64 : C3_BP;
+  // quarter-width (32-pixel) tiles where even 64-pixel tiles leave the chip short of workgroups: the cells' dilated convs on the 32x64 maps ran as
+  // 128 workgroups of 3 waves — half the CUs idle, one wave per SIMD on the others, every LDS / weight round trip exposed
+  static int quarter_on = -1; if (quarter_on < 0) { const char* e = getenv("ADDK_C3B_QUARTER"); quarter_on = (e && e[0] == '0') ? 0 : 1; }
+  const long blocks64 = (long)k.N * k.H * cdiv(k.W, 64) * cdiv(k.Cn, 32 * wc);
+  const bool quarter = half && quarter_on && wc == 3 && !bigd && (ks == 3 || ks == 5) && blocks64 < 192;      // measured: 160 ch @ 32x64 85 -> 63 us (5x5), 45 -> 34 (3x3); 80 ch @ 63x127 (252 blocks) is slower quartered (53 -> 66)
+  const int bpx = k.st == 2 ? (s2bpx == 128 ? 128 : 64) : quarter ? 32 : half ? 64 : C3_BP;
   k.spr = cdiv(k.W, bpx);
   k.ntiles = k.N * k.H * k.spr;
   k.red32 = 1;
@@ -954,6 +960,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   ADDK_C3B(3, 3, true) ADDK_C3B(4, 3, true) ADDK_C3B(5, 3, true) ADDK_C3B(2, 3, true)
   ADDK_C3B(2, 5, false) ADDK_C3B(3, 5, false) ADDK_C3B(4, 5, false) ADDK_C3B(5, 5, false)
   ADDK_C3BX(3, 3, false, 64) ADDK_C3BX(3, 5, false, 64) ADDK_C3BX(4, 3, false, 64) ADDK_C3BX(4, 3, true, 64)
+  ADDK_C3BX(3, 3, false, 32) ADDK_C3BX(3, 5, false, 32)
   ADDK_C3B(4, 1, false) ADDK_C3B(3, 1, false) ADDK_C3B(5, 1, false) ADDK_C3BX(4, 1, false, 64) ADDK_C3B(2, 1, false)
   }
 #undef ADDK_C3B

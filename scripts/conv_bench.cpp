@@ -58,6 +58,12 @@ int main(int argc, char** argv) {
     {"cell 1x1 160->160 @32x64", 2, 32, 64, 160, 160, 1, 1},
     {"cell 1x1 200->40 @125x253", 2, 125, 253, 200, 40, 1, 1},
     {"cell 5x5 40->40 @125x253", 2, 125, 253, 40, 40, 5, 1},
+    {"dil 5x5 d2 80->80 @63x127", 2, 63, 127, 80, 80, 5, 2},
+    {"dil 3x3 d2 80->80 @63x127", 2, 63, 127, 80, 80, 3, 2},
+    {"dil 5x5 d2 80->80 @64x128", 2, 64, 128, 80, 80, 5, 2},
+    {"dil 5x5 d2 160->160 @32x64", 2, 32, 64, 160, 160, 5, 2},
+    {"dil 3x3 d2 160->160 @32x64", 2, 32, 64, 160, 160, 3, 2},
+    {"dil 5x5 d2 40->40 @125x253", 2, 125, 253, 40, 40, 5, 2},
     {"glue 1x1 400->80 @63x127", 2, 63, 127, 400, 80, 1, 1},
     {"glue 1x1 800->160 @32x64", 2, 32, 64, 800, 160, 1, 1},
     {"stem2 3x3s2 64->128 @512x1024", 2, 512, 1024, 64, 128, 3, 1, 2},
