@@ -32,10 +32,14 @@ class ConvDgradArgs(C.Structure):
                 ('dab', vp), ('wpack', vp), ('wpack_floats', i64), ('wpack_ready', i32), ('_pad2', i32)]
 
 
+class BnFold(C.Structure):
+    _fields_ = [('y', vp), ('ldy', i32), ('_pad', i32), ('c1', vp), ('c2', vp), ('mean', vp)]
+
+
 class ConvWgradArgs(C.Structure):
     _fields_ = [('dy', vp), ('lddy', i32), ('Cout', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('src', Src), ('dw', vp),
-                ('ldw', i32), ('cin_total', i32), ('w_choff', i32), ('accumulate', i32), ('ws', vp), ('ws_floats', i64)]
+                ('ldw', i32), ('cin_total', i32), ('w_choff', i32), ('accumulate', i32), ('ws', vp), ('ws_floats', i64), ('fold', BnFold)]
 
 
 class BnFinalizeArgs(C.Structure):
@@ -52,7 +56,7 @@ class SepArgs(C.Structure):
 
 class SepBwdArgs(C.Structure):
     _fields_ = [('dy', vp), ('lddy', i32), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('src', Src), ('Cout', i32), ('ldw', i32),
-                ('dw_w', vp), ('pw_w', vp), ('g', vp), ('ldg', i32), ('accumulate', i32), ('dab', vp), ('ws', vp)]
+                ('dw_w', vp), ('pw_w', vp), ('g', vp), ('ldg', i32), ('accumulate', i32), ('dab', vp), ('ws', vp), ('fold', BnFold)]
 
 
 class CeUpsampleArgs(C.Structure):

@@ -27,6 +27,7 @@ struct SepbK {
   float* g; int ldg; int accumulate;
   double* dab; float* ws;
   int tiles_x, tiles_y, gx;
+  addk_bn_fold fold;             // fold.y: BatchNorm backward applied to dy on the fly (addk.h)
 };
 
 __device__ __forceinline__ float4 fma4b(float4 w, float4 v, float4 a) {
@@ -94,18 +95,33 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   __syncthreads();
 
   // ---- stage 1: dt = W^T dy on the haloed patch, 16 pixels at a time ----
+  // folded BatchNorm backward: dy = G + (c1 + c2 (y - mean)), addk_bn_bwd_apply's own expression, on this lane's channel quads
+  const bool fold = p.fold.y != nullptr;
+  float4 f1[KG], f2[KG], fm[KG];
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    f1[g] = zero4(); f2[g] = zero4(); fm[g] = zero4();
+    const int k = 16 * g + 4 * kq;
+    if (fold && k < C) { f1[g] = ld4(p.fold.c1 + k); f2[g] = ld4(p.fold.c2 + k); if (p.fold.mean) fm[g] = ld4(p.fold.mean + k); }
+  }
   for (int j = wave; j < G::NT16; j += 4) {
     const int pix = 16 * j + li;
     const int pr = pix / PW, pc = pix - pr * PW;
     const int oh = ih0 - HK + pr, ow = iw0 - HK + pc;
     const bool ok = pix < NPIX && (unsigned)oh < (unsigned)p.H && (unsigned)ow < (unsigned)p.W;
     const float* dp = p.dy + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.lddy : 0);
+    const float* yp = fold ? p.fold.y + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.fold.ldy : 0) : p.dy;
     float4 d[KG];
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const int k = 16 * g + 4 * kq;
       const bool okk = ok && k < C;
       float4 v = ld4(dp + (okk ? k : 0));
+      if (fold) {
+        const float4 y = ld4(yp + (okk ? k : 0));
+        v.x += fmaf(f2[g].x, y.x - fm[g].x, f1[g].x); v.y += fmaf(f2[g].y, y.y - fm[g].y, f1[g].y);
+        v.z += fmaf(f2[g].z, y.z - fm[g].z, f1[g].z); v.w += fmaf(f2[g].w, y.w - fm[g].w, f1[g].w);
+      }
       v.x = okk ? v.x : 0.f; v.y = okk ? v.y : 0.f; v.z = okk ? v.z : 0.f; v.w = okk ? v.w : 0.f;
       d[g] = v;
     }
@@ -258,6 +274,11 @@ bool sepb_fill(const addk_sep_bwd_args* a, SepbK& k, SepbCfg& c) {
   k.dy = a->dy; k.lddy = a->lddy; k.src = s; k.N = a->N; k.H = a->H; k.W = a->W; k.C = s.C;
   k.dww = a->dw_w; k.pww = a->pw_w; k.ldw = a->ldw; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate;
   k.dab = (double*)a->dab; k.ws = a->ws;
+  if (a->fold.y) {                 // BatchNorm backward applied on the fly: 16-byte loads of y and of the coefficient vectors
+    const addk_bn_fold& f = a->fold;
+    if (!f.c1 || !f.c2 || !aligned16(f.y) || f.ldy % 4 || f.ldy < a->Cout || !aligned16(f.c1) || !aligned16(f.c2) || (f.mean && !aligned16(f.mean))) return false;
+    k.fold = f;
+  }
   const long blocks2 = (long)a->N * cdiv(a->H, 8) * cdiv(a->W, 16);
   // 80-channel tiles need 100-127 KB of LDS: one workgroup per CU.  That is fine while the launch has at most two rounds of them
   // (config 2: 256 workgroups at 64x128) and LOSES to the separate depthwise / pointwise launches beyond (F = 40, 80 channels at

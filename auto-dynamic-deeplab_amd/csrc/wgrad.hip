@@ -21,6 +21,7 @@ struct WgK {
   int vecY, vecZ;
   // reduction target (used by the batched reduce)
   float* dw; int ldw, cin_total, w_choff, accumulate;
+  addk_bn_fold fold;       // fold.y: dy = G + (c1 + c2 (y - mean)) on the fly (register-streaming kernel only)
 };
 
 // Descriptor of this block's convolution, BY VALUE (scalar registers, loaded once): either the kernel argument or the
@@ -30,6 +31,7 @@ __device__ __forceinline__ WgK wg_desc(const WgK& pv, const WgK* __restrict__ op
   if (!BATCH) return pv;
   WgK k = ops[op];
   k.dy = gptr(k.dy); k.src.x = gptr(k.src.x); k.src.a = gptr(k.src.a); k.src.b = gptr(k.src.b); k.ws = gptr(k.ws); k.dw = gptr(k.dw);
+  k.fold.y = gptr(k.fold.y); k.fold.c1 = gptr(k.fold.c1); k.fold.c2 = gptr(k.fold.c2); k.fold.mean = gptr(k.fold.mean);
   return k;
 }
 
@@ -1081,6 +1083,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
   const float* ybase = p.dy + co0;
   const float* zbase = p.src.x + c0;
   const bool same = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;      // 1x1: the activation pixel is the dy pixel
+  // folded BatchNorm backward on the dy operand: dy = G + (c1 + c2 (y - mean)), addk_bn_bwd_apply's own expression
+  const bool fold = p.fold.y != nullptr;
+  const float* fbase = fold ? p.fold.y + co0 : p.dy;
+  RsFrag<LA> f1, f2, fm;
+#pragma unroll
+  for (int e = 0; e < LA; ++e) { f1.v[e] = 0.f; f2.v[e] = 0.f; fm.v[e] = 0.f; }
+  if (fold) {
+    f1 = rs_load<LA>(p.fold.c1 + co0, li, y4, y2, y1); f2 = rs_load<LA>(p.fold.c2 + co0, li, y4, y2, y1);
+    if (p.fold.mean) fm = rs_load<LA>(p.fold.mean + co0, li, y4, y2, y1);
+  }
 
   f32x4 acc[LA][LB];
 #pragma unroll
@@ -1096,6 +1108,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
       const int pp = pbeg + 4 * (s0 + u) + kq;
       const bool pv_ = (s0 + u) < s_end && pp < pend;
       dy4[u] = rs_load<LA>(ybase + (pv_ ? (long)pp * p.lddy : 0), li, pv_ && y4, pv_ && y2, pv_ && y1);
+      if (fold) {
+        const RsFrag<LA> yv = rs_load<LA>(fbase + (pv_ ? (long)pp * p.fold.ldy : 0), li, pv_ && y4, pv_ && y2, pv_ && y1);
+#pragma unroll
+        for (int e = 0; e < LA; ++e) {
+          const bool oke = pv_ && (LA == 4 ? y4 : (e < 2 ? y2 : y1));
+          const float v = dy4[u].v[e] + fmaf(f2.v[e], yv.v[e] - fm.v[e], f1.v[e]);
+          dy4[u].v[e] = oke ? v : 0.f;
+        }
+      }
       long zoff = 0; bool okz = pv_;
       if (same) zoff = (long)pp * p.src.ld;
       else if (okz) {
@@ -1402,6 +1423,14 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
     k.splits = cdiv(k.P, k.chunkP);
   }
   k.dw = a->dw; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.accumulate = a->accumulate;
+  k.fold = addk_bn_fold{nullptr, 0, 0, nullptr, nullptr, nullptr};
+  if (a->fold.y) {
+    const bool rs = !h3_ok(a) && !hk_ok(a) && rs_ok(a);
+    ADDK_REQUIRE(rs, "conv_wgrad: a folded BatchNorm backward needs the register-streaming kernel (kind 6) for this shape");
+    ADDK_REQUIRE(a->fold.c1 && a->fold.c2 && a->fold.ldy >= a->Cout && a->fold.ldy % 4 == 0 && aligned16(a->fold.y) && aligned16(a->fold.c1) &&
+                 aligned16(a->fold.c2) && (!a->fold.mean || aligned16(a->fold.mean)), "conv_wgrad: bad fold operands");
+    k.fold = a->fold;
+  }
   return 0;
 }
 

@@ -906,6 +906,11 @@ class Graph:
                 else:
                     ba.c1, ba.c2 = c1.ptr, c2.ptr
                     self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2]).payload = ba
+                if id(raw) in self.__dict__.get('_fold_ok', ()):
+                    # the two consumers of this gradient (fused SepConv-half backward, its pointwise weight gradient) apply
+                    # dy = G + c1 + c2 (x - mean) in their own loaders (addk_bn_fold): no bn_bwd_apply launch, G stays as it is
+                    self.__dict__.setdefault('_fold', {})[id(raw)] = (c1, c2, mu)
+                    return
                 # dy_raw = G + c1 + c2*x, in place on the accumulated gradient
                 cap = self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, mu.ptr if mu else None,
                                 c1.ptr, c2.ptr, raw.P, Cc, g.ptr, g.ld, rd=[g, raw, c1, c2, mu], wr=[g])
@@ -1006,10 +1011,25 @@ class Graph:
             ba.src = self.src(src, True)
             ba.Cout, ba.ldw = Cout, Cc
             ba.dw_w, ba.pw_w = self.param(dw_mod.weight), self.param(pw_mod.weight)
+        def fill_w(wa, dy_ptr, dy_ld, t_src, gp, acc):
+            wa.dy, wa.lddy, wa.Cout = dy_ptr, dy_ld, Cout
+            wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, H, W, 1, 1, 1, 0, 1
+            wa.src = t_src
+            wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = gp, Cc, Cc, 0, acc
         if probe:
             ba = L.SepBwdArgs()
             fill(ba, raw.ptr, raw.ld)
-            return int(lib.addk_sep_bwd_rows(C.byref(ba))) > 0
+            ok = int(lib.addk_sep_bwd_rows(C.byref(ba))) > 0
+            if ok and os.environ.get('ADDK_FOLD_BN_APPLY', '0') == '1':      # measured SLOWER (step 38.3 vs 37.4 ms): opt-in, see DESIGN §10
+                # may the BatchNorm backward behind this half be folded into its two consumers (sepb's dy loader and the pointwise weight
+                # gradient's)?  Only when that weight gradient runs on the register-streaming kernel (kind 6), the one that honours `fold`
+                wa = L.ConvWgradArgs()
+                ts = L.Src(); ts.x, ts.ld, ts.C = raw.ptr, Cc, Cc
+                fill_w(wa, raw.ptr, raw.ld, ts, raw.ptr, 0)
+                cfg = (C.c_int32 * 4)()
+                if lib.addk_conv_wgrad_config(C.byref(wa), cfg) == 0 and cfg[0] == 6:
+                    self.__dict__.setdefault('_fold_ok', set()).add(id(raw))
+            return ok
 
         def emit_bwd():
             if not self.grad_ready(raw):
@@ -1017,16 +1037,23 @@ class Graph:
             dy = self.grad(raw)
             # pointwise weight gradient: dW[co][ci] = sum_p dy[p][co] t[p][ci]
             wa = L.ConvWgradArgs()
-            wa.dy, wa.lddy, wa.Cout = dy.ptr, dy.ld, Cout
-            wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, H, W, 1, 1, 1, 0, 1
-            wa.src = self.src(t)
             gp, acc = self.param_grad(pw_mod.weight, (0, Cc))
-            wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = gp, Cc, Cc, 0, acc
+            fill_w(wa, dy.ptr, dy.ld, self.src(t), gp, acc)
             wa.ws_floats = lib.addk_conv_wgrad_ws(N * H * W, Cout, Cc, 1)
-            self._wgrads.append((wa, [dy] + self.lz(t), self.pgrad[pw_mod.weight], (id(pw_mod.weight), 0, Cc)))
+            # BatchNorm backward folded into both consumers (Graph.bn left dy un-applied and recorded its coefficient vectors)
+            fold = self.__dict__.get('_fold', {}).get(id(raw))
+            frd = []
+            if fold is not None:
+                c1, c2, mu = fold
+                frd = [raw, c1, c2] + ([mu] if mu is not None else [])
+            self._wgrads.append((wa, [dy] + self.lz(t) + frd, self.pgrad[pw_mod.weight], (id(pw_mod.weight), 0, Cc)))
             # fused data gradient + depthwise backward
             ba = L.SepBwdArgs()
             fill(ba, dy.ptr, dy.ld)
+            if fold is not None:
+                for a_ in (wa, ba):
+                    a_.fold.y, a_.fold.ldy, a_.fold.c1, a_.fold.c2 = raw.ptr, raw.ld, c1.ptr, c2.ptr
+                    a_.fold.mean = mu.ptr if mu is not None else None
             rows = int(lib.addk_sep_bwd_rows(C.byref(ba)))
             gs = slab = None
             if src.needs_grad:
@@ -1043,7 +1070,7 @@ class Graph:
             it.ws, it.dw, it.rows, it.n, it.accumulate = ws.ptr, gpw, rows, Cc * k * k, accw
             self._dwreds.append((it, ws, self.pgrad[dw_mod.weight]))
             self.keep.append(ba)
-            cb = self._add(self.bwd, 'sep_bwd', lib.addk_sep_bwd, C.byref(ba), rd=[dy, dw_mod.weight, pw_mod.weight] + self.lz(src),
+            cb = self._add(self.bwd, 'sep_bwd', lib.addk_sep_bwd, C.byref(ba), rd=[dy, dw_mod.weight, pw_mod.weight] + self.lz(src) + frd,
                            wr=[gs, slab, ws])
             bk = int(lib.addk_sep_bwd_batch_key(C.byref(ba)))
             if bk >= 0:

@@ -173,6 +173,13 @@ int addk_conv_pack_batch(const void* dev_descs, int32_t n, void* stream);
 /* Weight gradient for ONE source: dw[co][tap][w_choff+ci] = sum_p dy[p,co] * z[p@tap,ci],
  * z = relu?(a*x+b).  Deterministic split-P: partial tiles go to `ws`, then are reduced into
  * dw (accumulate: the shared ASPP/decoder head is used once per exit — SURVEY Q4). */
+/* BatchNorm backward FOLDED into a consumer of dy: the consumer computes, element by element and in addk_bn_bwd_apply's own order,
+ *   dy_used = dy + (c1 + c2 * (y - mean))        y: the BatchNorm's raw input at the same pixel / channel; mean NULL = 0
+ * instead of reading a gradient that addk_bn_bwd_apply rewrote in place (one launch and one read-modify-write of the tensor per
+ * BatchNorm saved; reference batchnorm.py:51-53).  y == NULL: dy is used as it is.  Honoured by addk_sep_bwd and by the
+ * register-streaming weight gradient (addk_conv_wgrad_config: kind 6); every other kernel refuses a non-NULL y. */
+typedef struct addk_bn_fold { const float* y; int32_t ldy; int32_t _pad; const float* c1; const float* c2; const float* mean; } addk_bn_fold;
+
 typedef struct addk_conv_wgrad_args {
   const float* dy; int32_t lddy; int32_t Cout;
   int32_t N, H, W, OH, OW, KH, KW, stride, pad, dil;
@@ -180,6 +187,7 @@ typedef struct addk_conv_wgrad_args {
   float* dw; int32_t ldw, cin_total, w_choff;
   int32_t accumulate;
   float* ws; int64_t ws_floats;  /* workspace, >= addk_conv_wgrad_ws() floats */
+  addk_bn_fold fold;             /* dy = gradient wrt a BatchNorm's OUTPUT, the BatchNorm backward applied on the fly (kind 6 only) */
 } addk_conv_wgrad_args;
 int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream);
 int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_t taps);
@@ -235,7 +243,7 @@ int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 
 /* Fused BACKWARD of a SepConv half (csrc/sepb.hip): pointwise data gradient (dt = W^T dy, matrix cores) and depthwise backward
  * (dx, depthwise weight-gradient partials, (dA, dB) of the input's lazy BatchNorm) in one launch; dt stays on chip.  dy is the
- * gradient wrt the pointwise output with the BatchNorm backward already applied (addk_bn_bwd_apply).  The pointwise WEIGHT
+ * gradient wrt the pointwise output with the BatchNorm backward already applied (addk_bn_bwd_apply) or, with `fold`, applied here.  The pointwise WEIGHT
  * gradient is not part of it (addk_conv_wgrad on dy and the stored depthwise output).  `ws` ([rows][C][K*K] floats) and `dab`
  * ([rows][C][2] fp64) get one row per workgroup, rows = addk_sep_bwd_rows(a); ws is reduced by addk_dw_wreduce_batch. */
 typedef struct addk_sep_bwd_args {
@@ -247,6 +255,7 @@ typedef struct addk_sep_bwd_args {
   float* g; int32_t ldg; int32_t accumulate;   /* gradient wrt src.x (NULL: skip) */
   double* dab;                      /* or NULL */
   float* ws;
+  addk_bn_fold fold;                /* fold.y != NULL: dy is the gradient BEFORE addk_bn_bwd_apply, which is applied on the fly */
 } addk_sep_bwd_args;
 int addk_sep_bwd_rows(const addk_sep_bwd_args* a);
 int addk_sep_bwd(const addk_sep_bwd_args* a, void* stream);
