@@ -52,7 +52,7 @@ struct SepbGeo {
   static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + DWS + RED) * 4;
 };
 
-template <int KS, int KG, int KP, int R>
+template <int KS, int KG, int KP, int R, bool FOLD>
 __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   typedef SepbGeo<KS, KG, KP, R> G;
   constexpr int CT = G::CT, PW = G::PW, NPIX = G::NPIX, KQ = G::KQ, HK = KS / 2, NT = KS * KS;
@@ -96,7 +96,8 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
 
   // ---- stage 1: dt = W^T dy on the haloed patch, 16 pixels at a time ----
   // folded BatchNorm backward: dy = G + (c1 + c2 (y - mean)), addk_bn_bwd_apply's own expression, on this lane's channel quads
-  const bool fold = p.fold.y != nullptr;
+  // (a template variant: as a run-time branch the coefficient quads cost the DEFAULT path 30-80 VGPRs)
+  const bool fold = FOLD && p.fold.y != nullptr;
   float4 f1[KG], f2[KG], fm[KG];
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
@@ -244,21 +245,21 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   }
 }
 
-template <int KS, int KG, int KP, int R>
+template <int KS, int KG, int KP, int R, bool FOLD>
 __global__ void __launch_bounds__(256, 2) sepb_kernel(const SepbK p) {
   extern __shared__ __attribute__((aligned(16))) float sepb_sm[];
-  sepb_body<KS, KG, KP, R>(p, sepb_sm);
+  sepb_body<KS, KG, KP, R, FOLD>(p, sepb_sm);
 }
-template <int KS, int KG, int KP, int R>
+template <int KS, int KG, int KP, int R, bool FOLD>
 __global__ void __launch_bounds__(256, 2) sepb_batch_kernel(const SepbK* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) float sepb_sm[];
   const SepbK p = tab[blockIdx.z];
   if ((int)blockIdx.x >= p.gx) return;
-  sepb_body<KS, KG, KP, R>(p, sepb_sm);
+  sepb_body<KS, KG, KP, R, FOLD>(p, sepb_sm);
 }
 
-struct SepbCfg { int ks, kg, kp, r; };
-inline int sepb_key(const SepbCfg& c) { return (c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r; }
+struct SepbCfg { int ks, kg, kp, r, fold; };
+inline int sepb_key(const SepbCfg& c) { return (c.fold << 20) | (c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r; }
 
 bool sepb_fill(const addk_sep_bwd_args* a, SepbK& k, SepbCfg& c) {
   if (!a || !(a->K == 3 || a->K == 5) || a->N <= 0 || a->H <= 0 || a->W <= 0) return false;
@@ -284,28 +285,29 @@ bool sepb_fill(const addk_sep_bwd_args* a, SepbK& k, SepbCfg& c) {
   // (config 2: 256 workgroups at 64x128) and LOSES to the separate depthwise / pointwise launches beyond (F = 40, 80 channels at
   // 128x256 = 1024 workgroups: step 72.2 ms fused vs 66.5 ms unfused) — those shapes stay on the unfused kernels
   if (kg == 5 && (long)a->N * cdiv(a->H, 4) * cdiv(a->W, 16) > 512) return false;
-  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1;
+  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1; c.fold = a->fold.y ? 1 : 0;
   { static int fr = -1; if (fr < 0) { const char* e = getenv("ADDK_SEP_R"); fr = e ? atoi(e) : 0; } if (fr == 1 || (fr == 2 && kg == 3)) c.r = fr; }   // tuning aid
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
   return true;
 }
 
-template <int KS, int KG, int KP, int R>
+template <int KS, int KG, int KP, int R, bool FOLD>
 int sepb_go(bool batch, dim3 grid, hipStream_t st, const SepbK* one, const SepbK* tab) {
   typedef SepbGeo<KS, KG, KP, R> G;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_kernel<KS, KG, KP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_batch_kernel<KS, KG, KP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_kernel<KS, KG, KP, R, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_batch_kernel<KS, KG, KP, R, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr = true;
   }
-  if (batch) hipLaunchKernelGGL((sepb_batch_kernel<KS, KG, KP, R>), grid, dim3(256), G::LDS, st, tab);
-  else hipLaunchKernelGGL((sepb_kernel<KS, KG, KP, R>), grid, dim3(256), G::LDS, st, *one);
+  if (batch) hipLaunchKernelGGL((sepb_batch_kernel<KS, KG, KP, R, FOLD>), grid, dim3(256), G::LDS, st, tab);
+  else hipLaunchKernelGGL((sepb_kernel<KS, KG, KP, R, FOLD>), grid, dim3(256), G::LDS, st, *one);
   return addk_check_launch("sep_bwd");
 }
 
 int sepb_dispatch(const SepbCfg& c, bool batch, dim3 grid, hipStream_t st, const SepbK* one, const SepbK* tab) {
-#define ADDK_SEPB(KS_, KG_, KP_, R_) if (c.ks == KS_ && c.kg == KG_ && c.kp == KP_ && c.r == R_) return sepb_go<KS_, KG_, KP_, R_>(batch, grid, st, one, tab);
+#define ADDK_SEPB(KS_, KG_, KP_, R_) if (c.ks == KS_ && c.kg == KG_ && c.kp == KP_ && c.r == R_) \
+    return c.fold ? sepb_go<KS_, KG_, KP_, R_, true>(batch, grid, st, one, tab) : sepb_go<KS_, KG_, KP_, R_, false>(batch, grid, st, one, tab);
   ADDK_SEPB(3, 3, 40, 1) ADDK_SEPB(3, 3, 40, 2) ADDK_SEPB(5, 3, 40, 1) ADDK_SEPB(5, 3, 40, 2)
   ADDK_SEPB(3, 3, 56, 1) ADDK_SEPB(3, 3, 56, 2) ADDK_SEPB(5, 3, 56, 1) ADDK_SEPB(5, 3, 56, 2)
   ADDK_SEPB(3, 5, 72, 1) ADDK_SEPB(5, 5, 72, 1) ADDK_SEPB(3, 5, 88, 1) ADDK_SEPB(5, 5, 88, 1)
@@ -354,6 +356,6 @@ extern "C" int64_t addk_sep_bwd_batch_prepare(const addk_sep_bwd_args* a, int32_
 extern "C" int addk_sep_bwd_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
   ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "sep_bwd_batch_run: bad args");
   const int key = (int)meta[0];
-  SepbCfg c{key >> 16, (key >> 12) & 15, (key >> 4) & 255, key & 15};
+  SepbCfg c{(key >> 16) & 15, (key >> 12) & 15, (key >> 4) & 255, key & 15, (key >> 20) & 1};
   return sepb_dispatch(c, true, dim3((unsigned)meta[2], 1, (unsigned)meta[1]), (hipStream_t)stream, nullptr, reinterpret_cast<const SepbK*>(dev_blob));
 }

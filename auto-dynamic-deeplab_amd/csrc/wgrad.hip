@@ -1049,7 +1049,7 @@ __device__ __forceinline__ RsFrag<LAY> rs_load(const float* base, int li, bool o
 // channel (relative to the tile origin) held by component e, row/column index R of the MFMA tile
 template <int LAY> __device__ __forceinline__ int rs_chan(int e, int R) { return LAY == 4 ? 4 * R + e : (e < 2 ? 2 * R + e : 32 + R); }
 
-template <int LA, int LB, bool BATCH>
+template <int LA, int LB, bool BATCH, bool FOLD>
 __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
   int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
   if (BATCH) {
@@ -1084,7 +1084,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
   const float* zbase = p.src.x + c0;
   const bool same = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;      // 1x1: the activation pixel is the dy pixel
   // folded BatchNorm backward on the dy operand: dy = G + (c1 + c2 (y - mean)), addk_bn_bwd_apply's own expression
-  const bool fold = p.fold.y != nullptr;
+  // (a template variant: as a run-time branch it cost the default path 12-16 VGPRs; a batch takes it when any of its convs folds)
+  const bool fold = FOLD && p.fold.y != nullptr;
   const float* fbase = fold ? p.fold.y + co0 : p.dy;
   RsFrag<LA> f1, f2, fm;
 #pragma unroll
@@ -1435,6 +1436,8 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
 }
 
 static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, const WgK& k, const WgK* ops, const int4* work) {
+  const bool fold = (kind >> 8) & 1;         // bit 8: some conv of the launch carries a folded BatchNorm backward (kind 6 only)
+  kind &= 255;
   bool done = false;
 #define ADDK_OS(K_, TY_, TZ_) \
   if (kind == K_) { \
@@ -1464,8 +1467,10 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
 #undef ADDK_HK
 #define ADDK_RS(A_, B_) \
   if (kind == 6 && cty == A_ && ctz == B_) { \
-    if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true>), grid, dim3(256), 0, st, k, ops, work); \
-    else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false>), grid, dim3(256), 0, st, k, ops, work); \
+    if (ops) { if (fold) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true, true>), grid, dim3(256), 0, st, k, ops, work); \
+               else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true, false>), grid, dim3(256), 0, st, k, ops, work); } \
+    else { if (fold) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false, true>), grid, dim3(256), 0, st, k, ops, work); \
+           else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false, false>), grid, dim3(256), 0, st, k, ops, work); } \
     done = true; }
   ADDK_RS(3, 3) ADDK_RS(3, 4) ADDK_RS(4, 3) ADDK_RS(4, 4)
 #undef ADDK_RS
@@ -1512,7 +1517,7 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   int rc = wg_fill(a, k, cty, ctz, tiles, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = wg_launch(kind_of(a), cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
+  rc = wg_launch(kind_of(a) | (k.fold.y ? 256 : 0), cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
   if (rc) return rc;
   long n = (long)a->Cout * k.taps * a->src.C;
   if (k.splits > 16 && n <= 65536) {
@@ -1538,7 +1543,7 @@ extern "C" int addk_conv_wgrad_config(const addk_conv_wgrad_args* a, int32_t* cf
 extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
   if (!a || n <= 0 || !meta) { addk_set_error("wgrad_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
   long nblocks = 0, nrblocks = 0;
-  int kind0 = -1, cty0 = 0, ctz0 = 0;
+  int kind0 = -1, cty0 = 0, ctz0 = 0, anyfold = 0;
   int budget = 8192 / n; if (budget < 32) budget = 32; if (budget > 1536) budget = 1536;
   const int min_steps = n >= 4 ? 8 : 1;
   int h3_steps = 0;
@@ -1564,6 +1569,7 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
     int rc = wg_fill(&a[i], k, cty, ctz, tiles, host_blob != nullptr, budget, min_steps, h3_steps);
     if (rc) return rc;
     int kind = kind_of(&a[i]);
+    if (k.fold.y) anyfold = 256;
     if (i == 0) { kind0 = kind; cty0 = cty; ctz0 = ctz; }
     if (kind != kind0 || cty != cty0 || ctz != ctz0) { addk_set_error("wgrad_batch_prepare: mixed tile configurations"); return ADDK_ERR_INVALID; }
     nblocks += (long)tiles * k.splits;
@@ -1573,7 +1579,7 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
   const int64_t off_work = ((int64_t)n * sizeof(WgK) + 15) / 16 * 16;
   const int64_t off_rwork = off_work + nblocks * (int64_t)sizeof(int4);
   const int64_t total = off_rwork + nrblocks * (int64_t)sizeof(int4);
-  meta[0] = kind0; meta[1] = cty0; meta[2] = ctz0; meta[3] = n; meta[4] = off_work; meta[5] = nblocks; meta[6] = off_rwork; meta[7] = nrblocks;
+  meta[0] = kind0 | anyfold; meta[1] = cty0; meta[2] = ctz0; meta[3] = n; meta[4] = off_work; meta[5] = nblocks; meta[6] = off_rwork; meta[7] = nrblocks;
   if (!host_blob) return total;
   if (blob_bytes < total) { addk_set_error("wgrad_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
   WgK* ops = reinterpret_cast<WgK*>(host_blob);

@@ -1020,7 +1020,7 @@ class Graph:
             ba = L.SepBwdArgs()
             fill(ba, raw.ptr, raw.ld)
             ok = int(lib.addk_sep_bwd_rows(C.byref(ba))) > 0
-            if ok and os.environ.get('ADDK_FOLD_BN_APPLY', '0') == '1':      # measured SLOWER (step 38.3 vs 37.4 ms): opt-in, see DESIGN §10
+            if ok and os.environ.get('ADDK_FOLD_BN_APPLY', '0') == '1':      # measured SLOWER (step 37.7 vs 36.5 ms): opt-in, see DESIGN §10
                 # may the BatchNorm backward behind this half be folded into its two consumers (sepb's dy loader and the pointwise weight
                 # gradient's)?  Only when that weight gradient runs on the register-streaming kernel (kind 6), the one that honours `fold`
                 wa = L.ConvWgradArgs()
