@@ -463,7 +463,10 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
 // and in 100 MHz reference ticks (s_memrealtime): their ratio is the clock the CUs ran at INSIDE this kernel
 __device__ unsigned long long g_c3b_diag[64][4];        // 64 slots: the workgroups' atomics do not queue on one L2 line
 #endif
-template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1>
+// TR = 2 (3x3 / 5x5, dilation 1): the tile is TWO output rows of BPX pixels (same accumulator count as one row of 2 BPX): the patch holds
+// KS + 1 input rows instead of 2 KS for the same outputs — a third less staging (global loads, prologue, split, LDS writes) and HBM-side
+// traffic; p.H then counts row PAIRS in the tile walk (p.HT) and the epilogue masks the odd last row.
+template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1, int TR = 1>
 __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const int gx) {      // workgroup bx of gx along x (tiles, slab row)
 #ifdef ADDK_C3B_DIAG
   const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
@@ -474,12 +477,14 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   constexpr int KH_ = KS > 10 ? KS / 10 : KS, KW_ = KS > 10 ? KS % 10 : KS;
   static_assert(KS < 10 || (MODE == MODE_DGRAD && !BIGD && ST == 1), "anchored tap sets: data gradient only");
   constexpr int OB = BPX + 16;                                      // ST = 2: LDS position of the first odd patch column
-  constexpr int BC = 32 * WC, NTHR = 64 * WC * PH, PT = BPX / 32 / PH;
+  static_assert(TR == 1 || (TR == 2 && (KS == 3 || KS == 5) && !BIGD && ST == 1), "two-row tiles: centred kernels at dilation 1");
+  constexpr int BC = 32 * WC, NTHR = 64 * WC * PH, PT = TR * BPX / 32 / PH, TPR = BPX / 32;      // TPR: 32-pixel tiles per tile row
+  constexpr int PR_ = (KS > 10 ? KS / 10 : KS) + TR - 1;                                          // patch rows
   constexpr int TAPS = KH_ * KW_, HK = KS > 10 ? 0 : KS / 2;
   constexpr int PWP = cb_pwmax(KS, BIGD, BPX, ST);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
-  constexpr int NS = (KH_ * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
+  constexpr int NS = (PR_ * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
   static_assert(NS <= 32, "slot mask is 32 bits");
-  constexpr int PLANE = KH_ * PWP * 2;                             // uint4 units per plane
+  constexpr int PLANE = PR_ * PWP * 2;                             // uint4 units per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* red = reinterpret_cast<double*>(smem);                  // [PH][BC][2] running statistics of this block (per pixel half)
   uint4* Pl = reinterpret_cast<uint4*>(smem + ((PH * BC * 16 + 15) & ~15));   // [NP][KS][PWP][2] 16-byte halves
@@ -495,7 +500,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   auto slot_geo = [&](int k, int& r, int& sp, int& pj, bool& live) {
     const int pix = (t + NTHR * k) >> 2;
     r = pix / PWP; sp = pix - r * PWP;
-    if (ST == 1) { pj = sp; live = r < KH_ && pj < BPX + (KW_ - 1) * p.dil; }
+    if (ST == 1) { pj = sp; live = r < PR_ && pj < BPX + (KW_ - 1) * p.dil; }
     else { const bool odd = sp >= OB; const int idx = odd ? sp - OB : sp; pj = 2 * idx + (odd ? 1 : 0); live = r < KH_ && (odd ? idx < BPX : idx <= BPX); }
   };
   // fragment read base per kernel column: pixel lane%32 + kw*d of patch row 0, the 16-byte half swizzled by bit 3 of the pixel
@@ -518,7 +523,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   for (int tlin = bx; tlin < p.ntiles; tlin += gx) {
     const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
     const int rowid = tile / p.spr, sx = tile - rowid * p.spr;
-    const int n = rowid / p.H, oh = rowid - n * p.H;
+    const int n = rowid / p.HT, oh = (rowid - n * p.HT) * TR;
     const int ow0 = sx * BPX;
     unsigned vmask = 0;
     const int pbase = (n * p.IH + oh * ST - HK * d) * p.IW + ow0 * ST - HK * d;
@@ -581,7 +586,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
         int r, sp, pj; bool live;
         slot_geo(k, r, sp, pj, live);
-        if (r < KH_) {
+        if (r < PR_) {
           uint2 pl[NP];
           split4<NP>(v, pl);
           const int slot = (r * PWP + sp) * 2 + ((q >> 1) ^ ((sp >> 3) & 1));
@@ -602,7 +607,9 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
       const int kh = tap / KW_, kw = tap - kh * KW_;
       const uint4* b = Pl + xb[kw];
 #pragma unroll
-      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + (kh * PWP + (wpx * PT + j) * 32) * 2];
+      const int L = wpx * PT + j;                      // linear 32-pixel tile of the block: tile row L / TPR, column tile L % TPR (wpx, j: compile-time or wave-uniform)
+#pragma unroll
+      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + ((kh + L / TPR) * PWP + (L % TPR) * 32) * 2];
     };
     // The accumulation inside the bf16 MFMA is not symmetric: what falls below its internal guard bits is floored, not rounded, so
     // a result sits, on average, 0.17 rms errors BELOW the exact sum whatever the sign of the data (scripts/bf16_bias_probe.hip:
@@ -691,17 +698,18 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
       for (int e = 0; e < 4; ++e) { s1[g][e] = 0.f; s2v[g][e] = 0.f; }
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-      const int lp = (wpx * PT + j) * 32 + lp32;
+      const int L = wpx * PT + j, jr = L / TPR;
+      const int lp = (L % TPR) * 32 + lp32;
       // output pixel: the tile grid's (oh, ow) itself, or (stride-2 data gradient) pixel (om oh + oro, om ow + oco) of the OHo x OWo map
-      const long pp = p.om == 1 ? (long)rowid * p.W + ow0 + lp : ((long)n * p.OHo + oh * p.om + p.oro) * p.OWo + (long)(ow0 + lp) * p.om + p.oco;
-      const bool pin = ow0 + lp < p.W;
+      const long pp = p.om == 1 ? ((long)n * p.H + oh + jr) * p.W + ow0 + lp : ((long)n * p.OHo + oh * p.om + p.oro) * p.OWo + (long)(ow0 + lp) * p.om + p.oco;
+      const bool pin = ow0 + lp < p.W && oh + jr < p.H;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = n0 + wave * 32 + 8 * g + 4 * hh;
         const int nrem = p.Cn - c;
         if (!pin || nrem <= 0) continue;
         float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-        if ((par0 + (unsigned)lp32) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
+        if ((par0 + (unsigned)(jr + lp32)) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
         if (MODE == MODE_FWD) {
           if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
           if (p.bias_n) {
@@ -759,9 +767,9 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   }
 }
 
-template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1>
+template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1, int TR = 1>
 __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
-  conv3b_body<WC, KS, MODE, NP, BIGD, PH, BPX, ST>(p, blockIdx.x, gridDim.x);
+  conv3b_body<WC, KS, MODE, NP, BIGD, PH, BPX, ST, TR>(p, blockIdx.x, gridDim.x);
 }
 // the four parity classes of the stride-2 data gradient in ONE launch: workgroups [row0[c], row0[c + 1]) run class c
 struct C3K4 { C3K c[4]; int row0[5]; };

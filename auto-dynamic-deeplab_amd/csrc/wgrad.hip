@@ -1417,7 +1417,8 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
     cty = rs_lay(k.vecY); ctz = rs_lay(k.vecZ);
     k.nyt = cdiv(a->Cout, k.vecY); k.nzt = cdiv(a->src.C, k.vecZ);
     tiles = k.nyt * k.taps * k.nzt;
-    int sp = cdiv(k.P, 2048);
+    static int rs_chunk = 0; if (!rs_chunk) { const char* e = getenv("ADDK_RS_CHUNK"); rs_chunk = e ? atoi(e) : 2048; if (rs_chunk < 256) rs_chunk = 2048; }      // tuning aid
+    int sp = cdiv(k.P, rs_chunk);
     if (sp > cap) sp = cap;
     if (sp < 1) sp = 1;
     k.chunkP = cdiv(cdiv(k.P, sp), 4) * 4;
