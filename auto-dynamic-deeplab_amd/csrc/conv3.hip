@@ -34,6 +34,7 @@ struct C3K {
   addk_src src[ADDK_MAX_SRC];
   int nsrc;
   int N, H, W, dil;       // H, W: the OUTPUT map (tiles, epilogue)
+  int HT;                   // tile rows in the walk: H, or ceil(H / 2) for two-row tiles
   int IH, IW;               // the input map (= H, W for the stride-1 launches)
   int Cn, ldy;
   float* y;
@@ -506,8 +507,16 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   // fragment read base per kernel column: pixel lane%32 + kw*d of patch row 0, the 16-byte half swizzled by bit 3 of the pixel
   // (tile j adds 32 pixels: bit 3 unchanged); patch row kh and tile j are immediate offsets
   int xb[KW_];
+  // 32-pixel tile j of this wave: tile row wrow + jrow(j), column tile wcol + jcol(j) (4-wave blocks of <= 64 channels split the tiles over two wave pairs:
+  // by rows when the tile has two, else by columns)
+  const int wrow = (PH == 2 && TR == 2) ? wpx : 0, wcol = (PH == 2 && TR == 1) ? wpx * PT : 0;
+  auto jrow = [](int j) { return PH == 1 ? j / TPR : 0; };
+  auto jcol = [](int j) { return PH == 1 ? j % TPR : j; };
 #pragma unroll
-  for (int kw = 0; kw < KW_; ++kw) { const int pj = ST == 2 ? (kw == 1 ? OB + lp32 : lp32 + (kw >> 1)) : lp32 + kw * d; xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)); }
+  for (int kw = 0; kw < KW_; ++kw) {
+    const int pj = ST == 2 ? (kw == 1 ? OB + lp32 : lp32 + (kw >> 1)) : lp32 + kw * d;
+    xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)) + (wrow * PWP + wcol * 32) * 2;
+  }
   const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)blockIdx.y * p.wp_blk + (long)wave * NP * 64 + lane);
   const int nT = p.nT;
   unsigned pmask = 0;                         // bit k: parity of (r*d + pj) of this thread's patch slot k (checkerboard sign, below)
@@ -607,9 +616,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
       const int kh = tap / KW_, kw = tap - kh * KW_;
       const uint4* b = Pl + xb[kw];
 #pragma unroll
-      const int L = wpx * PT + j;                      // linear 32-pixel tile of the block: tile row L / TPR, column tile L % TPR (wpx, j: compile-time or wave-uniform)
-#pragma unroll
-      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + ((kh + L / TPR) * PWP + (L % TPR) * 32) * 2];
+      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + ((kh + jrow(j)) * PWP + jcol(j) * 32) * 2];        // the wave's own tile row / first column tile sit in xb[]
     };
     // The accumulation inside the bf16 MFMA is not symmetric: what falls below its internal guard bits is floored, not rounded, so
     // a result sits, on average, 0.17 rms errors BELOW the exact sum whatever the sign of the data (scripts/bf16_bias_probe.hip:
@@ -698,8 +705,8 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
       for (int e = 0; e < 4; ++e) { s1[g][e] = 0.f; s2v[g][e] = 0.f; }
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-      const int L = wpx * PT + j, jr = L / TPR;
-      const int lp = (L % TPR) * 32 + lp32;
+      const int jr = wrow + jrow(j);
+      const int lp = (wcol + jcol(j)) * 32 + lp32;
       // output pixel: the tile grid's (oh, ow) itself, or (stride-2 data gradient) pixel (om oh + oro, om ow + oco) of the OHo x OWo map
       const long pp = p.om == 1 ? ((long)n * p.H + oh + jr) * p.W + ow0 + lp : ((long)n * p.OHo + oh * p.om + p.oro) * p.OWo + (long)(ow0 + lp) * p.om + p.oco;
       const bool pin = ow0 + lp < p.W && oh + jr < p.H;
@@ -897,6 +904,7 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
     c.wp = pk.out + pre * unit * np * 4;
     c.wp_blk = (long)pk.nchunks * tc * wc * np * 64;
     c.spr = cdiv(c.W, C3_BP);
+    c.HT = c.H;
     c.ntiles = c.N * c.H * c.spr;
     c.red32 = 1;
     if (c.slab) c.slab += (long)row0 * c.slab_ld * 2;
@@ -932,14 +940,18 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const long blocks64 = (long)k.N * k.H * cdiv(k.W, 64) * cdiv(k.Cn, 32 * wc);
   const bool quarter = half && quarter_on && wc == 3 && !bigd && (ks == 3 || ks == 5) && blocks64 < 192;      // measured: 160 ch @ 32x64 85 -> 63 us (5x5), 45 -> 34 (3x3); 80 ch @ 63x127 (252 blocks) is slower quartered (53 -> 66)
   const int bpx = k.st == 2 ? (s2bpx == 128 ? 128 : 64) : quarter ? 32 : half ? 64 : C3_BP;
-  k.spr = cdiv(k.W, bpx);
-  k.ntiles = k.N * k.H * k.spr;
+  // two-row tiles (2 x 64 pixels) for the full-width 3x3 launches at dilation 1 (decoder, stem1): KS + 1 staged rows per two output rows
+  static int tworow_on = -1; if (tworow_on < 0) { const char* e = getenv("ADDK_C3B_TWOROW"); tworow_on = (e && e[0] == '0') ? 0 : 1; }
+  const bool tworow = tworow_on && k.st == 1 && ks == 3 && !bigd && k.dil == 1 && k.om == 1 && bpx == C3_BP && (wc == 4 || wc == 2) && k.H >= 2;
+  k.HT = tworow ? cdiv(k.H, 2) : k.H;
+  k.spr = cdiv(k.W, tworow ? 64 : bpx);
+  k.ntiles = k.N * k.HT * k.spr;
   k.red32 = 1;
   if (desc_out) { *desc_out = pk; return ADDK_OK; }
   const long total = (long)cdiv(k.Cn, 32 * wc) * k.nT * wc * 64;   // pack threads: one per (tile, lane)
   int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
   if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
-  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * ks * cb_pwmax(ks, bigd, bpx, k.st) * 32;
+  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * (tworow ? ks + 1 : ks) * cb_pwmax(ks, bigd, tworow ? 64 : bpx, k.st) * 32;
   dim3 grid(rows, cdiv(k.Cn, 32 * wc));
   bool done = false;
 #define ADDK_C3B_(W_, K_, M_, P_, D_, X_) { \
@@ -952,7 +964,17 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
     if (mode == MODE_FWD) { if (np == 3) ADDK_C3B_(W_, K_, MODE_FWD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_FWD, 2, D_, X_) } \
     else { if (np == 3) ADDK_C3B_(W_, K_, MODE_DGRAD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_DGRAD, 2, D_, X_) } }
 #define ADDK_C3B(W_, K_, D_) ADDK_C3BX(W_, K_, D_, C3_BP)
-  if (k.st == 2) {               // stem2 forward
+  if (tworow) {
+#define ADDK_C3TR(W_, M_, P_) { \
+      constexpr int H_ = W_ == 2 ? 2 : 1; \
+      hipLaunchKernelGGL((conv3b_kernel<W_, 3, M_, P_, false, H_, 64, 1, 2>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
+#define ADDK_C3TRW(W_) if (wc == W_) { \
+      if (mode == MODE_FWD) { if (np == 3) ADDK_C3TR(W_, MODE_FWD, 3) else ADDK_C3TR(W_, MODE_FWD, 2) } \
+      else { if (np == 3) ADDK_C3TR(W_, MODE_DGRAD, 3) else ADDK_C3TR(W_, MODE_DGRAD, 2) } }
+    ADDK_C3TRW(4) ADDK_C3TRW(2)
+#undef ADDK_C3TRW
+#undef ADDK_C3TR
+  } else if (k.st == 2) {               // stem2 forward
     if (wc == 4 && ks == 3 && mode == MODE_FWD) {
 #define ADDK_C3S2(P_, X_) { \
       static bool attr = false; \

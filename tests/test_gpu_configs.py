@@ -127,7 +127,9 @@ def test_add_configs_eval_and_train_step(dev, golden, tag):
     assert cos >= 0.99
 
 
-@pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])
+@pytest.mark.parametrize('gname', ['genotype_1', pytest.param('genotype_2', marks=pytest.mark.skipif(
+    os.environ.get('ADDK_LONG_TESTS', '0') != '1', reason='second genotype of config 5 at 2x256x512 (+85 s of fp64 oracle): ADDK_LONG_TESTS=1; '
+    'its wiring is covered at 65x129 by test_add_configs_eval_and_train_step[F40_g2_65]'))])
 def test_f40_frozen_bn_gradients(dev, gname):
     """Config 5's architecture, backward included, at 2x256x512 (cell maps >= 8k pixels: the large-map kernels engage):
     BatchNorm frozen, every conv-weight gradient held against the fp64 oracle relative to the fp32 oracle's own error.

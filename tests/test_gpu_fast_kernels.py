@@ -23,6 +23,8 @@ SHAPES = [
     ('aspp_like_d6',   1, 70, 128, (48,), 256, 6, 3),
     ('wide_blocks_d1', 2, 64, 256, (32,), 256, 1, 3),
     ('max_dil_d18',    1, 64, 128, (16,), 64, 18, 3),
+    ('tworow_odd',     2, 65, 300, (24,), 128, 1, 3),      # full-width 3x3 at dilation 1: TWO-ROW tiles (2 x 64 px), odd row count, 300 = 4 x 64 + 44
+    ('tworow_c64',     1, 129, 200, (32,), 64, 1, 3),      # ... on the 4-wave form of the <= 64-channel launches (wave pairs split by tile row), dgrad too
     ('cell_dil5_40',   1, 70, 125, (40,), 40, 2, 5),       # dil_conv_5x5 at level 1 (3 column tiles, K tail 40 = 16+16+8)
     ('cell_dil5_80',   2, 63, 127, (80,), 80, 2, 5),       # level 2 (5 column tiles)
     ('cell_dil3_40',   1, 70, 125, (40,), 40, 2, 3),       # dil_conv_3x3
