@@ -464,9 +464,10 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
 // and in 100 MHz reference ticks (s_memrealtime): their ratio is the clock the CUs ran at INSIDE this kernel
 __device__ unsigned long long g_c3b_diag[64][4];        // 64 slots: the workgroups' atomics do not queue on one L2 line
 #endif
-// TR = 2 (3x3 / 5x5, dilation 1): the tile is TWO output rows of BPX pixels (same accumulator count as one row of 2 BPX): the patch holds
-// KS + 1 input rows instead of 2 KS for the same outputs — a third less staging (global loads, prologue, split, LDS writes) and HBM-side
-// traffic; p.H then counts row PAIRS in the tile walk (p.HT) and the epilogue masks the odd last row.
+// TR = 2 (3x3 / 5x5, dilation d <= 2): the tile is TWO output rows of BPX pixels, d rows apart — oh0 and oh0 + d, whose input rows oh0 + (r - HK) d,
+// r = 0..KS, overlap in KS - 1 of KS + 1 — with the accumulator count of one row of 2 BPX pixels: the patch holds KS + 1 input rows instead
+// of 2 KS for the same outputs, 33 % (3x3) / 40 % (5x5) less staging (global loads, prologue, split, LDS writes) and HBM-side traffic.  The
+// tile walk counts row PAIRS (p.HT; pair q -> oh0 = (q / d) 2d + q % d) and the epilogue masks second rows beyond the map.
 template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1, int TR = 1>
 __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const int gx) {      // workgroup bx of gx along x (tiles, slab row)
 #ifdef ADDK_C3B_DIAG
@@ -532,7 +533,8 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   for (int tlin = bx; tlin < p.ntiles; tlin += gx) {
     const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
     const int rowid = tile / p.spr, sx = tile - rowid * p.spr;
-    const int n = rowid / p.HT, oh = (rowid - n * p.HT) * TR;
+    const int n = rowid / p.HT, prq = rowid - n * p.HT;
+    const int oh = TR == 1 ? prq : (prq / d) * (2 * d) + prq % d;
     const int ow0 = sx * BPX;
     unsigned vmask = 0;
     const int pbase = (n * p.IH + oh * ST - HK * d) * p.IW + ow0 * ST - HK * d;
@@ -708,15 +710,15 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
       const int jr = wrow + jrow(j);
       const int lp = (wcol + jcol(j)) * 32 + lp32;
       // output pixel: the tile grid's (oh, ow) itself, or (stride-2 data gradient) pixel (om oh + oro, om ow + oco) of the OHo x OWo map
-      const long pp = p.om == 1 ? ((long)n * p.H + oh + jr) * p.W + ow0 + lp : ((long)n * p.OHo + oh * p.om + p.oro) * p.OWo + (long)(ow0 + lp) * p.om + p.oco;
-      const bool pin = ow0 + lp < p.W && oh + jr < p.H;
+      const long pp = p.om == 1 ? ((long)n * p.H + oh + jr * d) * p.W + ow0 + lp : ((long)n * p.OHo + oh * p.om + p.oro) * p.OWo + (long)(ow0 + lp) * p.om + p.oco;
+      const bool pin = ow0 + lp < p.W && oh + jr * d < p.H;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = n0 + wave * 32 + 8 * g + 4 * hh;
         const int nrem = p.Cn - c;
         if (!pin || nrem <= 0) continue;
         float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-        if ((par0 + (unsigned)(jr + lp32)) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
+        if ((par0 + (unsigned)(jr * d + lp32)) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
         if (MODE == MODE_FWD) {
           if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
           if (p.bias_n) {
@@ -940,18 +942,20 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const long blocks64 = (long)k.N * k.H * cdiv(k.W, 64) * cdiv(k.Cn, 32 * wc);
   const bool quarter = half && quarter_on && wc == 3 && !bigd && (ks == 3 || ks == 5) && blocks64 < 192;      // measured: 160 ch @ 32x64 85 -> 63 us (5x5), 45 -> 34 (3x3); 80 ch @ 63x127 (252 blocks) is slower quartered (53 -> 66)
   const int bpx = k.st == 2 ? (s2bpx == 128 ? 128 : 64) : quarter ? 32 : half ? 64 : C3_BP;
-  // two-row tiles (2 x 64 pixels) for the full-width 3x3 launches at dilation 1 (decoder, stem1): KS + 1 staged rows per two output rows
-  static int tworow_on = -1; if (tworow_on < 0) { const char* e = getenv("ADDK_C3B_TWOROW"); tworow_on = (e && e[0] == '0') ? 0 : 1; }
-  const bool tworow = tworow_on && k.st == 1 && ks == 3 && !bigd && k.dil == 1 && k.om == 1 && bpx == C3_BP && (wc == 4 || wc == 2) && k.H >= 2;
-  k.HT = tworow ? cdiv(k.H, 2) : k.H;
-  k.spr = cdiv(k.W, tworow ? 64 : bpx);
+  // two-row tiles (2 rows, d apart, of half the one-row width) for the 3x3 / 5x5 launches at dilation <= 2: KS + 1 staged rows per two output rows
+  static int tworow_on = -1; if (tworow_on < 0) { const char* e = getenv("ADDK_C3B_TWOROW"); tworow_on = e ? atoi(e) : 2; }      // 1: dilation-1 3x3 only (decoder, stem1); 2: all
+  const bool tr_shape = k.st == 1 && (ks == 3 || ks == 5) && !bigd && k.om == 1 && (bpx == C3_BP || (bpx == 64 && wc == 3)) && k.H >= 2 * k.dil;
+  const bool tworow = tr_shape && (tworow_on >= 2 || (tworow_on == 1 && ks == 3 && k.dil == 1 && (wc == 4 || wc == 2)));
+  const int rpx = tworow ? bpx / 2 : bpx;                       // pixels per tile row
+  k.HT = tworow ? cdiv(k.H, 2 * k.dil) * k.dil : k.H;
+  k.spr = cdiv(k.W, rpx);
   k.ntiles = k.N * k.HT * k.spr;
   k.red32 = 1;
   if (desc_out) { *desc_out = pk; return ADDK_OK; }
   const long total = (long)cdiv(k.Cn, 32 * wc) * k.nT * wc * 64;   // pack threads: one per (tile, lane)
   int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
   if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
-  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * (tworow ? ks + 1 : ks) * cb_pwmax(ks, bigd, tworow ? 64 : bpx, k.st) * 32;
+  const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * (tworow ? ks + 1 : ks) * cb_pwmax(ks, bigd, rpx, k.st) * 32;
   dim3 grid(rows, cdiv(k.Cn, 32 * wc));
   bool done = false;
 #define ADDK_C3B_(W_, K_, M_, P_, D_, X_) { \
@@ -965,13 +969,17 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
     else { if (np == 3) ADDK_C3B_(W_, K_, MODE_DGRAD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_DGRAD, 2, D_, X_) } }
 #define ADDK_C3B(W_, K_, D_) ADDK_C3BX(W_, K_, D_, C3_BP)
   if (tworow) {
-#define ADDK_C3TR(W_, M_, P_) { \
+#define ADDK_C3TR(W_, K_, X_, M_, P_) { \
       constexpr int H_ = W_ == 2 ? 2 : 1; \
-      hipLaunchKernelGGL((conv3b_kernel<W_, 3, M_, P_, false, H_, 64, 1, 2>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
-#define ADDK_C3TRW(W_) if (wc == W_) { \
-      if (mode == MODE_FWD) { if (np == 3) ADDK_C3TR(W_, MODE_FWD, 3) else ADDK_C3TR(W_, MODE_FWD, 2) } \
-      else { if (np == 3) ADDK_C3TR(W_, MODE_DGRAD, 3) else ADDK_C3TR(W_, MODE_DGRAD, 2) } }
-    ADDK_C3TRW(4) ADDK_C3TRW(2)
+      static bool attr = false; \
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, false, H_, X_, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+      hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, false, H_, X_, 1, 2>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
+#define ADDK_C3TRW(W_, K_, X_) if (!done && wc == W_ && ks == K_ && rpx == X_) { \
+      if (mode == MODE_FWD) { if (np == 3) ADDK_C3TR(W_, K_, X_, MODE_FWD, 3) else ADDK_C3TR(W_, K_, X_, MODE_FWD, 2) } \
+      else { if (np == 3) ADDK_C3TR(W_, K_, X_, MODE_DGRAD, 3) else ADDK_C3TR(W_, K_, X_, MODE_DGRAD, 2) } }
+    ADDK_C3TRW(4, 3, 64) ADDK_C3TRW(2, 3, 64) ADDK_C3TRW(3, 3, 64) ADDK_C3TRW(5, 3, 64)
+    ADDK_C3TRW(2, 5, 64) ADDK_C3TRW(3, 5, 64) ADDK_C3TRW(4, 5, 64) ADDK_C3TRW(5, 5, 64)
+    ADDK_C3TRW(3, 3, 32) ADDK_C3TRW(3, 5, 32)
 #undef ADDK_C3TRW
 #undef ADDK_C3TR
   } else if (k.st == 2) {               // stem2 forward
