@@ -62,54 +62,33 @@ __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
     if (active && i < p.nterm && p.term[i].a) { av[i] = ld4g(p.term[i].a + c, nrem, p.vec); bv[i] = ld4g(p.term[i].b + c, nrem, p.vec); }
   }
   if (active) {
-    // software-pipelined over the thread's pixels: the loads of pixel k + 1 (gradient, output, every term) are in flight while pixel k is
-    // reduced — a thread walks only 2-3 pixels, so an exposed round trip per pixel was most of the kernel's 18 us
-    const long stride = (long)gridDim.x * p.npl;
-    long pp = (long)blockIdx.x * p.npl + pl;
-    float4 d = zero4(), o = zero4(), x[ADDK_MAX_TERMS];
-    auto load = [&](long q, float4& dd, float4& oo, float4 (&xx)[ADDK_MAX_TERMS]) {
-      dd = ld4g(p.dout + q * p.lddo + c, nrem, p.vec);
-      if (p.relu_out) oo = ld4g(p.fout + q * p.ldfo + c, nrem, p.vec);
-#pragma unroll
-      for (int i = 0; i < ADDK_MAX_TERMS; ++i)
-        if (i < p.nterm && (p.g[i] || p.dab[i])) xx[i] = ld4g(p.term[i].x + q * p.term[i].ld + c, nrem, p.vec);
-    };
-#pragma unroll
-    for (int i = 0; i < ADDK_MAX_TERMS; ++i) x[i] = zero4();
-    if (pp < p.P) load(pp, d, o, x);
-    while (pp < p.P) {
-      const long nx = pp + stride;
-      float4 dn = zero4(), on = zero4(), xn[ADDK_MAX_TERMS];
-#pragma unroll
-      for (int i = 0; i < ADDK_MAX_TERMS; ++i) xn[i] = zero4();
-      if (nx < p.P) load(nx, dn, on, xn);
+    for (long pp = (long)blockIdx.x * p.npl + pl; pp < p.P; pp += (long)gridDim.x * p.npl) {
+      float4 d = ld4g(p.dout + pp * p.lddo + c, nrem, p.vec);
       if (p.relu_out) {
+        float4 o = ld4g(p.fout + pp * p.ldfo + c, nrem, p.vec);
         if (!(o.x > 0.f)) d.x = 0.f; if (!(o.y > 0.f)) d.y = 0.f; if (!(o.z > 0.f)) d.z = 0.f; if (!(o.w > 0.f)) d.w = 0.f;
       }
 #pragma unroll
       for (int i = 0; i < ADDK_MAX_TERMS; ++i) {
         if (i < p.nterm && (p.g[i] || p.dab[i])) {
-          const float4 xv = x[i];
+          float4 x = ld4g(p.term[i].x + pp * p.term[i].ld + c, nrem, p.vec);
           float4 dm = d;
           if (p.term[i].relu) {
-            if (!(fmaf(av[i].x, xv.x, bv[i].x) > 0.f)) dm.x = 0.f;
-            if (!(fmaf(av[i].y, xv.y, bv[i].y) > 0.f)) dm.y = 0.f;
-            if (!(fmaf(av[i].z, xv.z, bv[i].z) > 0.f)) dm.z = 0.f;
-            if (!(fmaf(av[i].w, xv.w, bv[i].w) > 0.f)) dm.w = 0.f;
+            if (!(fmaf(av[i].x, x.x, bv[i].x) > 0.f)) dm.x = 0.f;
+            if (!(fmaf(av[i].y, x.y, bv[i].y) > 0.f)) dm.y = 0.f;
+            if (!(fmaf(av[i].z, x.z, bv[i].z) > 0.f)) dm.z = 0.f;
+            if (!(fmaf(av[i].w, x.w, bv[i].w) > 0.f)) dm.w = 0.f;
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { sA[i][e] += (double)get4(dm, e) * (double)get4(xv, e); sB[i][e] += (double)get4(dm, e); }
+          for (int e = 0; e < 4; ++e) { sA[i][e] += (double)get4(dm, e) * (double)get4(x, e); sB[i][e] += (double)get4(dm, e); }
           if (p.g[i]) {
             float4 gv = make_float4(dm.x * av[i].x, dm.y * av[i].y, dm.z * av[i].z, dm.w * av[i].w);
             float* gp = p.g[i] + pp * p.ldg[i] + c;
-            if (p.acc[i]) { float4 oo = ld4g(gp, nrem, p.vec); gv.x += oo.x; gv.y += oo.y; gv.z += oo.z; gv.w += oo.w; }
+            if (p.acc[i]) { float4 o = ld4g(gp, nrem, p.vec); gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
             st4g(gp, gv, nrem, p.vec);
           }
         }
       }
-      pp = nx; d = dn; o = on;
-#pragma unroll
-      for (int i = 0; i < ADDK_MAX_TERMS; ++i) x[i] = xn[i];
     }
   }
   // Block reduction over the pixel lanes through an [npl][C4][2] fp64 panel: one barrier, then one thread per (channel, A|B)
