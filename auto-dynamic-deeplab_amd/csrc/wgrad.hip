@@ -1169,6 +1169,94 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
   }
 }
 
+// Weight gradient of a k x k conv with a HANDFUL of input channels (stem0: 3 -> 64, 3x3, stride 2; ADD.py:153-157): KH*KW*C <= 32 patch
+// values per output pixel.  On the generic kernel this launch re-read dy once per tap (0.37 ms, 0.9 TB/s).  Here it is ONE pass in the
+// register-streaming form of wgrad_rs_kernel: lane (li, kq) of a k-step = 4 pixels loads dy of pixel kq as one float4 at channel 4 li
+// (component e = A operand of output-channel tile {4r + e}) and GATHERS patch values e0 = li and 16 + li of that pixel (tap e / C,
+// channel e % C, prologue and zero padding applied) as the B operands of the two column tiles: 8 MFMAs per 4 pixels, dy read once.
+template <bool BATCH>
+__global__ void __launch_bounds__(256, 2) wgrad_st_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_y = blockIdx.y;
+  if (BATCH) {
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
+  __shared__ float tile[RS_T][33];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int C = p.src.C, NE = p.taps * C;                   // patch values per pixel (<= 32)
+  const bool y4 = 4 * li < p.Cout;
+  const int pbeg = blk_y * p.chunkP;
+  int pend = pbeg + p.chunkP; if (pend > p.P) pend = p.P;
+  const int span = (pend - pbeg + 3) / 4, per_wave = (span + 3) / 4;
+  const int s_beg = wave * per_wave, s_end = min(span, s_beg + per_wave);
+  // this lane's two patch elements: tap and channel, prologue coefficients
+  int ekh[2], ekw[2], ec[2]; bool eok[2]; float ea[2], eb[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int e = 16 * f + li;
+    eok[f] = e < NE;
+    const int tap = eok[f] ? e / C : 0;
+    ec[f] = eok[f] ? e - tap * C : 0;
+    ekh[f] = (tap / p.KW) * p.dil - p.pad; ekw[f] = (tap % p.KW) * p.dil - p.pad;
+    ea[f] = 1.f; eb[f] = 0.f;
+    if (p.src.a && eok[f]) { ea[f] = ((const gfloat*)p.src.a)[ec[f]]; eb[f] = ((const gfloat*)p.src.b)[ec[f]]; }
+  }
+  const bool zrelu = p.src.relu != 0;
+  const int ohw = p.OH * p.OW;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s0 = s_beg; s0 < s_end; s0 += RS_U) {
+    RsFrag<4> dy4[RS_U]; float zv[RS_U][2];
+#pragma unroll
+    for (int u = 0; u < RS_U; ++u) {
+      const int pp = pbeg + 4 * (s0 + u) + kq;
+      const bool pv_ = (s0 + u) < s_end && pp < pend;
+      dy4[u] = rs_load<4>(p.dy + (pv_ ? (long)pp * p.lddy : 0), li, pv_ && y4, false, false);
+      const int n = pp / ohw, rem = pp - n * ohw, oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int ih = oh * p.stride + ekh[f], iw = ow * p.stride + ekw[f];
+        const bool ok = pv_ && eok[f] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        float x = ((const gfloat*)p.src.x)[ok ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + ec[f] : 0];
+        x = fmaf(ea[f], x, eb[f]);
+        if (zrelu) x = fmaxf(x, 0.f);
+        zv[u][f] = ok ? x : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RS_U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy4[u].v[e], zv[u][f], acc[e][f], 0, 0, 0);
+  }
+  // combine the four waves in a fixed order; acc[e][f][r] = dW[4 (4 kq + r) + e][16 f + li]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = &tile[4 * (4 * kq + r) + e][16 * f + li];
+            *d = (w == 0) ? acc[e][f][r] : *d + acc[e][f][r];
+          }
+    }
+    __syncthreads();
+  }
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * NE;
+  for (int idx = t; idx < RS_T * 32; idx += 256) {
+    const int r = idx >> 5, cc = idx & 31;
+    if (r < p.Cout && cc < NE) wsb[(long)r * NE + cc] = tile[r][cc];
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* ws, int splits, int Cout, int taps, int C, float* dw, int ldw,
                                     int cin_total, int w_choff, int accumulate) {
   long n = (long)Cout * taps * C;
@@ -1310,7 +1398,12 @@ bool hk_ok(const addk_conv_wgrad_args* a) {
          a->Cout >= 32 && a->Cout <= 160 && a->Cout % 4 == 0 && a->src.C >= 16 && a->OW >= 32 &&
          aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) && (long)a->N * a->H * a->W >= 4096;
 }
-int kind_of(const addk_conv_wgrad_args* a) { return h3_ok(a) ? 5 : hk_ok(a) ? 7 : rs_ok(a) ? 6 : os_kind(a->Cout, a->src.C); }
+// 8: few input channels (stem0), all taps x channels in two column tiles of one workgroup (wgrad_st_kernel)
+bool st_ok(const addk_conv_wgrad_args* a) {
+  return (addk_get_fast_paths() & ADDK_FAST_WGRAD_RS) && a->src.C <= 4 && a->KH * a->KW * a->src.C <= 32 && a->Cout <= 64 && a->Cout % 4 == 0 &&
+         aligned16(a->dy) && a->lddy % 4 == 0 && (long)a->N * a->OH * a->OW >= 65536;
+}
+int kind_of(const addk_conv_wgrad_args* a) { return st_ok(a) ? 8 : h3_ok(a) ? 5 : hk_ok(a) ? 7 : rs_ok(a) ? 6 : os_kind(a->Cout, a->src.C); }
 // Halo-patch scheduling.  A block runs `steps` row segments; blocks are dispatched in grid order as CU slots free up
 // (2 resident blocks per CU at NT=2, 3 at NT=1), so what matters is that the LAST round of blocks is nearly full:
 // pick the segment count per block that minimises  ceil(blocks / slots) * (steps + start-up)  over the whole launch.
@@ -1366,6 +1459,7 @@ extern "C" int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_
     const int hs = h3_max_splits(h3_tiles(Cout, C));
     if (hs > splits) splits = hs;
   }
+  if (C <= 4 && taps * C <= 32 && Cout <= 64 && splits < 1024) splits = 1024;      // few input channels: wgrad_st_kernel slices the pixels only (st_ok)
   return (int64_t)splits * Cout * taps * C;
 }
 
@@ -1400,6 +1494,15 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   }
   k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
   k.vecZ = src_vec_ok(a->src);
+  if (st_ok(a)) {      // few input channels: one workgroup holds every (tap, channel) column; 1024-pixel slices, as many as the workspace bound allows
+    cty = 4; ctz = 2;
+    k.nyt = 1; k.nzt = 1; tiles = 1;
+    int sp = cdiv(k.P, 1024);
+    if (sp > 1024) sp = 1024;
+    k.chunkP = cdiv(cdiv(k.P, sp), 4) * 4;
+    k.splits = cdiv(k.P, k.chunkP);
+    ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  } else
   if (!h3_ok(a) && hk_ok(a)) {      // halo-patch kernel, taps split across waves: 64-pixel row segments like wgrad_h3
     const int ct = hk_ct(a->Cout, a->KH);
     cty = ct; ctz = a->KH;
@@ -1466,6 +1569,11 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_HK(3, 3) ADDK_HK(3, 5) ADDK_HK(5, 3)
 #undef ADDK_HK
+  if (kind == 8) {
+    if (ops) hipLaunchKernelGGL((wgrad_st_kernel<true>), grid, dim3(256), 0, st, k, ops, work);
+    else hipLaunchKernelGGL((wgrad_st_kernel<false>), grid, dim3(256), 0, st, k, ops, work);
+    done = true;
+  }
 #define ADDK_RS(A_, B_) \
   if (kind == 6 && cty == A_ && ctz == B_) { \
     if (ops) { if (fold) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true, true>), grid, dim3(256), 0, st, k, ops, work); \

@@ -292,9 +292,11 @@ def test_logits_upsample_backward_tiled_matches_autograd(lib, N, H, W, OH, OW, C
 
 @pytest.mark.parametrize('name,N,H,W,Ci,Cout,k,s,d', [
     ('pw40', 2, 63, 127, 40, 40, 1, 1, 1), ('pw80', 1, 64, 128, 80, 80, 1, 1, 1), ('glue200', 1, 50, 90, 200, 40, 1, 1, 1),
-    ('reduce_s2', 2, 128, 96, 80, 40, 1, 2, 1), ('dense3_s2', 2, 97, 129, 48, 96, 3, 2, 1), ('pw160', 2, 32, 64, 160, 160, 1, 1, 1)])
+    ('reduce_s2', 2, 128, 96, 80, 40, 1, 2, 1), ('dense3_s2', 2, 97, 129, 48, 96, 3, 2, 1), ('pw160', 2, 32, 64, 160, 160, 1, 1, 1),
+    ('stem0_like', 2, 256, 511, 3, 64, 3, 2, 1)])           # 3 input channels (ADD.py:153-157): all 27 (tap, channel) columns in one workgroup (wgrad_st_kernel), odd width
 def test_register_streaming_wgrad_matches_fp64_reference(lib, name, N, H, W, Ci, Cout, k, s, d):
-    """Weight gradients of the narrow cell convolutions (1x1, strided, multi-tile) on wgrad_rs_kernel vs autograd in fp64."""
+    """Weight gradients of the narrow cell convolutions (1x1, strided, multi-tile) on wgrad_rs_kernel, and of stem0 on its few-input-channel
+    sibling wgrad_st_kernel, vs autograd in fp64."""
     L = lib
     l = L.load()
     dev = torch.device('cuda:0')
@@ -322,7 +324,7 @@ def test_register_streaming_wgrad_matches_fp64_reference(lib, name, N, H, W, Ci,
         wa.ws = ws.data_ptr()
         cfg = (C.c_int32 * 4)()
         L.check(l.addk_conv_wgrad_config(C.byref(wa), cfg), 'wgrad_config')
-        assert (cfg[0] == 6) == (fast == 31), 'kernel kind %d with mask %d' % (cfg[0], fast)
+        assert (cfg[0] == (8 if Ci <= 4 else 6)) == (fast == 31), 'kernel kind %d with mask %d' % (cfg[0], fast)
         L.check(l.addk_conv_wgrad(C.byref(wa), torch.cuda.current_stream().cuda_stream), 'conv_wgrad')
         torch.cuda.synchronize()
         outs[fast] = dw
