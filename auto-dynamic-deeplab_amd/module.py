@@ -108,7 +108,7 @@ class Plan:
         return not self._has_coll
 
     def _forward_graphed(self, inputs):
-        if not self._graph_allowed(inputs):
+        if getattr(self, '_graph_refused', False) or not self._graph_allowed(inputs):
             return False
         self.calls += 1
         if self.calls < 3:
@@ -119,9 +119,16 @@ class Plan:
                 xs.copy_(x)
                 r.bind(xs)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-                self.g.run_parallel(self.g.fwd, None)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    self.g.run_parallel(self.g.fwd, None)
+            except Exception as e:      # a refused capture costs nothing but this call's graph: the eager launch loop stays the path of this plan
+                import warnings
+                warnings.warn('addk: hipGraph capture of the forward list refused (%s); this plan keeps the eager launch loop' % e)
+                self._graph_refused = True
+                return False
+            self.graph = graph
         for xs, x in zip(self.static_in, inputs):
             xs.copy_(x)
         self.graph.replay()
@@ -132,7 +139,7 @@ class Plan:
         Captured on the first backward that follows a graphed forward (the lists have run eagerly at least twice by then)."""
         if self.graph is None or not self.g.want_grad:
             return False
-        if self.bgraph is None:
+        if self.static_gy is None:
             self.static_gy = []
             for kind, o in self.outs:
                 if kind == 'in':
@@ -148,11 +155,22 @@ class Plan:
                 buf.zero_()
             else:
                 buf.copy_(gy)
+        if getattr(self, '_bgraph_refused', False):       # capture was refused once: the list runs eagerly on the plan-owned gradient buffers
+            self.g.run_parallel(self.g.bwd, None)
+            return True
         if self.bgraph is None:
             torch.cuda.synchronize()
-            self.bgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.bgraph, capture_error_mode='thread_local'):
+            bgraph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(bgraph, capture_error_mode='thread_local'):
+                    self.g.run_parallel(self.g.bwd, None)
+            except Exception as e:      # the incoming gradients already sit in the plan-owned buffers the commands point at: run the list eagerly
+                import warnings
+                warnings.warn('addk: hipGraph capture of the backward list refused (%s); this plan keeps the eager launch loop' % e)
+                self._bgraph_refused = True
                 self.g.run_parallel(self.g.bwd, None)
+                return True
+            self.bgraph = bgraph
         self.bgraph.replay()
         return True
 

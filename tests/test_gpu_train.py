@@ -193,24 +193,43 @@ def test_drop_in_step_replays_two_hipgraphs_and_equals_eager(dev, monkeypatch):
     whose data changes between steps goes through the plan-owned input / gradient buffers correctly."""
     from addk.loss import CrossEntropyLoss
     res = {}
-    for mode in ('1', '0'):
-        monkeypatch.setenv('ADDK_GRAPH_MODULE', mode)
+    real_graph = torch.cuda.graph
+
+    class _Refuse:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError('capture refused (test stub)')
+
+        def __exit__(self, *a):
+            return False
+    for mode in ('1', '0', 'refused'):
+        monkeypatch.setenv('ADDK_GRAPH_MODULE', '0' if mode == '0' else '1')
+        monkeypatch.setattr(torch.cuda, 'graph', _Refuse if mode == 'refused' else real_graph)
         ma, _ = _models(dev)
         ma.train()
         crit = CrossEntropyLoss(ignore_index=255)
         opt = torch.optim.SGD(ma.parameters(), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True)
         ls = []
-        for i in range(5):
-            x, t = _batch(2, (33, 65), seed=5 + (i % 2))          # two alternating batches: replay must pick up new input data
-            ys = ma(x.to(dev))
-            loss = sum(crit(y, t.to(dev)) for y in ys) / len(ys)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            ls.append(loss.item())
+        import warnings
+        with warnings.catch_warnings(record=True) as wlog:
+            warnings.simplefilter('always')
+            for i in range(5):
+                x, t = _batch(2, (33, 65), seed=5 + (i % 2))          # two alternating batches: replay must pick up new input data
+                ys = ma(x.to(dev))
+                loss = sum(crit(y, t.to(dev)) for y in ys) / len(ys)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                ls.append(loss.item())
         plans = [p for m in ma.modules() for p in getattr(m, '__dict__', {}).get('_addk_plans', {}).values()]
         assert plans and all((p.graph is not None and p.bgraph is not None) == (mode == '1') for p in plans if p.g.want_grad)
+        if mode == 'refused':        # a refused capture is reported once and the plan keeps the eager launch loop
+            assert sum('capture of the forward list refused' in str(w.message) for w in wlog) == 1
         res[mode] = (ls, torch.cat([p.detach().reshape(-1) for p in ma.parameters()]).cpu())
+    monkeypatch.setattr(torch.cuda, 'graph', real_graph)
+    assert res['refused'][0] == res['0'][0] and torch.equal(res['refused'][1], res['0'][1])
     assert res['1'][0] == res['0'][0], (res['1'][0], res['0'][0])
     assert torch.equal(res['1'][1], res['0'][1])
 
