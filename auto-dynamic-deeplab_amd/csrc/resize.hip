@@ -327,9 +327,11 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
 // ONCE in LDS, tw + 1 threads busy for a few dozen cycles, and every thread then issues its nh*nw independent 16-byte loads
 // straight from the table.  Statistics ((dA, dB) of a ReLU'd lazy source) as above: registers across segments, one row per workgroup.
 constexpr int RT_MAXW = 128;
+// MT: taps per axis an input pixel can receive from — 5 up to x2 up-sampling, 9 up to x4, 17 up to x8 (the resizes in front of ASPP)
+template <int MT>
 __global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int tiles_per_row, int ntiles, int tw) {
   extern __shared__ double redt[];       // [npl][C4][2]
-  __shared__ float wt_w[RT_MAXW][5], wt_h[5];
+  __shared__ float wt_w[RT_MAXW][MT], wt_h[MT];
   __shared__ int lo_w[RT_MAXW], n_w[RT_MAXW], lo_h, n_h;
   const int C = p.src.C;
   const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
@@ -348,21 +350,24 @@ __global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int ti
       const bool isw = (int)threadIdx.x < tw;
       const int i = isw ? iw0 + (int)threadIdx.x : ih, lim = isw ? p.W : p.H, in = lim, out = isw ? p.OW : p.OH;
       const float sc = isw ? sw : sh;
-      int lo = 0, cnt = 0; float wv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      int lo = 0, cnt = 0; float wv[MT];
+#pragma unroll
+      for (int k = 0; k < MT; ++k) wv[k] = 0.f;
       if (i < lim) {
         int hi; out_range(i, sc, out, lo, hi);
         while (lo < hi && tap_weight(lo, i, sc, in) == 0.f) ++lo;
         while (hi > lo && tap_weight(hi, i, sc, in) == 0.f) --hi;
         cnt = hi - lo + 1;
+        if (cnt > MT) cnt = MT;                           // (cannot happen for the scales the host sends here)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) wv[k] = k < cnt ? tap_weight(lo + k, i, sc, in) : 0.f;
+        for (int k = 0; k < MT; ++k) wv[k] = k < cnt ? tap_weight(lo + k, i, sc, in) : 0.f;
       }
       if (isw) { lo_w[threadIdx.x] = lo; n_w[threadIdx.x] = cnt;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) wt_w[threadIdx.x][k] = wv[k]; }
+        for (int k = 0; k < MT; ++k) wt_w[threadIdx.x][k] = wv[k]; }
       else { lo_h = lo; n_h = cnt;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) wt_h[k] = wv[k]; }
+        for (int k = 0; k < MT; ++k) wt_h[k] = wv[k]; }
     }
     __syncthreads();
     if (!active) continue;
@@ -373,17 +378,17 @@ __global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int ti
       const int nw = n_w[px], wlo = lo_w[px];
       const long pp = (long)rowid * p.W + iw;
       float4 dz = zero4();
-      float ww5[5]; int wo5[5];
+      float ww5[MT]; int wo5[MT];
 #pragma unroll
-      for (int k = 0; k < 5; ++k) { ww5[k] = wt_w[px][k]; wo5[k] = (k < nw ? wlo + k : wlo) * p.lddy; }
+      for (int k = 0; k < MT; ++k) { ww5[k] = wt_w[px][k]; wo5[k] = (k < nw ? wlo + k : wlo) * p.lddy; }
       for (int a = 0; a < nh; ++a) {
         const float wh = wt_h[a];
         const float* rowp = p.dy + (long)(n * p.OH + hlo + a) * p.OW * p.lddy + c;
-        float4 d5[5];
+        float4 d5[MT];
 #pragma unroll
-        for (int b = 0; b < 5; ++b) d5[b] = ld4(rowp + wo5[b]);
+        for (int b = 0; b < MT; ++b) d5[b] = ld4(rowp + wo5[b]);
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
+        for (int b = 0; b < MT; ++b) {
           const float k = wh * ww5[b];
           dz.x = fmaf(k, d5[b].x, dz.x); dz.y = fmaf(k, d5[b].y, dz.y); dz.z = fmaf(k, d5[b].z, dz.z); dz.w = fmaf(k, d5[b].w, dz.w);
         }
@@ -510,11 +515,15 @@ extern "C" int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream) {
     int rows = rs_rows(k.P, a->src.C);
     size_t sh = (size_t)m.npl * m.nq * 4 * 2 * sizeof(double);
     // at most x2 up-sampling (<= 5 taps per axis), vector-aligned, a few pixel lanes per workgroup: the table-driven kernel
-    if (k.vec && a->src.C == m.nq * 4 && m.npl >= 4 && a->OH <= 2 * a->H + 1 && a->OW <= 2 * a->W + 1 && (addk_get_fast_paths() & ADDK_FAST_DWTILE) &&
+    const bool up2 = a->OH <= 2 * a->H + 1 && a->OW <= 2 * a->W + 1, up4 = a->OH <= 4 * a->H + 1 && a->OW <= 4 * a->W + 1,
+               up8 = a->OH <= 8 * a->H + 1 && a->OW <= 8 * a->W + 1;
+    if (k.vec && a->src.C == m.nq * 4 && m.npl >= 2 && (up2 || up4 || up8) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) &&
         (long)a->N * a->H * a->W < (1L << 30)) {
-      int tw = m.npl * 4; if (tw > RT_MAXW) tw = RT_MAXW; if (tw > a->W) tw = a->W;
+      int tw = m.npl >= 4 ? m.npl * 4 : m.npl * 8; if (tw > RT_MAXW) tw = RT_MAXW; if (tw > a->W) tw = a->W;      // (2-3 pixel lanes: 260-512 channels)
       const int tpr = cdiv(a->W, tw), ntiles = a->N * a->H * tpr;
-      hipLaunchKernelGGL(resize_bwd_tab_kernel, dim3(rows), dim3(256), sh, st, k, tpr, ntiles, tw);
+      if (up2) hipLaunchKernelGGL(resize_bwd_tab_kernel<5>, dim3(rows), dim3(256), sh, st, k, tpr, ntiles, tw);
+      else if (up4) hipLaunchKernelGGL(resize_bwd_tab_kernel<9>, dim3(rows), dim3(256), sh, st, k, tpr, ntiles, tw);
+      else hipLaunchKernelGGL(resize_bwd_tab_kernel<17>, dim3(rows), dim3(256), sh, st, k, tpr, ntiles, tw);
       return addk_check_launch("resize_bwd_tab");
     }
     hipLaunchKernelGGL(resize_bwd_kernel<false>, dim3(rows), dim3(256), sh, st, k);

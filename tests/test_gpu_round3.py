@@ -267,10 +267,10 @@ def test_config5_architecture_full_size_logits_and_first_step_loss(dev):
 
 
 @pytest.mark.parametrize('shape', [(2, 40, 32, 64, 63, 127), (1, 40, 63, 127, 64, 128), (2, 64, 64, 128, 16, 32), (1, 80, 64, 128, 32, 64),
-                                   (2, 256, 16, 32, 32, 64), (1, 40, 128, 256, 125, 253)],
-                         ids=['up_32_63', 'fit_63_64', 'down4', 'down2', 'up2_c256', 'fit_128_125'])
+                                   (2, 256, 16, 32, 32, 64), (1, 40, 128, 256, 125, 253), (2, 160, 32, 64, 128, 256), (1, 80, 31, 63, 125, 253), (1, 160, 16, 32, 128, 256), (2, 400, 32, 64, 64, 128)],
+                         ids=['up_32_63', 'fit_63_64', 'down4', 'down2', 'up2_c256', 'fit_128_125', 'up4_c160', 'up4_odd', 'up8_c160', 'up2_c400'])
 def test_table_driven_resize_backward_matches_fp64_autograd(dev, shape):
-    """addk_resize_bwd on the table-driven kernel (csrc/resize.hip: resizes of at most x2 up-sampling) through the C ABI against
+    """addk_resize_bwd on the table-driven kernel (csrc/resize.hip: resizes of at most x4 up-sampling: 5 taps per axis up to x2, 9 up to x4, 17 up to x8) through the C ABI against
     fp64 autograd of F.interpolate(relu(a*x + b)): gradient wrt x (first touch and accumulate) and the (dA, dB) sums; and
     bit-identical to the per-thread kernel it replaces (fast path off)."""
     import addk._lib as L
