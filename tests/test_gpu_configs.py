@@ -199,7 +199,9 @@ def test_train_mode_gradient_spread_is_the_references_own(dev, hw):
     args = (ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(4), 0)
     crit = nn.CrossEntropyLoss(ignore_index=255)
     e32s, eas, coss, cos32 = [], [], [], []
-    ndraw = 4 if hw[0] % 2 == 0 else 2          # ~30 s each, almost all of it the oracle's fp64 pass
+    # ~30-45 s per draw, almost all of it the oracle's fp64 pass on the host: 3 even-size draws by default (ratios 0.95 0.36 2.02 with round 3's
+    # kernels), the fourth (the 8x outlier of the docstring) with ADDK_LONG_TESTS=1 — the GPU suite has to fit the driver's time limit on a slow box
+    ndraw = (4 if os.environ.get('ADDK_LONG_TESTS', '0') == '1' else 3) if hw[0] % 2 == 0 else 2
     for k in range(ndraw):
         mo = oracle.ADD(*args)
         fill_params(mo, 600 + k)
