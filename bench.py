@@ -262,7 +262,7 @@ def drop_in_step(model, x, t, steps=5):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(2):
+    for _ in range(4):          # two eager calls, the third captures the plan's forward / backward hipGraphs (module.Plan), the fourth replays
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
