@@ -342,6 +342,7 @@ def main():
     ap.add_argument('--math', choices=['fp32', 'bf16x6', 'bf16x3'], default=None,
                     help='arithmetic of the wide k x k contractions (default: the library default, see addk.get_precision())')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--extras-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--force-sync', action='store_true', help='rehearse the N>1 path (RCCL SyncBN + gradient all-reduce) at world_size 1')
     a = ap.parse_args()
     genotype = np.load(os.path.join(ROOT, 'searched_arch', a.genotype + '.npy'))
@@ -381,6 +382,27 @@ def main():
     model.to(dev)
     parallel.broadcast_params(model)
     n, h, w = a.batch, a.height, a.width
+    if a.extras_child:
+        # the measurements beside the headline number, in a process of their own (see `extras` below): one JSON object on the saved stdout
+        x, t = synthetic_batch(n, h, w, 1 + rank, dev)
+        res = {}
+
+        def guarded(name, fn):
+            try:
+                res[name] = fn()
+            except Exception as e:
+                res[name] = {'error': str(e).splitlines()[0] if str(e) else repr(e)}
+        with torch.no_grad():
+            guarded('segment_eval', lambda: segment_roofline(model, x, 'eval'))
+            guarded('segment_train', lambda: segment_roofline(model, x, 'train'))
+        guarded('per_exit_ms', lambda: per_exit_latency(model, dev))
+        guarded('drop_in', lambda: drop_in_step(model, x, t))
+        json_out.write(json.dumps(res) + '\n')
+        json_out.flush()                               # before the last, least proven extra: a crash there keeps the others
+        guarded('ddp_path_world1', lambda: ddp_path_world1(genotype, a, x, t, dev))
+        json_out.write(json.dumps({'ddp_path_world1': res['ddp_path_world1']}) + '\n')
+        json_out.flush()
+        return
     ts = TrainStep(model, (n, 3, h, w), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm,
                    use_graph=False if a.no_graph else None)
     x, t = synthetic_batch(n, h, w, 1 + rank, dev)
@@ -512,19 +534,35 @@ def main():
     default_cfg = (n, h, w, a.F, a.genotype) == (2, 1024, 2048, 20, 'autodeeplab/genotype')
     extras = world == 1 and not a.no_extras and comm is None and default_cfg
     if extras:
+        # Segment roofline, per-exit latency, the drop-in path and the N > 1 code path at world 1 run in a CHILD process: they capture
+        # hipGraphs of their own, start RCCL and replay captured collectives — one run in ~30 of this file ended without its JSON line
+        # while they still ran in-process (no stderr kept: cause unknown), and the headline number must not depend on them
         del ts
         torch.cuda.empty_cache()
-        with torch.no_grad():
-            seg = {m: segment_roofline(model, x, m) for m in ('eval', 'train')}
-        roof['segment'] = {'name': 'ASPP + cell forward, 1024x2048 bs=2 (BASELINE north_star: >= 0.60 of the HBM roofline)',
-                           'eval': seg['eval'], 'train': seg['train'], 'bound': 'hbm', 'peak_GBps': PEAK_HBM_GBS,
-                           'frac': seg['eval']['frac_hbm']}
-        out['per_exit_ms'] = per_exit_latency(model, dev)
-        out['drop_in'] = drop_in_step(model, x, t)
+        import subprocess
+        merged = {}
         try:
-            out['ddp_path_world1'] = ddp_path_world1(genotype, a, x, t, dev)
-        except Exception as e:                   # the extra must never cost the headline line
-            out['ddp_path_world1'] = {'error': str(e).splitlines()[0] if str(e) else repr(e)}
+            cmd = [sys.executable, os.path.abspath(__file__), '--extras-child', '--batch', str(n), '--height', str(h), '--width', str(w),
+                   '--F', str(a.F), '--genotype', a.genotype, '--math', math]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            for line in r.stdout.strip().splitlines():
+                try:
+                    merged.update(json.loads(line))
+                except ValueError:
+                    pass
+            if r.returncode != 0:
+                merged.setdefault('ddp_path_world1', {'error': 'extras child exited with code %d' % r.returncode})
+                sys.stderr.write(r.stderr[-2000:])
+        except subprocess.TimeoutExpired:
+            merged = {'error': 'extras child exceeded 900 s'}
+        if 'segment_eval' in merged and 'segment_train' in merged and 'error' not in merged['segment_eval'] and 'error' not in merged['segment_train']:
+            roof['segment'] = {'name': 'ASPP + cell forward, 1024x2048 bs=2 (BASELINE north_star: >= 0.60 of the HBM roofline)',
+                               'eval': merged['segment_eval'], 'train': merged['segment_train'], 'bound': 'hbm', 'peak_GBps': PEAK_HBM_GBS,
+                               'frac': merged['segment_eval']['frac_hbm']}
+        else:
+            roof['segment'] = {'error': str(merged.get('segment_eval', merged.get('error', 'extras child produced no output')))}
+        for key in ('per_exit_ms', 'drop_in', 'ddp_path_world1'):
+            out[key] = merged.get(key, {'error': merged.get('error', 'extras child produced no output')})
     if not a.no_cpu_baseline and world == 1 and default_cfg:
         cb = cpu_baseline(n, h, w)
         out['cpu_baseline'] = cb
