@@ -19,7 +19,10 @@ Besides the contract's fields the line carries, measured in this run on rank 0 a
   per_exit_ms        config 4: EDM-gated dynamic inference, early / final exit, 1024x2048 and 1025x2049, and the mean latency
                      at 0 / 50 / 100 % early exits
   drop_in            the same step through the reference's own call pattern (model(x); loss.backward(); torch.optim.SGD.step())
+  ddp_path_world1    the N > 1 code path (SyncBN exchanges + bucketed gradient all-reduce through RCCL) timed at world_size 1
   cpu_baseline       the CPU oracle on the same inputs (bounded sample), whose first-step loss the GPU loss is asserted against
+The four measurements beside the headline (segment, per_exit_ms, drop_in, ddp_path_world1) run in a child process of this file
+(--extras-child): whatever happens to them, the contract line is printed.
 """
 import argparse
 import json
