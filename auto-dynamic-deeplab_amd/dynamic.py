@@ -15,6 +15,11 @@ class DynamicPlan:
         from .modeling.ADD import _aspp_size
         for p in list(model.parameters()) + list(edm.parameters()):
             ensure_layout(p)
+        if x.shape[0] != 1:
+            # ADD.py:421 `if confidence_value > threshold` on a [bs, 1] tensor raises for bs > 1 ("Boolean value of Tensor with more
+            # than one value is ambiguous"): the gate is a per-image decision (eval.py:195-230 runs bs = 1); same error class here
+            raise RuntimeError('dynamic_inference gates one image at a time (got batch size %d): the reference\'s '
+                               '`if confidence_value > threshold` is ambiguous for more than one value' % x.shape[0])
         self.g = g = Graph(x.device, False, False, None)
         a, self.inref = g.input_nchw(x)
         size = (a.H, a.W)
@@ -100,8 +105,9 @@ class DynamicPlan:
             for k, end in enumerate(self.trunk_end):
                 self._seg(pos, end)
                 conf = self.conf[k].y.reshape(x.shape[0], -1)
+                assert conf.numel() == 1
                 h0, h1 = self.head_rng[k]
-                self._conf_host[:x.shape[0]].copy_(conf.reshape(-1), non_blocking=True)
+                self._conf_host[:1].copy_(conf.reshape(-1), non_blocking=True)
                 if self._conf_evt is not None:
                     self._conf_evt.record()
                     self._conf_evt.synchronize()                      # the host waits for this one scalar only

@@ -104,24 +104,18 @@ class TrainStep:
         self.nbt.bump(); self.nbt.flat.sub_(self.nbt.inc)      # flatten now (pointers must be fixed before graph capture)
         self.n_active = self.flat_p.numel()
         self.nbytes = g.nbytes
-        self.segmented = False
         if use_graph is None:
             # A step WITHOUT collectives is captured whole.  A step with RCCL collectives: whole when the world is this one
             # process (the forced-exchange rehearsal, tests/test_gpu_train.py) or ADDK_GRAPH_DDP=1 asks for it; with world > 1 the
             # default is the eager launch list until a multi-rank capture has been seen on hardware (no multi-GPU box was available
             # to the builder: DESIGN.md §7; bench.py times the eager list first and then TRIES the capture under a watchdog).
-            # ADDK_GRAPH_DDP=seg: every run of launches between two collectives as its own hipGraph, the collectives issued eagerly
-            # between them — no RCCL call inside any capture; correct (tested bit-identical) but measured SLOWER than the eager
-            # list at world 1 (48.2 vs 45.3 ms: each cut joins the two streams, ~330 graph launches leave gaps).
+            # (Round 3's third form — hipGraph segments between eager collectives — measured slower than the eager list twice
+            # and was removed in round 4.)
             ddp = os.environ.get('ADDK_GRAPH_DDP')
             if ddp is None:
                 ddp = '1' if self.world == 1 else '0'
             graphs_on = os.environ.get('ADDK_GRAPH', '1') == '1'
             use_graph = graphs_on and (not has_coll or ddp == '1')
-            self.segmented = graphs_on and has_coll and ddp == 'seg'
-        elif use_graph == 'seg':
-            use_graph, self.segmented = False, has_coll
-        self.segs = None
         self.has_coll = has_coll
         self.graph = None
         self.use_graph = use_graph
@@ -182,61 +176,10 @@ class TrainStep:
                 return None
         return graph
 
-    _COLLECTIVES = ('allreduce', 'allreduce_packed', 'grad_allreduce')
-
-    def _capture_segments(self):
-        """Cut the scheduled forward / backward lists at their collectives; every run of launches in between is re-scheduled on
-        its own (two streams, fork at its head, join at its tail: what crosses a cut is ordered by the main stream) and captured
-        as one hipGraph.  Returns [('graph', CUDAGraph) | ('call', cmd)] in replay order."""
-        g = self.g
-        segs = []
-        for lst in (g.fwd, g.bwd):
-            cur = []
-            for c in lst:
-                if c.name in self._COLLECTIVES:
-                    if cur:
-                        segs.append(('launches', cur))
-                        cur = []
-                    segs.append(('call', c))
-                else:
-                    cur.append(c)
-            if cur:
-                segs.append(('launches', cur))
-        out = []
-        for kind, item in segs:
-            if kind == 'call':
-                out.append((kind, item))
-                continue
-            for c in item:
-                c.event = None
-            _plan.schedule(item, g.nstreams)
-            for c in item:
-                c.event = torch.cuda.Event() if c.event else None
-            gr = torch.cuda.CUDAGraph()
-            # thread-local capture mode: ProcessGroupNCCL's watchdog thread polls the events of the collectives already issued
-            with torch.cuda.graph(gr, capture_error_mode='thread_local'):
-                g.run_parallel(item, None)
-            out.append(('graph', gr))
-        return out
-
-    def _run_segments(self):
-        st = torch.cuda.current_stream().cuda_stream
-        for kind, item in self.segs:
-            if kind == 'graph':
-                item.replay()
-            else:
-                rc = item.fn(*item.args, st)
-                if rc:
-                    L.check(rc, item.name)
-        if self.gsync is not None:
-            self.gsync.wait()
-        self._sgd(st)
-        self.nbt.flat.add_(self.nbt.inc)
-
     def enable_capture(self):
         """Switch a step that runs on the eager list to whole-step capture; the next step() runs eagerly once more and captures
         (a refused capture keeps every rank on the eager list).  Used by bench.py at world > 1 after the eager timing."""
-        self.use_graph, self.graph, self.segmented = True, None, False
+        self.use_graph, self.graph = True, None
 
     def load_batch(self, images, targets):
         self.x.copy_(images, non_blocking=True)
@@ -262,17 +205,26 @@ class TrainStep:
                     self.use_graph = False
             else:
                 self.graph.replay()
-        elif self.segmented:
-            if self.segs is None:
-                self._run()                          # this call's step, eagerly (warms RCCL); then the segments are captured
-                torch.cuda.synchronize()
-                self.segs = self._capture_segments()
-            else:
-                self._run_segments()
         else:
             self._run()
         self.steps += 1
         return self.loss
+
+    def close(self):
+        """Release everything that refers to the process group BEFORE `dist.destroy_process_group()`: the captured hipGraph (its
+        nodes are RCCL kernels of that communicator), the outstanding Work handles of the gradient buckets and the side streams'
+        pending launches.  Callers that own a process group call this, then `torch.cuda.synchronize()`, then destroy the group
+        (train.py:49-53 is the lifecycle the drop-in has to survive: a communicator torn down under a live graph or a polling
+        watchdog was the one ordering fault found in bench.py's and the tests' teardown paths)."""
+        if self.gsync is not None:
+            try:
+                self.gsync.wait()
+            except Exception:
+                del self.gsync.works[:]
+        if self.dev.type == 'cuda':
+            torch.cuda.synchronize()
+        self.graph = None
+        self.use_graph = False
 
     def grads(self):
         return {p: self.g.pgrad.get(p) for p in self.params}

@@ -207,12 +207,25 @@ def segment_roofline(model, x, mode, reps=8):
     for _ in range(2):
         g2.run_parallel(g2.fwd, None)
     whole2 = _events_ms(lambda: g2.run_parallel(g2.fwd, None), reps)
+    # the SAME segment on the list the model really runs (level-ordered, batched, two streams): the cell + ASPP commands of that list,
+    # re-scheduled on their own (their inputs — stem outputs, frozen-BN coefficients, packed weights — are resident from the runs above)
+    segc = [c for c in g2.fwd if c.tag in ('cell', 'aspp')]
+    for c in segc:
+        c.event = None
+    P.schedule(segc, g2.nstreams)
+    for c in segc:
+        c.event = torch.cuda.Event() if c.event else None
+    for _ in range(2):
+        g2.run_parallel(segc, None)
+    seg2 = _events_ms(lambda: g2.run_parallel(segc, None), reps)
     extra = TRAIN_EXTRA_GB if mode == 'train' else dict.fromkeys(ALG_GB, 0.0)
     ms = tot.get('cell', 0.0) + tot.get('aspp', 0.0)
     gb = n * (ALG_GB['cell'] + ALG_GB['aspp'] + extra['cell'] + extra['aspp'])
     gf = n * (GFLOP['cell'] + GFLOP['aspp'])
     out = {'mode': mode, 'aspp_plus_cell_ms': ms, 'alg_GB': gb, 'achieved_GBps': gb / ms * 1e3, 'frac_hbm': gb / ms * 1e3 / PEAK_HBM_GBS,
            'alg_GFLOP': gf, 'achieved_TFLOPs': gf / ms, 'frac_mfma_f32': gf / ms / PEAK_MFMA_F32_TFLOPS,
+           'aspp_plus_cell_ms_two_streams_batched': seg2, 'frac_hbm_two_streams_batched': gb / seg2 * 1e3 / PEAK_HBM_GBS,
+           'segment_launches': sum(i1 - i0 for tag, i0, i1 in runs if tag in ('cell', 'aspp')), 'segment_launches_batched': len(segc),
            'forward_ms_single_stream': whole, 'forward_ms_two_streams_batched': whole2, 'launches': nl, 'launches_batched': len(g2.fwd),
            'segments_ms': {k: round(v, 4) for k, v in tot.items() if k}}
     del g2
@@ -288,6 +301,7 @@ def ddp_path_world1(genotype, a, x, t, dev, steps=10):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
     os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
     dist.init_process_group(backend='nccl', init_method='env://')
+    ts = None
     try:
         comm = parallel.init_sync_bn(force=True)
         m = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=True), 0)
@@ -306,25 +320,16 @@ def ddp_path_world1(genotype, a, x, t, dev, steps=10):
         dt = (time.perf_counter() - t0) / steps
         nall = sum(getattr(c, 'members', 1) for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed'))
         ncmd = sum(1 for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed', 'grad_allreduce'))
-        res_seg = None
-        try:                                          # the N > 1 default: graph segments between eager collectives
-            ts2 = TrainStep(m, tuple(x.shape), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm, use_graph='seg')
-            ts2.load_batch(x, t)
-            for _ in range(3):
-                ts2.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(steps):
-                ts2.step()
-            torch.cuda.synchronize()
-            res_seg = (time.perf_counter() - t1) / steps * 1e3
-        except Exception as e:
-            res_seg = 'failed: %s' % (str(e).splitlines()[0] if str(e) else repr(e))
         return {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'hip_graph': ts.graph is not None,
-                'ms_per_step_graph_segments': res_seg,
                 'collectives_per_step': ncmd, 'exchanged_statistics_vectors': nall,
                 'what': 'world_size 1, exchanges forced: SyncBN statistics all-reduces (one per dependency level) + bucketed gradient all-reduce'}
     finally:
+        # teardown in dependency order: the captured graph holds RCCL kernel nodes of this communicator and the
+        # gradient buckets hold Work handles on it — release those, drain the device, THEN destroy the group
+        if ts is not None:
+            ts.close()
+        ts = None
+        torch.cuda.synchronize()
         parallel.disable_sync_bn()
         dist.destroy_process_group()
 
@@ -387,14 +392,18 @@ def main():
     n, h, w = a.batch, a.height, a.width
     if a.extras_child:
         # the measurements beside the headline number, in a process of their own (see `extras` below): one JSON object on the saved stdout
+        import faulthandler
+        faulthandler.enable(all_threads=True)         # a fatal signal leaves the Python stacks of every thread on stderr, which the parent keeps
         x, t = synthetic_batch(n, h, w, 1 + rank, dev)
         res = {}
 
         def guarded(name, fn):
+            sys.stderr.write('[bench extras] begin %s\n' % name); sys.stderr.flush()     # which extra was running, should the process die
             try:
                 res[name] = fn()
             except Exception as e:
                 res[name] = {'error': str(e).splitlines()[0] if str(e) else repr(e)}
+            sys.stderr.write('[bench extras] end %s\n' % name); sys.stderr.flush()
         with torch.no_grad():
             guarded('segment_eval', lambda: segment_roofline(model, x, 'eval'))
             guarded('segment_train', lambda: segment_roofline(model, x, 'train'))
@@ -456,12 +465,18 @@ def main():
     if (world > 1 or try_cap == 'force') and ts.graph is None and ts.has_coll and not a.no_graph and try_cap != '0':
         import threading
         eager_line = contract_line(dt, False, 'whole-step capture with RCCL collectives did not finish in time: eager launch list')
+        phase = ['capture']
 
         def bail():
+            # a hang is NOT a successful run: the eager measurement is valid and is printed, but the line says so in machine-readable
+            # fields and every rank leaves with a distinct exit code (3) while the stuck capture / replay is still in flight
             if rank == 0:
+                eager_line['capture_hang'] = True
+                eager_line['capture_phase'] = phase[0]
                 json_out.write(json.dumps(eager_line) + '\n')
                 json_out.flush()
-            os._exit(0)
+            sys.stderr.write('[bench] rank %d: capture watchdog fired in phase %r\n' % (rank, phase[0])); sys.stderr.flush()
+            os._exit(3)
         timer = threading.Timer(float(os.environ.get('ADDK_BENCH_CAPTURE_LIMIT', '120')), bail)
         timer.daemon = True
         timer.start()
@@ -469,8 +484,10 @@ def main():
             ts.enable_capture()
             ts.step()
             if ts.graph is not None:
-                for _ in range(2):
+                for i in range(2):
+                    phase[0] = 'replay warm-up step %d' % i
                     ts.step()
+                phase[0] = 'timed replay of %d steps' % a.steps
                 dt2 = timed(a.steps)
                 modes['hip_graph'] = dt2 / a.steps * 1e3
                 if dt2 < dt:
@@ -482,6 +499,8 @@ def main():
         timer.cancel()
     loss = float(ts.loss.item())
     if rank != 0:
+        ts.close()
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
         return
     ms = dt / a.steps * 1e3
@@ -538,8 +557,12 @@ def main():
     extras = world == 1 and not a.no_extras and comm is None and default_cfg
     if extras:
         # Segment roofline, per-exit latency, the drop-in path and the N > 1 code path at world 1 run in a CHILD process: they capture
-        # hipGraphs of their own, start RCCL and replay captured collectives — one run in ~30 of this file ended without its JSON line
-        # while they still ran in-process (no stderr kept: cause unknown), and the headline number must not depend on them
+        # hipGraphs of their own, start RCCL and replay captured collectives — one run in ~30 of round 3's bench ended without its JSON line
+        # while they still ran in-process (no stderr kept).  Round 4 fixed the one ordering fault the teardown paths had (communicator
+        # destroyed under a live captured graph and live Work handles: TrainStep.close); the child stays because a long
+        # side measurement has no business in the process that owns the contract line, and its rc / last marker / stderr tail are now
+        # fields of that line
+        ts.close()
         del ts
         torch.cuda.empty_cache()
         import subprocess
@@ -553,11 +576,20 @@ def main():
                     merged.update(json.loads(line))
                 except ValueError:
                     pass
+            # the child's fate goes INTO the line (negative rc = killed by that signal); its stderr carries the begin/end marker of every
+            # extra and, after a fatal signal, faulthandler's stacks
+            out['extras_rc'] = r.returncode
+            marks = [l for l in r.stderr.splitlines() if l.startswith('[bench extras]')]
+            out['extras_last_marker'] = marks[-1] if marks else None
             if r.returncode != 0:
+                out['extras_stderr_tail'] = r.stderr[-2000:]
                 merged.setdefault('ddp_path_world1', {'error': 'extras child exited with code %d' % r.returncode})
-                sys.stderr.write(r.stderr[-2000:])
-        except subprocess.TimeoutExpired:
+                sys.stderr.write(r.stderr[-6000:])
+        except subprocess.TimeoutExpired as e:
             merged = {'error': 'extras child exceeded 900 s'}
+            out['extras_rc'] = 'timeout'
+            err = e.stderr.decode(errors='replace') if isinstance(e.stderr, bytes) else (e.stderr or '')
+            out['extras_stderr_tail'] = err[-2000:]
         if 'segment_eval' in merged and 'segment_train' in merged and 'error' not in merged['segment_eval'] and 'error' not in merged['segment_train']:
             roof['segment'] = {'name': 'ASPP + cell forward, 1024x2048 bs=2 (BASELINE north_star: >= 0.60 of the HBM roofline)',
                                'eval': merged['segment_eval'], 'train': merged['segment_train'], 'bound': 'hbm', 'peak_GBps': PEAK_HBM_GBS,
@@ -592,6 +624,9 @@ def main():
     json_out.write(json.dumps(out) + '\n')
     json_out.flush()
     if comm is not None:
+        if 'ts' in locals():
+            ts.close()
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
 
 
