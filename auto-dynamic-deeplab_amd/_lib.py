@@ -15,14 +15,15 @@ i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
 
 class Src(C.Structure):
-    _fields_ = [('x', vp), ('a', vp), ('b', vp), ('ld', i32), ('C', i32), ('relu', i32), ('_pad', i32)]
+    _fields_ = [('x', vp), ('a', vp), ('b', vp), ('ld', i32), ('C', i32), ('relu', i32), ('rs_hw', i32)]
 
 
 class ConvArgs(C.Structure):
     _fields_ = [('src', Src * MAX_SRC), ('nsrc', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('Cout', i32), ('ldw', i32),
                 ('cin_total', i32), ('w_choff', i32), ('ldy', i32), ('w', vp), ('y', vp), ('bias', vp), ('bias_n', vp),
-                ('stats', vp), ('stats_ld', i32), ('_pad', i32), ('wpack', vp), ('wpack_floats', i64), ('wpack_ready', i32), ('_pad2', i32)]
+                ('stats', vp), ('stats_ld', i32), ('_pad', i32), ('wpack', vp), ('wpack_floats', i64), ('wpack_ready', i32), ('_pad2', i32),
+                ('rs_y', vp), ('rs_ldy', i32), ('_pad3', i32)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -147,6 +148,7 @@ _SIGS = {
     'addk_conv_fwd_pack_desc': (i32, [C.POINTER(ConvArgs), vp]),
     'addk_conv_dgrad_pack_desc': (i32, [C.POINTER(ConvDgradArgs), vp]),
     'addk_conv_pack_batch': (i32, [vp, i32, vp]),
+    'addk_conv_fwd_resample_ok': (i32, [C.POINTER(ConvArgs)]),
     'addk_conv_wgrad': (i32, [C.POINTER(ConvWgradArgs), vp]),
     'addk_conv_wgrad_ws': (i64, [i64, i32, i32, i32]),
     'addk_conv_wgrad_config': (i32, [C.POINTER(ConvWgradArgs), C.POINTER(i32)]),

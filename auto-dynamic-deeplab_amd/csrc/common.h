@@ -85,6 +85,28 @@ __device__ __forceinline__ float4 prologue4(float4 x, const float* a, const floa
   return x;
 }
 
+// Bilinear source index of F.interpolate(mode='bilinear', align_corners=False) in fp32, as ATen's area_pixel_compute_source_index:
+//     scale = in/out;  src = max(0, scale*(dst+0.5)-0.5);  i0 = floor(src); i1 = min(i0+1, in-1); l1 = src-i0.
+// One definition for the stand-alone resize kernels (resize.hip) and for the 1x1 convolutions that sample their input on the fly
+// (pw.hip, addk_src.rs_hw): the two forms are bit-identical by construction.
+__device__ __forceinline__ void src_index(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+__device__ __forceinline__ float4 lerp4(float4 v00, float4 v01, float4 v10, float4 v11, float lh0, float lh1, float lw0, float lw1) {
+  float4 o;
+  o.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
+  o.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
+  o.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
+  o.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+  return o;
+}
+
 __device__ __forceinline__ float get4(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 __device__ __forceinline__ void set4(float4& v, int e, float f) { if (e == 0) v.x = f; else if (e == 1) v.y = f; else if (e == 2) v.z = f; else v.w = f; }
 

@@ -590,6 +590,8 @@ extern "C" int addk_conv_fwd(const addk_conv_args* a, void* stream) {
     int r = addk_c3_try_fwd(a, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), stream);
     if (r <= 0) return r;
   }
+  for (int i = 0; i < a->nsrc; ++i)
+    ADDK_REQUIRE(a->src[i].rs_hw == 0, "conv_fwd: source %d is a resampled map (rs_hw) but the launch is not one addk_conv_fwd_resample_ok() accepts", i);
   k.nsrc = a->nsrc;
   k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
   k.KH = a->KH; k.KW = a->KW; k.stride = a->stride; k.pad = a->pad; k.dil = a->dil;

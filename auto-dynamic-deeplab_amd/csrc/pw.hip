@@ -33,6 +33,9 @@ struct PwK {
   float* t; int ldt;                   // optional copy of the depthwise output (training: the backward pass reads it)
   const float* ea; const float* eb;    // inference epilogue: y = ea*acc + eb + sum of terms
   int nterm; addk_src term[ADDK_MAX_TERMS];
+  // RS (forward only): src.x is an [N, RH, RW] map sampled bilinearly onto this launch's [N, H, W] pixel grid (addk_src.rs_hw);
+  // rs_y: optional materialised copy of the interpolated input (training: the backward pass reads it)
+  int RH, RW; float* rs_y; int rs_ldy;
 };
 
 // These launches are latency chains (kernel arguments -> weight panel -> one or two pixel tiles -> store -> statistics)
@@ -44,7 +47,11 @@ struct PwK {
 // (pixel li, channels 16g + 4kq + {0..3}) from the SEP*SEP neighbouring pixels, all loads unconditional and independent (L1/L2 hits:
 // neighbouring lanes share them), zero padding after the prologue as in the reference; tap weights sit in LDS as [tap][channel].
 // No barrier in the main loop and no round trip of the depthwise output through HBM (operations.py:51-53: ReLU, dw, pw in one launch).
-template <int CT, int KG, int MODE, bool RED32, int SEP = 0>     // CT column tiles of 16, KG groups of 16 reduction channels
+// RS: the B operand is the bilinear interpolation (align_corners = False) of a map of another size, taken while the fragment is loaded —
+// four 16-byte loads per channel group instead of one (neighbouring lanes share them: L1 / L2 hits), the resize.hip expressions
+// (common.h: src_index, lerp4) in the same order, so the result is bit-identical to addk_resize_fwd followed by the plain launch
+// (ADD.py:76-77,84-90: F.interpolate in front of `preprocess` / `pre_preprocess`; the resized tensor is never written at inference).
+template <int CT, int KG, int MODE, bool RED32, int SEP = 0, bool RS = false>     // CT column tiles of 16, KG groups of 16 reduction channels
 __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2], const float* dwl = nullptr, float* patch = nullptr, const float* abl = nullptr) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -99,8 +106,31 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
 
   const int wstride = p.gx * 4;
   float4 xf[KG];
+  const float rs_sh = RS ? (float)p.RH / (float)p.H : 0.f, rs_sw = RS ? (float)p.RW / (float)p.W : 0.f;
   auto load_tile = [&](int tile, float4 (&x)[KG]) {
     const int pp = tile * 16 + li;
+    if (RS) {
+      const int hw = p.H * p.W, pc = pp < p.P ? pp : 0;
+      const int n = pc / hw, rem = pc - n * hw, oh = rem / p.W, ow = rem - oh * p.W;
+      int h0, h1, w0, w1; float lh0, lh1, lw0, lw1;
+      src_index(oh, rs_sh, p.RH, h0, h1, lh0, lh1);
+      src_index(ow, rs_sw, p.RW, w0, w1, lw0, lw1);
+      const float* b = p.src.x + (long)n * p.RH * p.RW * p.src.ld;
+      const long o00 = ((long)h0 * p.RW + w0) * p.src.ld, o01 = ((long)h0 * p.RW + w1) * p.src.ld;
+      const long o10 = ((long)h1 * p.RW + w0) * p.src.ld, o11 = ((long)h1 * p.RW + w1) * p.src.ld;
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const int k = 16 * g + 4 * kq;
+        const bool ok = pp < p.P && k < p.K;
+        const float* bk = ok ? b + k : p.src.x;
+        const float4 v00 = ld4(bk + (ok ? o00 : 0)), v01 = ld4(bk + (ok ? o01 : 0)), v10 = ld4(bk + (ok ? o10 : 0)), v11 = ld4(bk + (ok ? o11 : 0));
+        float4 v = lerp4(v00, v01, v10, v11, lh0, lh1, lw0, lw1);
+        if (p.rs_y && ok && blockIdx.y == 0) st4(p.rs_y + (long)pp * p.rs_ldy + k, v);
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        x[g] = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const int k = 16 * g + 4 * kq;
@@ -287,18 +317,18 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
   }
 }
 
-template <int CT, int KG, int MODE, bool RED32>
-__global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_kernel(const PwK p) {
+template <int CT, int KG, int MODE, bool RED32, bool RS = false>
+__global__ void __launch_bounds__(256, (KG <= 3 && !RS ? 4 : 3)) pw_kernel(const PwK p) {
   __shared__ double red[4][CT * 16][2];
-  pw_body<CT, KG, MODE, RED32>(p, red);
+  pw_body<CT, KG, MODE, RED32, 0, RS>(p, red);
 }
 // several independent pointwise convs of one dependency level in ONE launch: block (x, y, z) runs descriptor z
-template <int CT, int KG, int MODE, bool RED32>
-__global__ void __launch_bounds__(256, (KG <= 3 ? 4 : 3)) pw_batch_kernel(const PwK* __restrict__ tab) {
+template <int CT, int KG, int MODE, bool RED32, bool RS = false>
+__global__ void __launch_bounds__(256, (KG <= 3 && !RS ? 4 : 3)) pw_batch_kernel(const PwK* __restrict__ tab) {
   __shared__ double red[4][CT * 16][2];
   const PwK p = tab[blockIdx.z];
   if ((int)blockIdx.x >= p.gx || (int)blockIdx.y >= p.gy) return;
-  pw_body<CT, KG, MODE, RED32>(p, red);
+  pw_body<CT, KG, MODE, RED32, 0, RS>(p, red);
 }
 
 // Streaming-K pointwise forward for the 1x1 convs the register-stationary kernel does not take: many input channels
@@ -313,10 +343,11 @@ struct PwkK {
   float* y; int ldy; const float* bias;
   double* slab; int slab_ld;
   int P, ntiles16, rows, gx;
+  int H, W; float* rs_y; int rs_ldy;       // RS: this launch's pixel grid; sources with rs_hw != 0 are sampled onto it (pw_body's RS form)
 };
 
-template <int CT, bool RED32>
-__global__ void __launch_bounds__(256, 3) pwk_kernel(const PwkK p) {
+template <int CT, bool RED32, bool RS = false>
+__global__ void __launch_bounds__(256, RS ? 2 : 3) pwk_kernel(const PwkK p) {
   __shared__ double red[4][CT * 16][2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.y * (CT * 16);
@@ -341,13 +372,31 @@ __global__ void __launch_bounds__(256, 3) pwk_kernel(const PwkK p) {
 #pragma unroll
     for (int i = 0; i < CT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one group = 16 input channels of one source: x quad, prologue coefficients, CT weight quads
-    struct Grp { float4 x, a, b, w[CT]; bool ok, pro, relu; };
+    struct Grp { float4 x, x01, x10, x11, a, b, w[CT]; float lh0, lh1, lw0, lw1; bool ok, pro, relu, rs, copy; int k; };
     int s = 0, g = 0, choff = 0;
+    int rn = 0, roh = 0, row = 0;
+    if (RS) {
+      const int hw = p.H * p.W, pc = pok ? pp : 0;
+      rn = pc / hw; const int rem = pc - rn * hw; roh = rem / p.W; row = rem - roh * p.W;
+    }
     auto load = [&](Grp& G, int s_, int g_, int choff_) {
       const addk_src S = p.src[s_];
       const int k = 16 * g_ + 4 * kq;
       const bool kok = k < S.C;
       G.ok = kok && pok; G.pro = S.a != nullptr; G.relu = S.relu != 0;
+      G.rs = RS && S.rs_hw != 0;
+      if (G.rs) {             // wave-uniform: the four taps of the interpolation, combined in compute() (the loads stay in flight)
+        const int RH = S.rs_hw >> 16, RW = S.rs_hw & 0xffff;
+        int h0, h1, w0, w1;
+        src_index(roh, (float)RH / (float)p.H, RH, h0, h1, G.lh0, G.lh1);
+        src_index(row, (float)RW / (float)p.W, RW, w0, w1, G.lw0, G.lw1);
+        const float* b = S.x + (G.ok ? (long)rn * RH * RW * S.ld + k : 0);
+        G.x = ld4(b + (G.ok ? ((long)h0 * RW + w0) * S.ld : 0));
+        G.x01 = ld4(b + (G.ok ? ((long)h0 * RW + w1) * S.ld : 0));
+        G.x10 = ld4(b + (G.ok ? ((long)h1 * RW + w0) * S.ld : 0));
+        G.x11 = ld4(b + (G.ok ? ((long)h1 * RW + w1) * S.ld : 0));
+        G.copy = s_ == 0 && p.rs_y != nullptr && blockIdx.y == 0; G.k = k;
+      } else
       G.x = ld4(S.x + (G.ok ? (long)pp * S.ld + k : 0));
       G.a = make_float4(1.f, 1.f, 1.f, 1.f); G.b = zero4();
       if (S.a) { G.a = ld4(S.a + (kok ? k : 0)); G.b = ld4(S.b + (kok ? k : 0)); }
@@ -360,6 +409,10 @@ __global__ void __launch_bounds__(256, 3) pwk_kernel(const PwkK p) {
     };
     auto compute = [&](const Grp& G) {
       float4 v = G.x;
+      if (RS && G.rs) {
+        v = lerp4(G.x, G.x01, G.x10, G.x11, G.lh0, G.lh1, G.lw0, G.lw1);
+        if (G.copy && G.ok) st4(p.rs_y + (long)pp * p.rs_ldy + G.k, v);
+      }
       v.x = fmaf(G.a.x, v.x, G.b.x); v.y = fmaf(G.a.y, v.y, G.b.y); v.z = fmaf(G.a.z, v.z, G.b.z); v.w = fmaf(G.a.w, v.w, G.b.w);
       if (G.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       v.x = G.ok ? v.x : 0.f; v.y = G.ok ? v.y : 0.f; v.z = G.ok ? v.z : 0.f; v.w = G.ok ? v.w : 0.f;
@@ -428,8 +481,9 @@ __global__ void __launch_bounds__(256, 3) pwk_kernel(const PwkK p) {
   }
 }
 
-struct PwCfg { int ct, kg, red32, gx, gy; };
+struct PwCfg { int ct, kg, red32, gx, gy, rs; };
 static bool pw_config(PwK& k, int rows, PwCfg& c) {
+  c.rs = k.RH != 0;
   c.kg = cdiv(k.K, 16);
   if (!(c.kg == 3 || c.kg == 5)) return false;
   c.ct = c.kg == 5 ? 2 : 3;
@@ -452,7 +506,10 @@ int pw_launch(PwK& k, int rows, hipStream_t st) {
   dim3 grid(c.gx, c.gy);          // measured: fewer, fatter workgroups are slower (14 -> 36 us); parallelism wins
 #define ADDK_PW(CT_, KG_) \
   if (c.ct == CT_ && c.kg == KG_) { \
-    if (c.red32) hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, k); \
+    if (MODE == PW_FWD && c.rs) { \
+      if (c.red32) hipLaunchKernelGGL((pw_kernel<CT_, KG_, PW_FWD, true, true>), grid, dim3(256), 0, st, k); \
+      else hipLaunchKernelGGL((pw_kernel<CT_, KG_, PW_FWD, false, true>), grid, dim3(256), 0, st, k); \
+    } else if (c.red32) hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, k); \
     else hipLaunchKernelGGL((pw_kernel<CT_, KG_, MODE, false>), grid, dim3(256), 0, st, k); \
     return addk_check_launch("pw_conv"); }
   ADDK_PW(1, 3) ADDK_PW(2, 3) ADDK_PW(3, 3)
@@ -462,11 +519,14 @@ int pw_launch(PwK& k, int rows, hipStream_t st) {
 }
 
 template <int MODE>
-int pw_batch_launch(const PwK* tab, int n, int ct, int kg, int red32, int gx, int gy, hipStream_t st) {
+int pw_batch_launch(const PwK* tab, int n, int ct, int kg, int red32, int rs, int gx, int gy, hipStream_t st) {
   dim3 grid(gx, gy, n);
 #define ADDK_PW(CT_, KG_) \
   if (ct == CT_ && kg == KG_) { \
-    if (red32) hipLaunchKernelGGL((pw_batch_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, tab); \
+    if (MODE == PW_FWD && rs) { \
+      if (red32) hipLaunchKernelGGL((pw_batch_kernel<CT_, KG_, PW_FWD, true, true>), grid, dim3(256), 0, st, tab); \
+      else hipLaunchKernelGGL((pw_batch_kernel<CT_, KG_, PW_FWD, false, true>), grid, dim3(256), 0, st, tab); \
+    } else if (red32) hipLaunchKernelGGL((pw_batch_kernel<CT_, KG_, MODE, true>), grid, dim3(256), 0, st, tab); \
     else hipLaunchKernelGGL((pw_batch_kernel<CT_, KG_, MODE, false>), grid, dim3(256), 0, st, tab); \
     return addk_check_launch("pw_conv_batch"); }
   ADDK_PW(1, 3) ADDK_PW(2, 3) ADDK_PW(3, 3)
@@ -487,6 +547,13 @@ bool pw_fill_fwd(const addk_conv_args* a, PwK& k) {
   k.y = a->y; k.ldy = a->ldy; k.bias = a->bias;
   k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
   k.P = a->N * a->OH * a->OW; k.ntiles16 = cdiv(k.P, 16);
+  k.H = a->OH; k.W = a->OW;
+  if (s.rs_hw) {                      // the input is sampled from an [N, RH, RW] map (addk_src.rs_hw)
+    k.RH = s.rs_hw >> 16; k.RW = s.rs_hw & 0xffff;
+    if (k.RH < 1 || k.RW < 1) return false;
+    k.rs_y = a->rs_y; k.rs_ldy = a->rs_ldy;
+    if (k.rs_y && (!aligned16(k.rs_y) || k.rs_ldy % 4 || k.rs_ldy < s.C)) return false;
+  }
   return true;
 }
 bool pw_fill_dgrad(const addk_conv_dgrad_args* a, PwK& k) {
@@ -501,7 +568,7 @@ bool pw_fill_dgrad(const addk_conv_dgrad_args* a, PwK& k) {
   k.P = a->N * a->H * a->W; k.ntiles16 = cdiv(k.P, 16);
   return true;
 }
-inline int pw_key(const PwCfg& c, int mode) { return (mode << 12) | (c.ct << 8) | (c.kg << 4) | c.red32; }
+inline int pw_key(const PwCfg& c, int mode) { return (mode << 12) | (c.ct << 8) | (c.kg << 4) | (c.rs << 1) | c.red32; }
 
 
 // stem0 (ADD.py:153-157): 3x3 stride-2 convolution of the 3-channel image into 64 channels.  On the generic implicit-GEMM
@@ -591,27 +658,42 @@ __global__ void __launch_bounds__(256) stem0_kernel(const StemK p) {
 }  // namespace
 
 // Returns 0 when the launch was taken, 1 when the shape is not covered (caller falls back), <0 on error.
-static int pwk_try_fwd(const addk_conv_args* a, int rows, hipStream_t st) {
-  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->bias_n || a->H != a->OH || a->W != a->OW) return 1;
-  if (!aligned16(a->y) || a->ldy % 4 || a->Cout % 4 || !aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return 1;
+static bool pwk_covers(const addk_conv_args* a, bool& rs) {
+  rs = false;
+  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->bias_n || a->H != a->OH || a->W != a->OW) return false;
+  if (!aligned16(a->y) || a->ldy % 4 || a->Cout % 4 || !aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return false;
   int ktot = 0;
-  for (int i = 0; i < a->nsrc; ++i) { if (!src_vec_ok(a->src[i])) return 1; ktot += a->src[i].C; }
+  for (int i = 0; i < a->nsrc; ++i) {
+    if (!src_vec_ok(a->src[i])) return false;
+    ktot += a->src[i].C;
+    if (a->src[i].rs_hw) { rs = true; if ((a->src[i].rs_hw >> 16) < 1 || (a->src[i].rs_hw & 0xffff) < 1) return false; }
+  }
+  if (a->rs_y && (!a->src[0].rs_hw || !aligned16(a->rs_y) || a->rs_ldy % 4 || a->rs_ldy < a->src[0].C)) return false;
   // narrow outputs only: with 256 output channels (ASPP 1x1 1280->256) every wave would stream the whole 1.3 MB weight panel
   // and the LDS-staged kernel's operand reuse wins (63 vs 42 TF/s)
-  if (ktot < 64 || a->Cout > 160 || (long)a->N * a->OH * a->OW < 1024) return 1;
+  if (ktot < 64 || a->Cout > 160 || (long)a->N * a->OH * a->OW < 1024) return false;
+  return true;
+}
+static int pwk_try_fwd(const addk_conv_args* a, int rows, hipStream_t st) {
+  bool rs;
+  if (!pwk_covers(a, rs)) return 1;
   PwkK k{};
   for (int i = 0; i < a->nsrc; ++i) k.src[i] = a->src[i];
   k.nsrc = a->nsrc; k.Cn = a->Cout; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
   k.y = a->y; k.ldy = a->ldy; k.bias = a->bias;
   k.slab = (double*)a->stats; k.slab_ld = a->stats_ld > 0 ? a->stats_ld : a->Cout;
   k.P = a->N * a->OH * a->OW; k.ntiles16 = cdiv(k.P, 16); k.rows = rows;
+  k.H = a->OH; k.W = a->OW; k.rs_y = a->rs_y; k.rs_ldy = a->rs_ldy;
   int ct = cdiv(a->Cout, 16); if (ct > 3) ct = 3;
   k.gx = rows; if (k.gx > cdiv(k.ntiles16, 4)) k.gx = cdiv(k.ntiles16, 4); if (k.gx < 1) k.gx = 1;
   dim3 grid(k.gx, cdiv(a->Cout, 16 * ct));
   const bool red32 = k.P >= 4096;
 #define ADDK_PWK(CT_) \
   if (ct == CT_) { \
-    if (red32) hipLaunchKernelGGL((pwk_kernel<CT_, true>), grid, dim3(256), 0, st, k); \
+    if (rs) { \
+      if (red32) hipLaunchKernelGGL((pwk_kernel<CT_, true, true>), grid, dim3(256), 0, st, k); \
+      else hipLaunchKernelGGL((pwk_kernel<CT_, false, true>), grid, dim3(256), 0, st, k); \
+    } else if (red32) hipLaunchKernelGGL((pwk_kernel<CT_, true>), grid, dim3(256), 0, st, k); \
     else hipLaunchKernelGGL((pwk_kernel<CT_, false>), grid, dim3(256), 0, st, k); \
     return addk_check_launch("pwk_conv"); }
   ADDK_PWK(1) ADDK_PWK(2) ADDK_PWK(3)
@@ -646,6 +728,16 @@ int addk_pw_try_fwd(const addk_conv_args* a, int rows, void* stream) {
     if (r <= 0) return r;
   }
   return pwk_try_fwd(a, rows, (hipStream_t)stream);       // many input channels / several sources: streaming-K kernel
+}
+extern "C" int addk_conv_fwd_resample_ok(const addk_conv_args* a) {
+  if (!a || a->nsrc < 1 || a->nsrc > ADDK_MAX_SRC || !(addk_get_fast_paths() & ADDK_FAST_PW)) return 0;
+  bool any = false;
+  for (int i = 0; i < a->nsrc; ++i) any = any || a->src[i].rs_hw != 0;
+  if (!any || a->wpack) return 0;
+  PwK k; PwCfg c;
+  if (pw_fill_fwd(a, k) && pw_config(k, addk_conv_rows((long)a->N * a->OH * a->OW, a->Cout), c)) return 1;
+  bool rs;
+  return pwk_covers(a, rs) ? 1 : 0;
 }
 int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
   PwK k;
@@ -697,8 +789,8 @@ extern "C" int64_t addk_conv_dgrad_batch_prepare(const addk_conv_dgrad_args* a, 
 }
 extern "C" int addk_conv_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
   ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0 && meta[3] > 0, "conv_batch_run: bad args");
-  const int key = (int)meta[0], mode = key >> 12, ct = (key >> 8) & 15, kg = (key >> 4) & 15, red32 = key & 1;
+  const int key = (int)meta[0], mode = key >> 12, ct = (key >> 8) & 15, kg = (key >> 4) & 15, red32 = key & 1, rs = (key >> 1) & 1;
   const PwK* tab = reinterpret_cast<const PwK*>(dev_blob);
-  if (mode == PW_FWD) return pw_batch_launch<PW_FWD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
-  return pw_batch_launch<PW_DGRAD>(tab, (int)meta[1], ct, kg, red32, (int)meta[2], (int)meta[3], (hipStream_t)stream);
+  if (mode == PW_FWD) return pw_batch_launch<PW_FWD>(tab, (int)meta[1], ct, kg, red32, rs, (int)meta[2], (int)meta[3], (hipStream_t)stream);
+  return pw_batch_launch<PW_DGRAD>(tab, (int)meta[1], ct, kg, red32, 0, (int)meta[2], (int)meta[3], (hipStream_t)stream);
 }

@@ -9,16 +9,6 @@
 
 namespace {
 
-__device__ __forceinline__ void src_index(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
-  float s = scale * ((float)dst + 0.5f) - 0.5f;
-  if (s < 0.f) s = 0.f;
-  i0 = (int)s;
-  if (i0 > in - 1) i0 = in - 1;
-  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
-  l1 = s - (float)i0;
-  l0 = 1.f - l1;
-}
-
 // candidate output range [lo, hi] whose taps may touch input index i
 __device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, int& hi) {
   float inv = 1.f / scale;
@@ -62,11 +52,7 @@ __global__ void __launch_bounds__(256) resize_fwd_kernel(const RsK p) {
     float4 v01 = prologue4(ld4g(b + ((long)h0 * p.W + w1) * p.src.ld, nrem, p.vec), p.src.a, p.src.b, c, nrem, relu, p.vec);
     float4 v10 = prologue4(ld4g(b + ((long)h1 * p.W + w0) * p.src.ld, nrem, p.vec), p.src.a, p.src.b, c, nrem, relu, p.vec);
     float4 v11 = prologue4(ld4g(b + ((long)h1 * p.W + w1) * p.src.ld, nrem, p.vec), p.src.a, p.src.b, c, nrem, relu, p.vec);
-    float4 o;
-    o.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
-    o.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
-    o.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
-    o.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+    const float4 o = lerp4(v00, v01, v10, v11, lh0, lh1, lw0, lw1);
     st4g(p.y + pp * p.ldy + c, o, nrem, p.vec);
   }
 }

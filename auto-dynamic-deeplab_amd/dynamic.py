@@ -37,7 +37,7 @@ class DynamicPlan:
             if i in model.C_index or i == model.num_net - 1:
                 if i != model.num_net - 1:
                     conf = g.output_nchw(edm.emit(g, y))              # EDM applies ReLU to y in place (Q3) ...
-                    y = Act(y.raw, y.bn, True, False)                 # ... so everything downstream sees relu(y)
+                    y = Act(y.raw, y.bn, True, False, rs=y.rs)              # ... so everything downstream sees relu(y)
                     send = y
                     self.trunk_end.append(len(g.fwd))
                     self.conf.append(conf)

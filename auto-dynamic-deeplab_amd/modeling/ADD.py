@@ -135,7 +135,7 @@ def _emit_stems(mod, g, x):
     s = g.conv_bn([x], mod.stem0[0], mod.stem0[1], relu_in=False, post_relu=True)
     s0 = g.conv_bn([s], mod.stem1[0], mod.stem1[1], relu_in=False)
     s1 = g.conv_bn([s0], mod.stem2[1], mod.stem2[2], relu_in=True)
-    return Act(s0.raw, s0.bn, True, s0.needs_grad), s1
+    return Act(s0.raw, s0.bn, True, s0.needs_grad, rs=s0.rs), s1
 
 
 def _make_heads(mod, network_arch, C_index, F, B, num_classes, BatchNorm, low_level_layer):

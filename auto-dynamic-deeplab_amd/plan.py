@@ -112,16 +112,27 @@ class BNState:
 
 
 class Act:
-    """Lazy activation: value = relu?(a*raw+b)."""
-    __slots__ = ('raw', 'bn', 'relu', 'needs_grad', 'zero')
+    """Lazy activation: value = relu?(a*raw+b).  `rs` (a Resample, shared by every Act derived from one Graph.resize call): `raw` is
+    the bilinear interpolation of another map and has NOT been written yet — a 1x1 convolution that consumes it samples the source
+    map itself (addk_src.rs_hw); any other consumer makes Graph.src / Graph.lz emit the stand-alone resize launch first."""
+    __slots__ = ('raw', 'bn', 'relu', 'needs_grad', 'zero', 'rs')
 
-    def __init__(self, raw, bn=None, relu=False, needs_grad=False, zero=False):
-        self.raw, self.bn, self.relu, self.needs_grad, self.zero = raw, bn, relu, needs_grad, zero
+    def __init__(self, raw, bn=None, relu=False, needs_grad=False, zero=False, rs=None):
+        self.raw, self.bn, self.relu, self.needs_grad, self.zero, self.rs = raw, bn, relu, needs_grad, zero, rs
 
     N = property(lambda s: s.raw.N)
     H = property(lambda s: s.raw.H)
     W = property(lambda s: s.raw.W)
     C = property(lambda s: s.raw.C)
+
+
+class Resample:
+    """Deferred bilinear resize (Graph.resize): `src` is the TRef of the map to sample, `emit()` appends the stand-alone launch that
+    writes the resized tensor, `done` says that some launch writes it (that launch, or a folding consumer's copy-out in training)."""
+    __slots__ = ('src', 'emit', 'done')
+
+    def __init__(self, src, emit):
+        self.src, self.emit, self.done = src, emit, False
 
 
 class Cmd:
@@ -636,18 +647,34 @@ class Graph:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.nstreams - 1)]
         return self._streams
 
-    def src(self, act, relu_in=False):
+    def _pending(self, act):
+        return act.rs is not None and not act.rs.done
+
+    def src(self, act, relu_in=False, fold=False):
+        """Source descriptor of a lazy activation.  fold=True (a consumer that samples a deferred resize itself): the descriptor
+        points at the map to interpolate; otherwise a still-deferred resize is emitted as its own launch now."""
         s = L.Src()
-        s.x = act.raw.ptr
+        if fold and self._pending(act):
+            r = act.rs.src
+            s.x, s.ld, s.rs_hw = r.ptr, r.ld, (r.H << 16) | r.W
+        else:
+            if self._pending(act):
+                act.rs.emit()
+            s.x, s.ld = act.raw.ptr, act.raw.ld
         if act.bn is not None:
             s.a, s.b = act.bn.a.ptr, act.bn.b.ptr
-        s.ld, s.C, s.relu = act.raw.ld, act.raw.C, int(bool(act.relu or relu_in))
+        s.C, s.relu = act.raw.C, int(bool(act.relu or relu_in))
         return s
 
-    @staticmethod
-    def lz(act):
+    def lz(self, act, fold=False):
         """Memory regions a consumer of lazy activation `act` reads."""
-        return [act.raw] + ([act.bn.a, act.bn.b] if act.bn is not None else [])
+        if fold and self._pending(act):
+            first = act.rs.src
+        else:
+            if self._pending(act):
+                act.rs.emit()
+            first = act.raw
+        return [first] + ([act.bn.a, act.bn.b] if act.bn is not None else [])
 
     def _dab(self, act, rows):
         """Allocate a (dA,dB) partial slab for a lazy source whose BN is in training mode."""
@@ -679,9 +706,11 @@ class Graph:
         assert weight.numel() == Cout * ldw, 'weight %s does not match Cout=%d k=%d cin=%d' % (tuple(weight.shape), Cout, k, cin_total)
         if fwd:
             ar = L.ConvArgs()
-            for i, s in enumerate(srcs):
-                assert (s.N, s.H, s.W) == (N, H, W), 'virtual concat needs equal spatial size'
-                ar.src[i] = self.src(s, relu_in)
+            # a deferred bilinear resize in front of a 1x1 convolution (ADD.py:76-77,84-90) is sampled by the convolution itself where
+            # the pointwise kernels cover the shape (addk_conv_fwd_resample_ok): no resize launch, no resized tensor at inference; in
+            # training the launch also writes the resized tensor, which the backward pass reads (ADDK_FOLD_RESIZE=0: never)
+            fold = (k == 1 and stride == 1 and pad == 0 and out_hw is None and any(self._pending(s) for s in srcs)
+                    and os.environ.get('ADDK_FOLD_RESIZE', '1') == '1')
             ar.nsrc = len(srcs)
             ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
             ar.KH = ar.KW = k
@@ -692,15 +721,36 @@ class Graph:
             ar.bias_n = bias_n.ptr if bias_n is not None else None
             ar.stats = stats.ptr if stats is not None else None
             ar.stats_ld = stats_ld
+            rs_out = None
+            if fold:
+                for i, s in enumerate(srcs):
+                    assert (s.N, s.H, s.W) == (N, H, W), 'virtual concat needs equal spatial size'
+                    ar.src[i] = self.src(s, relu_in, fold=True)
+                if self.want_grad:                    # one copy-out slot: only src[0] may be a sampled map when a backward pass follows
+                    if any(self._pending(s) for s in srcs[1:]):
+                        fold = False
+                    elif self._pending(srcs[0]):
+                        ar.rs_y, ar.rs_ldy = srcs[0].raw.ptr, srcs[0].raw.ld
+                fold = fold and int(lib.addk_conv_fwd_resample_ok(C.byref(ar))) == 1
+                if not fold:
+                    ar.rs_y, ar.rs_ldy = None, 0
+            if not fold:
+                for i, s in enumerate(srcs):
+                    assert (s.N, s.H, s.W) == (N, H, W), 'virtual concat needs equal spatial size'
+                    ar.src[i] = self.src(s, relu_in)  # (a still-deferred resize is emitted as its own launch here)
+            rd_src = [r for s_ in srcs for r in self.lz(s_, fold=fold)]
+            if fold and self.want_grad and self._pending(srcs[0]):
+                rs_out = srcs[0].raw
+                srcs[0].rs.done = True                # this launch writes the resized tensor
             wpk = None
-            npk = int(lib.addk_conv_fwd_pack_floats(C.byref(ar)))       # > 0: wide 3x3 stride-1 conv, halo-patch kernel (conv3.hip)
+            npk = 0 if fold else int(lib.addk_conv_fwd_pack_floats(C.byref(ar)))       # > 0: wide 3x3 stride-1 conv, halo-patch kernel (conv3.hip)
             if npk > 0:
                 wpk = self.buf(npk)
                 ar.wpack, ar.wpack_floats = wpk.ptr, npk
                 self._hoist_pack(lib.addk_conv_fwd_pack_desc, ar, weight, wpk, create=True)
             self.keep.append(ar)
             cf = self._add(self.fwd, 'conv_fwd', lib.addk_conv_fwd, C.byref(ar),
-                           rd=[r for s_ in srcs for r in self.lz(s_)] + [weight, bias, bias_n], wr=[out, stats, wpk])
+                           rd=rd_src + [weight, bias, bias_n], wr=[out, stats, wpk, rs_out])
             bk = int(lib.addk_conv_fwd_batch_key(C.byref(ar)))
             if bk >= 0:
                 cf.payload, cf.bkey = ar, bk
@@ -1192,7 +1242,7 @@ class Graph:
     def materialize(self, act, relu_in=False):
         if act.bn is None and not (act.relu or relu_in):
             return act
-        a = Act(act.raw, act.bn, act.relu or relu_in, act.needs_grad)
+        a = Act(act.raw, act.bn, act.relu or relu_in, act.needs_grad, rs=act.rs)
         return self.affine_sum([a])
 
     def resize(self, src, OH, OW, relu_in=False):
@@ -1203,13 +1253,24 @@ class Graph:
         N, H, W, Cc = src.N, src.H, src.W, src.C
         out = self.tensor(N, OH, OW, Cc)
         ar = L.ResizeArgs()
-        carrier = src if relu else Act(src.raw, None, False, src.needs_grad)
+        carrier = src if relu else Act(src.raw, None, False, src.needs_grad, rs=src.rs)
         ar.src = self.src(carrier, relu_in)
         ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, OH, OW
         ar.y, ar.ldy, ar.nchw_out = out.ptr, out.ld, 0
         self.keep.append(ar)
-        self._add(self.fwd, 'resize_fwd', lib.addk_resize_fwd, C.byref(ar), rd=self.lz(src), wr=[out])
-        res = Act(out, None if relu else src.bn, False, src.needs_grad)
+        tag = self.tag
+
+        def emit_fwd():
+            c = self._add(self.fwd, 'resize_fwd', lib.addk_resize_fwd, C.byref(ar), rd=self.lz(carrier), wr=[out])
+            c.tag = tag
+            if rs is not None:
+                rs.done = True
+        rs = None
+        if relu or self._pending(src) or src.raw.H >= (1 << 15) or src.raw.W >= (1 << 16):
+            emit_fwd()                    # the interpolated values are relu(a x + b): not an affine of the interpolated raw map
+        else:
+            rs = Resample(src.raw, emit_fwd)      # deferred: a 1x1 consumer samples src.raw itself (Graph.conv), anyone else emits it
+        res = Act(out, None if relu else src.bn, False, src.needs_grad, rs=rs)
         if self.want_grad and src.needs_grad:
             def emit_bwd():
                 if not self.grad_ready(out):

@@ -51,7 +51,11 @@ typedef struct addk_src {
   int32_t ld;       /* pixel stride (floats) */
   int32_t C;        /* channels of this source */
   int32_t relu;     /* ReLU after the affine */
-  int32_t _pad;
+  int32_t rs_hw;    /* 0: plain source.  (SH << 16) | SW: `x` is an [N, SH, SW] map that the consumer samples bilinearly
+                       (F.interpolate(mode='bilinear'), align_corners=False: ADD.py:76-77,84-90) onto ITS OWN input grid while it
+                       stages the tile — the resize in front of a 1x1 convolution never materialises.  The lazy affine / ReLU apply
+                       AFTER the interpolation (an affine commutes with it; the ReLU is the consumer's own, operations.py:23).  Only
+                       addk_conv_fwd honours it, and only for the shapes addk_conv_fwd_resample_ok() accepts. */
 } addk_src;
 
 /* BatchNorm statistics -> lazy affine (F.batch_norm training mode, batchnorm.py:51-53): argument block of addk_bn_finalize, also
@@ -104,8 +108,17 @@ typedef struct addk_conv_args {
   int32_t wpack_ready;        /* 1: wpack already holds this launch's packed weights (addk_conv_pack_batch ran since the
                                  last weight update); 0: the launch packs them itself */
   int32_t _pad2;
+  float* rs_y;                /* src[0].rs_hw != 0 only: optional materialised copy of the interpolated src[0] (before the affine /
+                                 ReLU), pixel stride rs_ldy — training writes it because the backward pass (weight gradient, ReLU
+                                 mask, the resize's own gather backward) reads it; NULL at inference */
+  int32_t rs_ldy;
+  int32_t _pad3;
 } addk_conv_args;
 int addk_conv_fwd(const addk_conv_args* a, void* stream);
+/* 1 when addk_conv_fwd takes this launch with src[i].rs_hw set (a 1x1 stride-1 convolution on the register-stationary or the
+ * streaming-K pointwise kernel, pw.hip: ADD.py:84-90 `pre_preprocess` / `preprocess` behind F.interpolate), else 0: the caller
+ * then runs addk_resize_fwd first.  Results are bit-identical either way (the same fp32 expressions in the same order). */
+int addk_conv_fwd_resample_ok(const addk_conv_args* a);
 /* floats of `wpack` this launch can use; 0 = the halo-patch kernel does not cover the shape */
 int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a);
 /* Arithmetic of the wide k x k stride-1 contractions (the halo-patch kernels, forward and data gradient):

@@ -1,0 +1,181 @@
+"""GPU tests of the round-4 kernels, all through the C ABI.
+
+* the 1x1 convolutions that sample a bilinear resize themselves (addk_src.rs_hw, pw.hip RS forms; reference ADD.py:76-77,84-90:
+  F.interpolate in front of `preprocess` / `pre_preprocess`): BIT-identical to addk_resize_fwd followed by the plain launch, and both
+  against an fp64 F.interpolate + conv2d; the training copy-out equals the stand-alone resize's output bit for bit;
+* whole cells / the whole network with the fold on and off give identical outputs and gradients."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def L():
+    assert torch.cuda.is_available()
+    import addk  # noqa: F401
+    from addk import _lib as L
+    L.load()
+    return L
+
+
+@pytest.fixture()
+def dev():
+    return torch.device('cuda:0')
+
+
+# name, N, (source H, W), (consumer H, W), K, Cout, lazy BN on the source, extra padded channels (ld > C), batched
+RS_SHAPES = [
+    ('up2_odd_k80', 2, (32, 64), (63, 127), 80, 80, True, 0),        # pw_kernel KG = 5 (dense features of level 2 into an even-size-drifted map)
+    ('up2_k40', 1, (63, 127), (125, 253), 40, 40, True, 0),          # pw_kernel KG = 3, CT = 3
+    ('down2_k40', 2, (125, 253), (63, 127), 40, 80, False, 0),       # down-sampling (ADD.py:84: fit() runs both ways)
+    ('down4_k128', 1, (128, 256), (32, 64), 128, 80, True, 0),       # pwk_kernel: cell 1's prev_prev (stem2 output), 4x down
+    ('up_k800', 1, (16, 32), (31, 63), 800, 160, True, 0),           # pwk_kernel, K = 800 (level-3 concat into level 2)
+    ('same_w_k200', 2, (33, 64), (65, 64), 200, 40, True, 0),        # only H differs (fit() compares H alone)
+    ('ld_pad_k80', 1, (20, 40), (39, 79), 80, 40, True, 8),          # source is a channel slice of a wider buffer
+    ('tiny_tail_k48', 1, (9, 17), (33, 65), 48, 48, True, 0),        # P = 2145: not a multiple of 16
+]
+
+
+def _mk_src(L, x, a, b, C_, ld, relu, rs_hw=0):
+    s = L.Src()
+    s.x, s.ld, s.C, s.relu, s.rs_hw = x.data_ptr(), ld, C_, int(relu), rs_hw
+    if a is not None:
+        s.a, s.b = a.data_ptr(), b.data_ptr()
+    return s
+
+
+@pytest.mark.parametrize('shape', RS_SHAPES, ids=[s[0] for s in RS_SHAPES])
+def test_conv1x1_samples_resize_itself_bit_identical(L, dev, shape):
+    lib = L.load()
+    name, N, (SH, SW), (H, W), K, Cout, lazy, padc = shape
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    ld = K + padc
+    xs = torch.randn(N, SH, SW, ld, generator=g).to(dev)
+    a = (torch.rand(K, generator=g) + 0.5).to(dev) if lazy else None
+    b = (torch.randn(K, generator=g) * 0.3).to(dev) if lazy else None
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(dev)
+    P = N * H * W
+    rows = lib.addk_conv_rows(P, Cout)
+
+    def conv(src, rs_y=None):
+        ar = L.ConvArgs()
+        ar.src[0] = src
+        ar.nsrc = 1
+        ar.N, ar.H, ar.W, ar.OH, ar.OW = N, H, W, H, W
+        ar.KH = ar.KW = 1
+        ar.stride, ar.pad, ar.dil, ar.Cout = 1, 0, 1, Cout
+        ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = K, K, 0, Cout
+        y = torch.full((P, Cout), float('nan'), device=dev)
+        slab = torch.zeros(rows, Cout, 2, device=dev, dtype=torch.float64)
+        ar.w, ar.y, ar.stats, ar.stats_ld = w.data_ptr(), y.data_ptr(), slab.data_ptr(), Cout
+        if rs_y is not None:
+            ar.rs_y, ar.rs_ldy = rs_y.data_ptr(), K
+        if src.rs_hw:
+            assert lib.addk_conv_fwd_resample_ok(C.byref(ar)) == 1, 'the pointwise kernels should cover %s' % name
+        L.check(lib.addk_conv_fwd(C.byref(ar), st), 'conv_fwd')
+        return y, slab.sum(0)
+
+    # unfused: stand-alone resize of the raw map, then the plain 1x1 launch with the lazy affine + ReLU
+    rz = torch.full((P, K), float('nan'), device=dev)
+    ra = L.ResizeArgs()
+    ra.src = _mk_src(L, xs, None, None, K, ld, False)
+    ra.N, ra.H, ra.W, ra.OH, ra.OW = N, SH, SW, H, W
+    ra.y, ra.ldy, ra.nchw_out = rz.data_ptr(), K, 0
+    L.check(lib.addk_resize_fwd(C.byref(ra), st), 'resize_fwd')
+    y0, s0 = conv(_mk_src(L, rz, a, b, K, K, True))
+    # folded, with and without the training copy-out
+    copy = torch.full((P, K), float('nan'), device=dev)
+    y1, s1 = conv(_mk_src(L, xs, a, b, K, ld, True, (SH << 16) | SW))
+    y2, s2 = conv(_mk_src(L, xs, a, b, K, ld, True, (SH << 16) | SW), rs_y=copy)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0) and torch.equal(y2, y0), 'folded 1x1 differs from resize + 1x1 (max %.3e)' % float((y1 - y0).abs().max())
+    assert torch.equal(s1, s0) and torch.equal(s2, s0)
+    assert torch.equal(copy, rz), 'the copy-out is not the resized tensor'
+    # and against fp64 torch: F.interpolate(bilinear, align_corners=False) -> affine -> ReLU -> 1x1
+    xd = xs[..., :K].permute(0, 3, 1, 2).double().cpu()
+    r = F.interpolate(xd, size=(H, W), mode='bilinear', align_corners=False)
+    if lazy:
+        r = r * a.double().cpu().view(1, K, 1, 1) + b.double().cpu().view(1, K, 1, 1)
+    ref = F.conv2d(r.relu(), w.double().cpu().view(Cout, K, 1, 1)).permute(0, 2, 3, 1).reshape(P, Cout)
+    err = float((y1.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
+def test_resample_is_refused_where_no_kernel_covers_it(L, dev):
+    """A 3x3 convolution, a wide (256-channel) head or a tiny map must not be handed a sampled source: the query says no, and
+    a launch that insists fails loudly instead of reading the small map as if it had the consumer's size."""
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    xs = torch.randn(1, 8, 8, 80, device=dev)
+    w = torch.randn(256, 9 * 80, device=dev)
+    y = torch.empty(40 * 40, 256, device=dev)
+    # (kernel size, K, Cout, consumer map side, covered?)
+    for k, K, cout, oh, covered in ((3, 80, 80, 15, False),       # not a 1x1
+                                    (1, 64, 256, 40, False),      # K = 64 is the streaming kernel's, which stops at 160 output channels
+                                    (1, 64, 80, 15, False),       # ... and needs >= 1024 pixels
+                                    (1, 80, 80, 15, True)):       # the register-stationary kernel takes any map size
+        ar = L.ConvArgs()
+        ar.src[0] = _mk_src(L, xs, None, None, K, 80, True, (8 << 16) | 8)
+        ar.nsrc = 1
+        ar.N, ar.H, ar.W, ar.OH, ar.OW = 1, oh, oh, oh, oh
+        ar.KH = ar.KW = k
+        ar.stride, ar.pad, ar.dil, ar.Cout = 1, k // 2, 1, cout
+        ar.ldw, ar.cin_total, ar.w_choff, ar.ldy = k * k * K, K, 0, cout
+        ar.w, ar.y = w.data_ptr(), y.data_ptr()
+        ok = lib.addk_conv_fwd_resample_ok(C.byref(ar))
+        assert ok == int(covered), (k, K, cout, oh)
+        rc = lib.addk_conv_fwd(C.byref(ar), st)
+        if covered:
+            assert rc == 0
+        else:
+            assert rc < 0 and b'resampled' in lib.addk_last_error()
+    torch.cuda.synchronize()
+
+
+def _cell_net(dev, F_=20, seed=11):
+    import oracle  # noqa: F401
+    from _util import ARCH_C2, GENOTYPE_AUTODEEPLAB, fill_params, make_args
+    from addk.modeling.ADD import ADD
+    m = ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(F_), 0)
+    fill_params(m, seed)
+    return m.to(dev)
+
+
+def test_whole_network_fold_on_equals_fold_off(dev, monkeypatch):
+    """ADD F=20 at an even size (the size class whose dense connections need resizes): eval logits, train-mode logits,
+    loss and every parameter gradient are IDENTICAL with the resizes folded into their 1x1 consumers and with stand-alone launches;
+    the folded plans hold (almost) no resize launch."""
+    from _util import rand_tensor
+    from addk.train import TrainStep
+    x = rand_tensor(3, 'fold_x', (2, 3, 256, 512)).to(dev)
+    t = torch.from_numpy(np.random.default_rng(4).integers(0, 19, (2, 256, 512))).long().to(dev)
+    res = {}
+    for fold in ('1', '0'):
+        monkeypatch.setenv('ADDK_FOLD_RESIZE', fold)
+        m = _cell_net(dev)
+        m.eval()
+        with torch.no_grad():
+            ye = [y.clone() for y in m(x)]
+        plan = next(iter(m._plans().values()))
+        n_rs_eval = sum(1 for c in plan.g.fwd if c.name == 'resize_fwd')
+        ts = TrainStep(m, (2, 3, 256, 512), use_graph=False)
+        ts.load_batch(x, t)
+        ts.forward_backward_only()
+        torch.cuda.synchronize()
+        n_rs_train = sum(1 for c in ts.g.fwd if c.name == 'resize_fwd')
+        res[fold] = (ye, float(ts.loss.item()), ts.flat_g.clone(), n_rs_eval, n_rs_train)
+        del ts, m
+        torch.cuda.empty_cache()
+    a, b = res['1'], res['0']
+    assert a[3] < b[3] - 30 and a[4] < b[4] - 30, 'the fold removed too few resize launches: %s vs %s' % (a[3:], b[3:])
+    for ya, yb in zip(a[0], b[0]):
+        assert torch.equal(ya, yb)
+    assert a[1] == b[1]
+    assert torch.equal(a[2], b[2])
