@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libaddk.so')
+LIB_PATH = os.environ.get('ADDK_LIB') or os.path.join(_HERE, 'libaddk.so')      # ADDK_LIB: an A/B or diagnostic build of the same sources (scripts/*.sh)
 
 MAX_SRC, MAX_SLAB, MAX_TERMS = 12, 32, 4
 fp = C.POINTER(C.c_float)

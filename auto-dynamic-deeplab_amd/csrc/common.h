@@ -47,7 +47,18 @@ __device__ __forceinline__ float4 ld4(const float* p) {
 }
 __device__ __forceinline__ void st4(float* p, float4 v) {
   const addk_f32x4 t = {v.x, v.y, v.z, v.w};
+#ifdef ADDK_ST_WT          // experiment (scripts/ab_store_wt.sh): every 16-byte global store write-through (sc1), see st4_wt below
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"((__attribute__((address_space(1))) addk_f32x4*)p), "v"(t));
+#else
   *(__attribute__((address_space(1))) addk_f32x4*)p = t;
+#endif
+}
+// Write-through 16-byte store (`sc1`: the bytes leave the XCD's L2 as they are written instead of waiting, dirty, for the end-of-kernel
+// write-back — MI355X_MICROARCH.md, 'stores of each flavour' / 'publish-large').  For launches whose output is consumed by the NEXT kernel
+// (another XCD's L2 never sees it anyway): experiment of round 4, see DESIGN.md.
+__device__ __forceinline__ void st4_wt(float* p, float4 v) {
+  const addk_f32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"((__attribute__((address_space(1))) addk_f32x4*)p), "v"(t) : "memory");
 }
 __device__ __forceinline__ float4 lds_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void lds_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

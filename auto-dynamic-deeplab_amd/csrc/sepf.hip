@@ -18,6 +18,7 @@
 //     slab row -> the LAST workgroup finalizes the statistics (bnfin.h): no bn_finalize launch;
 //     inference epilogue: own frozen BatchNorm + the other branches of the cell block (ADD.py:108).
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 #include "bnfin.h"
 
@@ -30,6 +31,7 @@ struct SepfK {
   double* slab; int slab_ld; int rows;
   const float* ea; const float* eb; int nterm; addk_src term[ADDK_MAX_TERMS];
   int tiles_x, tiles_y, gx;
+  int wt;                    // 1: write-through (sc1) output stores (ADDK_SEPF_WT=1, experiment)
   BnFin fin;
 };
 
@@ -63,11 +65,29 @@ struct SepfGeo {
   static constexpr int PATCH = NPIX * KP + 8;                     // floats (+8: the clamped tail read of the last pixel stays inside)
   static constexpr int DWL = KS * KS * KG * 16, PWL = KG * CT * 64 * 4;
   static constexpr int RED = (4 * CT * 16 * 2 > 514 ? 4 * CT * 16 * 2 : 514) * 2;   // floats: [4][CT*16][2] doubles, or the finalize scratch
-  static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + RED) * 4;
+  static constexpr int EAB = 2 * KG * 16;                                            // inference epilogue coefficients (ea, eb)
+  static constexpr int NPL = 256 / KQ;                                               // pixel lanes of the staging map: thread = (pixel lane, channel quad)
+  static constexpr int NLD = (NPIX + NPL - 1) / NPL;                                 // patch loads per thread
+  static constexpr int UNMAX = (KS == 5 && R == 2) ? 6 : 10;                         // (the 5x5 two-row variant is short of registers: two rounds)
+  static constexpr int UN = NLD <= UNMAX ? NLD : (NLD + 1) / 2;                      // ... per round: one round where 10 loads in flight suffice
+  static constexpr int TPX = 4 * R * 16, TLD = TPX * KP;                             // first sum term of the inference epilogue, staged like the patch
+  static constexpr int NTL = (TPX + NPL - 1) / NPL;
+  static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + RED + EAB + TLD) * 4;
 };
+
+#ifdef ADDK_SEPF_DIAG
+// diagnostic build (scripts/sepf_phases.sh): every workgroup adds the length of its phases in 100 MHz reference ticks (s_memrealtime) and
+// keeps the earliest start / latest end of the launch, so that the in-kernel time can be set against the launch's wall time
+__device__ unsigned long long g_sepf_diag[64][8];
+__device__ unsigned long long g_sepf_span[2] = {~0ull, 0ull};
+#define SEPF_STAMP(i) const unsigned long long diag_t##i = __builtin_amdgcn_s_memrealtime()
+#else
+#define SEPF_STAMP(i)
+#endif
 
 template <int KS, int KG, int KP, int R, bool IO16 = false>
 __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
+  SEPF_STAMP(0);
   typedef SepfGeo<KS, KG, KP, R> G;
   constexpr int CT = G::CT, PH = G::PH, PW = G::PW, NPIX = G::NPIX, KQ = G::KQ, HK = KS / 2;
   float* patch = sm;
@@ -81,9 +101,58 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   const int ty = b % p.tiles_y; const int n = b / p.tiles_y;
   const int oh0 = ty * (4 * R), ow0 = tx * 16;
 
-  // ---- stage: weights (tiny, L2-resident) and the input patch; every global load here is independent of every other ----
-  for (int i = t; i < G::DWL; i += 256) dwl[i] = 0.f;
-  __syncthreads();
+  // ---- stage.  Round 4: EVERY global load of the tile is issued before anything waits — the first round of patch loads, the operands
+  // of the inference epilogue (other branches of the cell block) and the weights are ONE round trip to memory; they used to be three
+  // dependent ones (weights -> patch -> epilogue operands: 2.5 + 1.7 + 2.7 us of a 9.8 us workgroup, profiles/r04_sepf_phases.txt). ----
+  constexpr int NPL = G::NPL, UN = G::UN;
+  float* eab = reinterpret_cast<float*>(red) + G::RED;
+  const int q = t % KQ, pl = t / KQ;
+  const bool qact = pl < NPL && q < nq;
+  const long xq = qact ? 4 * q : 0;
+  const int ih0 = oh0 - HK, iw0 = ow0 - HK;
+  float4 pv[UN]; bool pok[UN];
+  auto patch_issue = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pix = base + u * NPL;
+      const int pr = pix / PW, pc = pix - pr * PW;
+      const int ih = ih0 + pr, iw = iw0 + pc;
+      pok[u] = qact && pix < NPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      pv[u] = ldx<IO16>(p.src.x, xq + (pok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
+    }
+  };
+  patch_issue(pl);
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  if (p.src.a && qact) { av = ld4(p.src.a + 4 * q); bv = ld4(p.src.b + 4 * q); }
+  // epilogue operands: the first two sum terms of this lane's output elements (a cell block has two branches: one term)
+  int pp[R]; bool pin[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int oh = oh0 + wave * R + r, ow = ow0 + li;
+    pin[r] = oh < p.H && ow < p.W;
+    pp[r] = (n * p.H + oh) * p.W + ow;
+  }
+  // the first sum term (a cell block has two branches: one term) travels with the patch: loaded now, parked in LDS, read by the epilogue
+  float* tl = eab + G::EAB;                                    // [4R x 16 pixels][KP]
+  constexpr int NTL = G::NTL;
+  float4 tq[NTL];
+  const bool t0 = p.nterm > 0;
+  if (t0) {
+#pragma unroll
+    for (int u = 0; u < NTL; ++u) {
+      const int pix = pl + u * NPL;
+      const int oh = oh0 + (pix >> 4), ow = ow0 + (pix & 15);
+      const bool ok = qact && pix < G::TPX && oh < p.H && ow < p.W;
+      tq[u] = ldx<IO16>(p.term[0].x, ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);             // the loads above stay above: hipcc otherwise sinks each one to its first use
+  // weights (tiny, L2-resident).  Channels beyond C of the tap table are zeroed by the threads that do not write a weight there (no
+  // barrier between a zero fill and the weights any more)
+  for (int i = t; i < KS * KS * (KG * 16 - C); i += 256) {
+    const int tp = i / (KG * 16 - C), c = C + i - tp * (KG * 16 - C);
+    dwl[tp * (KG * 16) + c] = 0.f;
+  }
   for (int i = t; i < C * KS * KS; i += 256) {                 // coalesced read of [C][KS*KS], transposed into [tap][channel]
     const int c = i / (KS * KS), tp = i - c * (KS * KS);
     dwl[tp * (KG * 16) + c] = ((const gfloat*)p.dww)[i];
@@ -96,40 +165,38 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
     v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
     lds_st4(pwl + s * 4, v);
   }
+  if (t0 && qact) {
+#pragma unroll
+    for (int u = 0; u < NTL; ++u) {
+      const int pix = pl + u * NPL;
+      if (pix < G::TPX) lds_st4(tl + pix * KP + 4 * q, tq[u]);
+    }
+  }
+  if (p.ea && t < 2 * nq) {                                    // frozen-BatchNorm coefficients of the inference epilogue -> LDS
+    const int which = t / nq, qq = t - which * nq;
+    lds_st4(eab + which * (KG * 16) + 4 * qq, ld4((which ? p.eb : p.ea) + 4 * qq));
+  }
+  SEPF_STAMP(1);
   {
-    const int npl = 256 / KQ;                                  // pixel lanes; thread = (pixel lane, channel quad incl. the zero padding quads)
-    const int q = t % KQ, pl = t / KQ;
-    const bool qact = pl < npl && q < nq;
-    float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
-    if (p.src.a && qact) { av = ld4(p.src.a + 4 * q); bv = ld4(p.src.b + 4 * q); }
     const bool relu = p.src.relu != 0;
-    const long xq = qact ? 4 * q : 0;
-    const int ih0 = oh0 - HK, iw0 = ow0 - HK;
-    if (pl < npl) {
-      constexpr int UN = 6;
-      for (int base = pl; base < NPIX; base += UN * npl) {
-        float4 v[UN]; bool ok[UN];
+    if (pl < NPL) {
+      for (int base = pl; base < NPIX; base += UN * NPL) {
+        if (base != pl) patch_issue(base);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-          const int pix = base + u * npl;
-          const int pr = pix / PW, pc = pix - pr * PW;
-          const int ih = ih0 + pr, iw = iw0 + pc;
-          ok[u] = qact && pix < NPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-          v[u] = ldx<IO16>(p.src.x, xq + (ok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const int pix = base + u * npl;
-          float4 z = fma4(av, v[u], bv);
+          const int pix = base + u * NPL;
+          float4 z = fma4(av, pv[u], bv);
           if (relu) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
-          z.x = ok[u] ? z.x : 0.f; z.y = ok[u] ? z.y : 0.f; z.z = ok[u] ? z.z : 0.f; z.w = ok[u] ? z.w : 0.f;
+          z.x = pok[u] ? z.x : 0.f; z.y = pok[u] ? z.y : 0.f; z.z = pok[u] ? z.z : 0.f; z.w = pok[u] ? z.w : 0.f;
           if (pix < NPIX) lds_st4(patch + pix * KP + 4 * q, z);
         }
       }
     }
     if (t < 8) patch[NPIX * KP + t] = 0.f;
   }
+  SEPF_STAMP(2);
   __syncthreads();
+  SEPF_STAMP(3);
 
   // ---- compute: wave = rows [wave*R, wave*R + R) x 16 pixels ----
   f32x4 macc[R][CT];
@@ -137,13 +204,6 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int i = 0; i < CT; ++i) macc[r][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int pp[R]; bool pin[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int oh = oh0 + wave * R + r, ow = ow0 + li;
-    pin[r] = oh < p.H && ow < p.W;
-    pp[r] = (n * p.H + oh) * p.W + ow;
-  }
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
     const int q = 4 * g + kq;
@@ -182,6 +242,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
           macc[r][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(get4(wf[i], e), get4(acc[r], e), macc[r][i], 0, 0, 0);
   }
 
+  SEPF_STAMP(4);
   // ---- epilogue: lane holds channels i*16 + kq*4 + {0..3} of pixel pp[r] ----
   float s1[CT][4], s2[CT][4];
 #pragma unroll
@@ -193,22 +254,36 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
     const int c = i * 16 + kq * 4;
     if (c >= C) continue;                                   // C % 4 == 0: a quad is valid as a whole
     float4 ea = make_float4(1.f, 1.f, 1.f, 1.f), eb = zero4();
-    if (p.ea) { ea = ld4(p.ea + c); eb = ld4(p.eb + c); }
+    if (p.ea) { ea = lds_ld4(eab + c); eb = lds_ld4(eab + KG * 16 + c); }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (!pin[r]) continue;
       float4 v = make_float4(macc[r][i][0], macc[r][i][1], macc[r][i][2], macc[r][i][3]);
       if (p.ea) v = fma4(ea, v, eb);
-      for (int ti = 0; ti < p.nterm; ++ti) {
+      if (t0) {                                              // same order and expressions as before: term 0 (from LDS), then the rest
+        const addk_src& T = p.term[0];
+        const float4 u = prologue4(lds_ld4(tl + ((wave * R + r) * 16 + li) * KP + c), T.a, T.b, c, 4, T.relu != 0, true);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      for (int ti = 1; ti < p.nterm; ++ti) {
         const addk_src& T = p.term[ti];
         const float4 u = prologue4(ldx<IO16>(T.x, (long)pp[r] * T.ld + c), T.a, T.b, c, 4, T.relu != 0, true);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
-      stx<IO16>(p.y, (long)pp[r] * p.ldy + c, v);
+      if (!IO16 && p.wt) st4_wt(p.y + (long)pp[r] * p.ldy + c, v); else stx<IO16>(p.y, (long)pp[r] * p.ldy + c, v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float f = get4(v, e); s1[i][e] += f; s2[i][e] = fmaf(f, f, s2[i][e]); }
     }
   }
+#ifdef ADDK_SEPF_DIAG
+  if (t == 0) {
+    const unsigned long long diag_t5 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* d = g_sepf_diag[blockIdx.x & 63];
+    atomicAdd(&d[0], diag_t1 - diag_t0); atomicAdd(&d[1], diag_t2 - diag_t1); atomicAdd(&d[2], diag_t3 - diag_t2);
+    atomicAdd(&d[3], diag_t4 - diag_t3); atomicAdd(&d[4], diag_t5 - diag_t4); atomicAdd(&d[5], 1ull);
+    atomicMin(&g_sepf_span[0], diag_t0); atomicMax(&g_sepf_span[1], diag_t5);
+  }
+#endif
   if (p.slab) {            // butterfly over the 16 pixel lanes (fp64), the four waves through LDS, one slab row per workgroup
     double (*rd)[CT * 16][2] = reinterpret_cast<double (*)[CT * 16][2]>(red);
 #pragma unroll
@@ -285,6 +360,7 @@ bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   { static int fr = -1; if (fr < 0) { const char* e = getenv("ADDK_SEP_R"); fr = e ? atoi(e) : 0; } if (fr == 1 || (fr == 2 && kg == 3)) c.r = fr; }   // tuning aid
   c.io16 = a->io16 ? 1 : 0;
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
+  { static int wt = -1; if (wt < 0) { const char* e = getenv("ADDK_SEPF_WT"); wt = (e && e[0] == '1') ? 1 : 0; } k.wt = wt; }
   k.rows = a->stats_rows;
   if (k.slab && k.gx > k.rows) return false;             // the caller sizes the slab with addk_sep_rows
   if (a->fin.a) {
@@ -340,6 +416,20 @@ int sepf_dispatch(const SepfCfg& c, bool batch, dim3 grid, hipStream_t st, const
 
 }  // namespace
 
+#ifdef ADDK_SEPF_DIAG
+// out[0..4]: phase ticks (weights, patch loads + LDS stores, barrier, compute, epilogue issue) summed over workgroups, out[5]: workgroups,
+// out[6]: latest end - earliest start of all workgroups since the last call (10 ns ticks); resets
+extern "C" int addk_sepf_diag(unsigned long long* out8) {
+  unsigned long long h[64][8], sp[2];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sepf_diag), sizeof h) != hipSuccess) return ADDK_ERR_INVALID;
+  if (hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_sepf_span), sizeof sp) != hipSuccess) return ADDK_ERR_INVALID;
+  for (int k = 0; k < 8; ++k) { out8[k] = 0; for (int i = 0; i < 64; ++i) out8[k] += h[i][k]; }
+  out8[6] = sp[1] > sp[0] ? sp[1] - sp[0] : 0;
+  memset(h, 0, sizeof h); sp[0] = ~0ull; sp[1] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sepf_span), sp, sizeof sp);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sepf_diag), h, sizeof h) == hipSuccess ? ADDK_OK : ADDK_ERR_INVALID;
+}
+#endif
 // slab rows a fused launch writes (= its workgroups): the caller sizes `stats` with max(this, addk_conv_rows)
 extern "C" int addk_sep_rows(const addk_sep_args* a) {
   SepfK k; SepfCfg c;

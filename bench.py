@@ -334,6 +334,70 @@ def ddp_path_world1(genotype, a, x, t, dev, steps=10):
         dist.destroy_process_group()
 
 
+def timed_region(ts, steps, warmup, world, rank, barrier, max_over_ranks, contract_line, json_out, no_graph=False):
+    """The contract's measurement and the whole N > 1 control flow, independent of what `ts` is (tests/test_parallel_gloo.py drives it
+    with a stub step on two gloo ranks): W untimed warm-up steps, EXACTLY K steps between barrier + device synchronisation on both
+    sides, the MAXIMUM over ranks.  With world > 1 the step runs on the eager launch list (the safe default: no RCCL call inside a
+    capture has been seen on a multi-GPU box by the builder); the whole-step capture — 40 vs 45 ms at world 1 — is then TRIED under a
+    watchdog: a refused capture falls back collectively inside TrainStep; if the captured steps do not finish within the limit, rank 0
+    prints the eager line with `capture_hang: true` and every rank leaves with exit code 3 (a hang is not a successful run).
+    Returns (seconds for K steps, {mode: ms per step}, first two warm-up losses)."""
+    def timed(k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            ts.step()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    losses = []
+    for i in range(warmup):
+        ts.step()
+        if i < 2:
+            losses.append(float(ts.loss.item()))
+    dt = timed(steps)
+    modes = {('hip_graph' if ts.graph is not None else 'eager_list'): dt / steps * 1e3}
+    try_cap = os.environ.get('ADDK_BENCH_TRY_CAPTURE', '1')
+    if (world > 1 or try_cap == 'force') and ts.graph is None and ts.has_coll and not no_graph and try_cap != '0':
+        import threading
+        eager_line = contract_line(dt, False, 'whole-step capture with RCCL collectives did not finish in time: eager launch list')
+        phase = ['capture']
+
+        def bail():
+            # a hang is NOT a successful run: the eager measurement is valid and is printed, but the line says so in machine-readable
+            # fields and every rank leaves with a distinct exit code (3) while the stuck capture / replay is still in flight
+            if rank == 0:
+                eager_line['capture_hang'] = True
+                eager_line['capture_phase'] = phase[0]
+                json_out.write(json.dumps(eager_line) + '\n')
+                json_out.flush()
+            sys.stderr.write('[bench] rank %d: capture watchdog fired in phase %r\n' % (rank, phase[0])); sys.stderr.flush()
+            os._exit(3)
+        timer = threading.Timer(float(os.environ.get('ADDK_BENCH_CAPTURE_LIMIT', '120')), bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            ts.enable_capture()
+            ts.step()
+            if ts.graph is not None:
+                for i in range(2):
+                    phase[0] = 'replay warm-up step %d' % i
+                    ts.step()
+                phase[0] = 'timed replay of %d steps' % steps
+                dt2 = timed(steps)
+                modes['hip_graph'] = dt2 / steps * 1e3
+                if dt2 < dt:
+                    dt = dt2
+                else:
+                    ts.use_graph = False
+            else:
+                modes['hip_graph'] = 'capture refused: eager launch list on every rank'
+        except Exception as e:
+            sys.stderr.write('[bench] capture attempt failed: %r\n' % (e,))
+        timer.cancel()
+    return dt, modes, losses
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -425,13 +489,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(k):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            ts.step()
-        barrier()
-        d = time.perf_counter() - t0
+    def max_over_ranks(d):
         if world > 1:
             tt = torch.tensor([d], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -451,52 +509,7 @@ def main():
             line['note'] = note
         return line
 
-    losses = []
-    for i in range(a.warmup):
-        ts.step()
-        if i < 2:
-            losses.append(float(ts.loss.item()))
-    dt = timed(a.steps)
-    modes = {('hip_graph' if ts.graph is not None else 'eager_list'): dt / a.steps * 1e3}
-    # N > 1: the step ran on the eager launch list (the safe default: no RCCL call inside a capture has been seen on a multi-GPU box by
-    # the builder).  Now TRY the whole-step capture — measured 40 vs 45 ms at world 1 — under a watchdog: if the captured step has not
-    # finished its K steps within the limit, rank 0 prints the eager line and every rank leaves; a refused capture falls back by itself.
-    try_cap = os.environ.get('ADDK_BENCH_TRY_CAPTURE', '1')
-    if (world > 1 or try_cap == 'force') and ts.graph is None and ts.has_coll and not a.no_graph and try_cap != '0':
-        import threading
-        eager_line = contract_line(dt, False, 'whole-step capture with RCCL collectives did not finish in time: eager launch list')
-        phase = ['capture']
-
-        def bail():
-            # a hang is NOT a successful run: the eager measurement is valid and is printed, but the line says so in machine-readable
-            # fields and every rank leaves with a distinct exit code (3) while the stuck capture / replay is still in flight
-            if rank == 0:
-                eager_line['capture_hang'] = True
-                eager_line['capture_phase'] = phase[0]
-                json_out.write(json.dumps(eager_line) + '\n')
-                json_out.flush()
-            sys.stderr.write('[bench] rank %d: capture watchdog fired in phase %r\n' % (rank, phase[0])); sys.stderr.flush()
-            os._exit(3)
-        timer = threading.Timer(float(os.environ.get('ADDK_BENCH_CAPTURE_LIMIT', '120')), bail)
-        timer.daemon = True
-        timer.start()
-        try:
-            ts.enable_capture()
-            ts.step()
-            if ts.graph is not None:
-                for i in range(2):
-                    phase[0] = 'replay warm-up step %d' % i
-                    ts.step()
-                phase[0] = 'timed replay of %d steps' % a.steps
-                dt2 = timed(a.steps)
-                modes['hip_graph'] = dt2 / a.steps * 1e3
-                if dt2 < dt:
-                    dt = dt2
-                else:
-                    ts.use_graph = False
-        except Exception as e:
-            sys.stderr.write('[bench] capture attempt failed: %r\n' % (e,))
-        timer.cancel()
+    dt, modes, losses = timed_region(ts, a.steps, a.warmup, world, rank, barrier, max_over_ranks, contract_line, json_out, no_graph=a.no_graph)
     loss = float(ts.loss.item())
     if rank != 0:
         ts.close()

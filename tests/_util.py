@@ -34,3 +34,11 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rms_err(a, b):
+    """rms(a - b) / rms(b): unlike rel_err (max-abs / max-abs) every element counts, so the small-magnitude elements are constrained too
+    (VERDICT r03 weak 1e).  Asserted beside rel_err by tests/test_gpu_parity.py::_chk at the same tolerance."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float(((a - b) ** 2).mean().sqrt() / ((b ** 2).mean().sqrt() + 1e-300))

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 import oracle                       # noqa: E402  (the checker)
 from _util import (ARCH_C2, ARCH_C3, GENOTYPE_AUTODEEPLAB, GENOTYPE_BASELINE_2, GENOTYPE_40_1,   # noqa: E402
-                   NETWORK_PATH_BASELINE, fill_params, make_args, probe_weights, rand_tensor, rel_err)
+                   NETWORK_PATH_BASELINE, fill_params, make_args, probe_weights, rand_tensor, rel_err, rms_err)
 
 TOL = 1e-3
 BN = nn.BatchNorm2d
@@ -34,10 +34,13 @@ FAILS = []
 
 
 def _chk(name, a, b, tol=TOL):
-    e = rel_err(a, b)
-    REPORT.append('%-60s %.3e%s' % (name, e, '' if e <= tol else '   <-- FAIL (tol %.0e)' % tol))
-    if not e <= tol:
-        FAILS.append('%s: rel err %.3e > %.1e' % (name, e, tol))
+    """Two metrics at the same tolerance: max-abs error / max-abs reference (the 1e-3 of north_star) AND rms error / rms reference,
+    in which every element counts (a tensor whose small-magnitude elements were wrong passed the first alone: VERDICT r03 weak 1e)."""
+    e, r = rel_err(a, b), rms_err(a, b)
+    ok = e <= tol and r <= tol
+    REPORT.append('%-60s %.3e  rms %.3e%s' % (name, e, r, '' if ok else '   <-- FAIL (tol %.0e)' % tol))
+    if not ok:
+        FAILS.append('%s: rel err %.3e / rms err %.3e > %.1e' % (name, e, r, tol))
     return e
 
 
@@ -333,7 +336,7 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
     crit = nn.CrossEntropyLoss(ignore_index=255)
     ratios = []
     for draw, (sx, st) in enumerate([(61, 62), (71, 72)] if big else [(61, 62)]):
-        ma, mo, _ = _build_add(dev, Fv, ARCH_C2)
+        ma, mo, _chk_sum = _build_add(dev, Fv, ARCH_C2)
         ma.eval(); mo.eval()
         x = rand_tensor(sx, 'frozen_x', (2, 3) + hw)
         tgt = torch.from_numpy(np.random.default_rng(st).integers(0, 19, (2,) + hw)).long()
@@ -343,18 +346,23 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
         torch.cuda.synchronize()
         pa = dict(ma.named_parameters())
         if big:
-            m64 = oracle.ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(Fv), ARCH_C2['low_level_layer']).double()
-            m64.load_state_dict(mo.state_dict()); m64.eval()
-            (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
-            p64 = dict(m64.named_parameters())
+            # [r4] fp64 truth = the REAL reference run in double precision, held sub-sampled by tests/golden/grads64.npz (no fp64 pass on
+            # the host): max-abs error over the held positions / the whole tensor's max |g64|, and the rms error beside it (every element
+            # counts there, not only the largest); the fp32 oracle runs live and is measured the same way
+            from grads64_util import Grads64
+            fx = Grads64('frozen512_%d' % draw)
+            assert abs(_chk_sum - fx.chk) <= 1e-9 * abs(fx.chk), 'weights differ from the ones the fixture was made with'
         n = 0
-        ours, theirs, groups = [], [], {}
+        ours, theirs, groups, ours_rms, theirs_rms = [], [], {}, [], []
         for k, p in mo.named_parameters():
             if p.dim() == 4 and p.grad is not None:
                 assert pa[k].grad is not None, k
                 if big:
-                    ours.append(_chk('frozen_bn%d.%d/g:%s' % (hw[0], draw, k), pa[k].grad.cpu().double(), p64[k].grad, 1e-2))
-                    theirs.append(rel_err(p.grad.double(), p64[k].grad))
+                    ours.append(fx.rel_err(k, pa[k].grad)); theirs.append(fx.rel_err(k, p.grad))
+                    ours_rms.append(fx.rms_err(k, pa[k].grad)); theirs_rms.append(fx.rms_err(k, p.grad))
+                    REPORT.append('%-60s %.3e (rms %.3e)' % ('frozen_bn%d.%d/g:%s vs reference fp64' % (hw[0], draw, k), ours[-1], ours_rms[-1]))
+                    assert ours[-1] <= 1e-2, (k, ours[-1])
+                    _chk('frozen_bn%d.%d/g-full:%s' % (hw[0], draw, k), pa[k].grad, p.grad, 1e-2)      # every element, against the live fp32 oracle
                     grp = '.'.join(k.split('.')[:2]) if k.startswith('cells.') else k.split('.')[0]
                     groups.setdefault(grp, []).append((ours[-1], theirs[-1]))
                 else:
@@ -368,8 +376,11 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
             for grp, v in groups.items():      # per module: median error of its conv-weight gradients, addk and the fp32 oracle, both vs fp64
                 REPORT.append('frozen_bn512 draw %d per-layer %-22s n=%3d  addk %.2e  fp32 oracle %.2e  ratio %.2f' % (
                     draw, grp, len(v), med([a for a, _ in v]), med([b for _, b in v]), med([a for a, _ in v]) / max(med([b for _, b in v]), 1e-30)))
+            REPORT.append('frozen_bn512 draw %d rms error vs fp64: addk max %.2e median %.2e | fp32 oracle max %.2e median %.2e' % (
+                draw, max(ours_rms), med(ours_rms), max(theirs_rms), med(theirs_rms)))
             ratios.append((max(ours) / max(theirs), med(ours) / med(theirs)))
             assert ratios[-1][0] <= 3 and ratios[-1][1] <= 2.5, ratios
+            assert max(ours_rms) <= 3 * max(theirs_rms) and med(ours_rms) <= 2.5 * med(theirs_rms), (max(ours_rms), max(theirs_rms), med(ours_rms), med(theirs_rms))
         del ma, mo
         torch.cuda.empty_cache()
     if big:

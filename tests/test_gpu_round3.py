@@ -105,18 +105,19 @@ def test_full_size_frozen_bn_gradients_on_sentinel_convs(dev):
     for k in sentinels:
         po[k].requires_grad_(True)
     (sum(crit(y, tgt) for y in mo(x)) / 2).backward()
-    g32 = {k: po[k].grad.detach().double() for k in sentinels}
-    m64 = mo.double()
-    for k in sentinels:
-        po[k].grad = None
-    (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
+    # [r4] fp64 truth: the real reference in double precision at this very shape, held sub-sampled by tests/golden/grads64.npz — the
+    # full-size fp64 pass on the host (the longest single item of the round-3 suite) is gone
+    from grads64_util import Grads64
+    fx = Grads64('full_sentinels')
+    assert set(fx.names()) == set(sentinels)
     worst = 0.0
     for k in sentinels:
-        g64 = po[k].grad.detach()
-        ea, eo = rel_err(ga[k], g64), rel_err(g32[k], g64)
+        ea, eo = fx.rel_err(k, ga[k]), fx.rel_err(k, po[k].grad)
+        ra, ro = fx.rms_err(k, ga[k]), fx.rms_err(k, po[k].grad)
         worst = max(worst, ea / max(eo, 1e-30))
-        _log('config2 2x1024x2048 frozen-BN gradient %-44s addk %.2e  fp32 oracle %.2e  ratio %.2f', k, ea, eo, ea / max(eo, 1e-30))
+        _log('config2 2x1024x2048 frozen-BN gradient %-44s addk %.2e  fp32 oracle %.2e  ratio %.2f | rms addk %.2e  fp32 oracle %.2e', k, ea, eo, ea / max(eo, 1e-30), ra, ro)
         assert ea <= max(4 * eo, 1e-3), (k, ea, eo)
+        assert ra <= max(4 * ro, 1e-3), (k, ra, ro)
     _log('config2 2x1024x2048 frozen-BN sentinel gradients: worst ratio to the fp32 oracle %.2f', worst)
 
 
@@ -197,7 +198,7 @@ def test_bf16x3_whole_network_parity(dev):
     try:
         addk.set_precision('bf16x3')
         hw = (256, 512)
-        ma, mo, _, args = _build(dev, 40, ARCH_C2, _geno('genotype_1'), seed=900)
+        ma, mo, chk, args = _build(dev, 40, ARCH_C2, _geno('genotype_1'), seed=900)
         x = rand_tensor(61, 'f40_frozen_x', (2, 3) + hw)
         tgt = _target(hw)
         crit = nn.CrossEntropyLoss(ignore_index=255)
@@ -209,16 +210,16 @@ def test_bf16x3_whole_network_parity(dev):
             assert e <= 1e-3
         (sum(crit(y, tgt.to(dev)) for y in ya) / 2).backward()
         (sum(crit(y, tgt) for y in yo) / 2).backward()
-        m64 = oracle.ADD(*args).double()
-        m64.load_state_dict(mo.state_dict()); m64.eval()
-        (sum(crit(y, tgt) for y in m64(x.double())) / 2).backward()
         torch.cuda.synchronize()
-        pa, p64 = dict(ma.named_parameters()), dict(m64.named_parameters())
+        from grads64_util import Grads64
+        fx = Grads64('f40_genotype_1')          # [r4] the real reference in double precision (tests/golden/grads64.npz), same draw as test_f40_frozen_bn_gradients
+        assert abs(chk - fx.chk) <= 1e-9 * abs(fx.chk)
+        pa = dict(ma.named_parameters())
         ours, theirs = [], []
         for k, p in mo.named_parameters():
             if p.dim() == 4 and p.grad is not None:
-                ours.append(rel_err(pa[k].grad.cpu().double(), p64[k].grad))
-                theirs.append(rel_err(p.grad.double(), p64[k].grad))
+                ours.append(fx.rel_err(k, pa[k].grad))
+                theirs.append(fx.rel_err(k, p.grad))
         med = lambda v: sorted(v)[len(v) // 2]
         p90 = lambda v: sorted(v)[int(len(v) * 0.9)]
         _log('bf16x3 F40_g1 frozen-BN 256x512, %d conv-weight gradients vs fp64: addk max %.2e p90 %.2e median %.2e | fp32 oracle max %.2e p90 %.2e median %.2e',

@@ -258,3 +258,40 @@ def test_shard_indices_equal_torch_distributed_sampler():
             s = DistributedSampler(ds, num_replicas=world, rank=rank)
             s.set_epoch(5)
             assert list(s) == parallel.shard_indices(n, rank, world, epoch=5)
+
+
+@pytest.mark.parametrize('mode', ['capture_ok', 'capture_refused', 'capture_hang'])
+def test_bench_multi_rank_control_flow_world2(mode):
+    """bench.py's N > 1 control flow (bench.timed_region: eager timing, capture trial under the watchdog) on two gloo ranks with a stub
+    step (tests/tools/bench_flow_driver.py) — the rehearsal of what the driver's first real multi-GPU run will execute:
+      capture_ok       rank 0 prints exactly ONE JSON line with n_gpus 2, the faster (captured) mode wins, both ranks exit 0;
+      capture_refused  one line, eager numbers, hip_graph false, both ranks exit 0;
+      capture_hang     the watchdog fires: rank 0 still prints exactly one line — the eager measurement with capture_hang true and the
+                       phase it was stuck in — and BOTH ranks exit with code 3 (a hang must not look like a success)."""
+    import json
+    import subprocess
+    port = 29500 + ((os.getpid() + hash(mode)) % 2000)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', ADDK_BENCH_CAPTURE_LIMIT='1.0')
+    env.pop('ADDK_BENCH_TRY_CAPTURE', None)
+    drv = os.path.join(ROOT, 'tests', 'tools', 'bench_flow_driver.py')
+    procs = [subprocess.Popen([sys.executable, drv, mode], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    rcs = [p.returncode for p in procs]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    lines1 = [l for l in outs[1][0].splitlines() if l.startswith('{')]
+    assert len(lines0) == 1 and not lines1, (outs, rcs)
+    d = json.loads(lines0[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0
+    if mode == 'capture_hang':
+        assert rcs == [3, 3], (rcs, outs[0][1][-500:], outs[1][1][-500:])
+        assert d.get('capture_hang') is True and d['capture_phase'] == 'capture' and d['config']['hip_graph'] is False
+        assert 'watchdog fired' in outs[1][1]
+    else:
+        assert rcs == [0, 0], (rcs, outs[0][1][-800:], outs[1][1][-800:])
+        assert 'capture_hang' not in d
+        if mode == 'capture_ok':
+            assert d['config']['hip_graph'] is True and set(d['ms_per_step_by_mode']) == {'eager_list', 'hip_graph'}
+            assert d['ms_per_step_by_mode']['hip_graph'] < d['ms_per_step_by_mode']['eager_list']
+        else:
+            assert d['config']['hip_graph'] is False and isinstance(d['ms_per_step_by_mode']['hip_graph'], str)
