@@ -17,8 +17,8 @@ def set_precision(mode):
     MFMA; 'bf16x6' = every operand split into three bf16 terms, six product terms on the bf16 matrix pipe with fp32
     accumulation (as accurate as the fp32 MFMA chain, 2.5x its rate); 'bf16x3' = three terms (fast mode, ~5e-7 rms per
     dot product).  Process-wide; set it before plans are built (packed-weight buffers are sized per mode)."""
-    _lib.check(load().addk_set_conv_precision({'fp32': 0, 'bf16x3': 1, 'bf16x6': 2}[mode]), 'set_precision')
+    _lib.check(load().addk_set_conv_precision({'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'tail_x3': 3}[mode]), 'set_precision')
 
 
 def get_precision():
-    return ('fp32', 'bf16x3', 'bf16x6')[load().addk_get_conv_precision()]
+    return ('fp32', 'bf16x3', 'bf16x6', 'tail_x3')[load().addk_get_conv_precision()]

@@ -115,6 +115,11 @@ class AffineSumBwdArgs(C.Structure):
                 ('accumulate', i32 * MAX_TERMS), ('dab', vp * MAX_TERMS)]
 
 
+class EdmArgs(C.Structure):
+    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('_pad', i32), ('conv_w', vp), ('w1', vp), ('b1', vp), ('w2', vp), ('b2', vp),
+                ('w3', vp), ('b3', vp), ('out', vp), ('out_host', vp), ('ws', vp)]
+
+
 class ResizeArgs(C.Structure):
     _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32), ('y', vp), ('ldy', i32),
                 ('nchw_out', i32)]
@@ -149,6 +154,9 @@ _SIGS = {
     'addk_conv_dgrad_pack_desc': (i32, [C.POINTER(ConvDgradArgs), vp]),
     'addk_conv_pack_batch': (i32, [vp, i32, vp]),
     'addk_conv_fwd_resample_ok': (i32, [C.POINTER(ConvArgs)]),
+    'addk_edm_head_ws_bytes': (i64, [i32, i32, i32]),
+    'addk_edm_head_supported': (i32, [C.POINTER(EdmArgs)]),
+    'addk_edm_head': (i32, [C.POINTER(EdmArgs), vp]),
     'addk_conv_wgrad': (i32, [C.POINTER(ConvWgradArgs), vp]),
     'addk_conv_wgrad_ws': (i64, [i64, i32, i32, i32]),
     'addk_conv_wgrad_config': (i32, [C.POINTER(ConvWgradArgs), C.POINTER(i32)]),

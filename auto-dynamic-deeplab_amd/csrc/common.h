@@ -47,15 +47,13 @@ __device__ __forceinline__ float4 ld4(const float* p) {
 }
 __device__ __forceinline__ void st4(float* p, float4 v) {
   const addk_f32x4 t = {v.x, v.y, v.z, v.w};
-#ifdef ADDK_ST_WT          // experiment (scripts/ab_store_wt.sh): every 16-byte global store write-through (sc1), see st4_wt below
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"((__attribute__((address_space(1))) addk_f32x4*)p), "v"(t));
-#else
   *(__attribute__((address_space(1))) addk_f32x4*)p = t;
-#endif
 }
 // Write-through 16-byte store (`sc1`: the bytes leave the XCD's L2 as they are written instead of waiting, dirty, for the end-of-kernel
 // write-back — MI355X_MICROARCH.md, 'stores of each flavour' / 'publish-large').  For launches whose output is consumed by the NEXT kernel
-// (another XCD's L2 never sees it anyway): experiment of round 4, see DESIGN.md.
+// (another XCD's L2 never sees it anyway).  Measured on the fused SepConv half: 0.5-0.9 us per launch (profiles/r04_sepf_phases.txt); as a
+// blanket replacement of st4 it was slower (36.0 vs 35.6 ms per step: profiles/r04_ab_store_wt_global_rejected.txt) — only sepf.hip uses it.
+// The "memory" clobber is what keeps the compiler from moving dependent memory operations across a store it cannot see.
 __device__ __forceinline__ void st4_wt(float* p, float4 v) {
   const addk_f32x4 t = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"((__attribute__((address_space(1))) addk_f32x4*)p), "v"(t) : "memory");

@@ -475,7 +475,9 @@ int pick_pt(long P) { return P >= 128L * 512 ? 2 : 1; }
 
 // Arithmetic of the wide k x k contractions (the halo-patch kernels of conv3.hip): 0 = exact fp32 MFMA
 // (v_mfma_f32_16x16x4_f32), 2 = split-bf16 with six product terms (fp32-equivalent accuracy at 2.5x the rate), 1 = three
-// terms (fast mode, ~5e-7 rms).  addk_set_conv_precision / ADDK_MATH=fp32|bf16x3|bf16x6.  Every other kernel is fp32.
+// terms (fast mode, ~5e-7 rms), 3 = "tail_x3": three terms in the exit heads only (launches with >= 192 output / gradient channels:
+// ASPP and decoder forward, data and weight gradients — nothing downstream amplifies their rounding), six everywhere else.
+// addk_set_conv_precision / ADDK_MATH=fp32|bf16x3|bf16x6|tail_x3.  Every other kernel is fp32.
 int g_prec = -1;
 int conv_precision() {
   if (g_prec < 0) {
@@ -483,6 +485,7 @@ int conv_precision() {
     g_prec = ADDK_DEFAULT_PRECISION;
     if (e && e[0] == 'f') g_prec = 0;
     else if (e && e[0] == 'b') g_prec = strstr(e, "x3") ? 1 : 2;
+    else if (e && e[0] == 't') g_prec = 3;
   }
   return g_prec;
 }
@@ -535,7 +538,7 @@ __global__ void mfma_selftest_kernel(float* out) {
 }  // namespace
 
 extern "C" int addk_set_conv_precision(int mode) {
-  if (mode < 0 || mode > 2) { addk_set_error("conv precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)"); return ADDK_ERR_INVALID; }
+  if (mode < 0 || mode > 3) { addk_set_error("conv precision must be 0 (fp32), 1 (bf16x3), 2 (bf16x6) or 3 (tail_x3)"); return ADDK_ERR_INVALID; }
   g_prec = mode;
   return ADDK_OK;
 }

@@ -826,6 +826,7 @@ inline int c3_planes(int Cn, int taps) {
   (void)taps;
   if (g_c3b_minc < 0) { const char* e = getenv("ADDK_C3B_MINC"); g_c3b_minc = e ? atoi(e) : 0; }
   if (m == 0 || Cn < g_c3b_minc) return 0;
+  if (m == 3) return Cn >= 192 ? 2 : 3;          // tail_x3: three product terms in the exit heads (ASPP, decoder: 256 / 304 / 400 channels), six elsewhere
   return m == 2 ? 3 : 2;
 }
 // Column block (16-channel tiles per block).  128-channel blocks (2x2 waves) for the wide heads when that still

@@ -31,7 +31,7 @@ struct SepfK {
   double* slab; int slab_ld; int rows;
   const float* ea; const float* eb; int nterm; addk_src term[ADDK_MAX_TERMS];
   int tiles_x, tiles_y, gx;
-  int wt;                    // 1: write-through (sc1) output stores (ADDK_SEPF_WT=1, experiment)
+  int wt;                    // 1 (default): write-through (sc1) output stores, ADDK_SEPF_WT=0 restores write-back ones
   BnFin fin;
 };
 
@@ -360,7 +360,7 @@ bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   { static int fr = -1; if (fr < 0) { const char* e = getenv("ADDK_SEP_R"); fr = e ? atoi(e) : 0; } if (fr == 1 || (fr == 2 && kg == 3)) c.r = fr; }   // tuning aid
   c.io16 = a->io16 ? 1 : 0;
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
-  { static int wt = -1; if (wt < 0) { const char* e = getenv("ADDK_SEPF_WT"); wt = (e && e[0] == '1') ? 1 : 0; } k.wt = wt; }
+  { static int wt = -1; if (wt < 0) { const char* e = getenv("ADDK_SEPF_WT"); wt = (e && e[0] == '0') ? 0 : 1; } k.wt = wt; }
   k.rows = a->stats_rows;
   if (k.slab && k.gx > k.rows) return false;             // the caller sizes the slab with addk_sep_rows
   if (a->fin.a) {

@@ -1550,7 +1550,7 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     done = true; }
   ADDK_OS(1, 4, 2) ADDK_OS(2, 3, 3) ADDK_OS(3, 2, 2) ADDK_OS(4, 4, 4)
 #undef ADDK_OS
-  const int hk_np = addk_get_conv_precision() == 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;
+  const int hk_np = addk_get_conv_precision() >= 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;      // (tail_x3: the cells' convs keep six terms)
 #define ADDK_HKB_(K_, C_, B_, P_) { \
     static bool attr = false; \
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_hkb_kernel<K_, C_, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
@@ -1585,7 +1585,9 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
 #undef ADDK_RS
   // 3x3 convolutions in a split-bf16 mode: the transposed-read kernel — the 128-channel blocks (decoder, ASPP) and the
   // 64-channel blocks (stem1: 0.76 -> 0.61 ms alone; ADDK_WGRAD_SPLIT_NARROW=0 keeps stem1 and the cells' dilated convs on fp32)
-  const int wg_np = addk_get_conv_precision() == 2 ? 3 : addk_get_conv_precision() == 1 ? 2 : 0;
+  const int wg_prec = addk_get_conv_precision();
+  // tail_x3 (mode 3): the 128-channel blocks are the exit heads (decoder, ASPP) -> three terms; stem1's 64-channel blocks keep six
+  const int wg_np = wg_prec == 2 ? 3 : wg_prec == 1 ? 2 : wg_prec == 3 ? (cty == 8 ? 2 : 3) : 0;
 #define ADDK_H3B_(N_, B_, P_) { \
     static bool attr = false; \
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \

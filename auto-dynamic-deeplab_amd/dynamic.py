@@ -21,6 +21,15 @@ class DynamicPlan:
             raise RuntimeError('dynamic_inference gates one image at a time (got batch size %d): the reference\'s '
                                '`if confidence_value > threshold` is ambiguous for more than one value' % x.shape[0])
         self.g = g = Graph(x.device, False, False, None)
+        # the gate scalar travels through pinned host memory: the fused EDM head (csrc/edm.hip) writes it there itself; on the generic path an
+        # asynchronous 4-byte copy does.  Either way the host waits on ONE event, not on the whole device (ADD.py:421 does
+        # `if confidence_value > threshold`, a blocking read)
+        self._conf_host = torch.zeros(1, dtype=torch.float32)
+        self._conf_evt = None
+        if x.is_cuda:                                   # (dry-run planning on CPU in tests/test_plan_dryrun.py builds plans without a device)
+            self._conf_host = self._conf_host.pin_memory()
+            self._conf_evt = torch.cuda.Event()
+        self.conf_fused = []
         a, self.inref = g.input_nchw(x)
         size = (a.H, a.W)
         aspp_size = _aspp_size(size, model.network_arch[-1])          # 2^-last
@@ -36,7 +45,14 @@ class DynamicPlan:
             send = None
             if i in model.C_index or i == model.num_net - 1:
                 if i != model.num_net - 1:
-                    conf = g.output_nchw(edm.emit(g, y))              # EDM applies ReLU to y in place (Q3) ...
+                    g.edm_fused = False
+                    ca = edm.emit(g, y, host_out=self._conf_host if x.is_cuda else None)
+                    self.conf_fused.append(bool(g.edm_fused))
+                    if g.edm_fused:                                   # the head wrote [N,1,1,1] itself (and the pinned word): no layout launch
+                        from .plan import OutRef
+                        conf = OutRef(ca.raw.view().permute(0, 3, 1, 2))
+                    else:
+                        conf = g.output_nchw(ca)                      # EDM applies ReLU to y in place (Q3) ...
                     y = Act(y.raw, y.bn, True, False, rs=y.rs)              # ... so everything downstream sees relu(y)
                     send = y
                     self.trunk_end.append(len(g.fwd))
@@ -57,13 +73,6 @@ class DynamicPlan:
         import os
         g.nstreams = int(os.environ.get('ADDK_STREAMS', '2'))
         self.calls = 0
-        # the gate scalar travels through pinned host memory: an asynchronous 4-byte copy + an event the host waits on, instead of
-        # a blocking read that idles the host until the whole device has drained (ADD.py:421 does `if confidence_value > threshold`)
-        self._conf_host = torch.empty(max(1, x.shape[0]), dtype=torch.float32)
-        self._conf_evt = None
-        if x.is_cuda:                                   # (dry-run planning on CPU in tests/test_plan_dryrun.py builds plans without a device)
-            self._conf_host = self._conf_host.pin_memory()
-            self._conf_evt = torch.cuda.Event()
 
     def check_params(self):
         return all(p.data_ptr() == q for p, q in zip(self.params, self.ptrs))
@@ -107,7 +116,8 @@ class DynamicPlan:
                 conf = self.conf[k].y.reshape(x.shape[0], -1)
                 assert conf.numel() == 1
                 h0, h1 = self.head_rng[k]
-                self._conf_host[:1].copy_(conf.reshape(-1), non_blocking=True)
+                if not self.conf_fused[k]:
+                    self._conf_host[:1].copy_(conf.reshape(-1), non_blocking=True)
                 if self._conf_evt is not None:
                     self._conf_evt.record()
                     self._conf_evt.synchronize()                      # the host waits for this one scalar only

@@ -324,7 +324,13 @@ class EDM(AddkModule):
         self.edm = nn.Sequential(nn.Linear(128, 64), nn.ReLU(inplace=True), nn.Linear(64, 32), nn.ReLU(inplace=True),
                                  nn.Linear(32, 1))
 
-    def emit(self, g, x):
+    def emit(self, g, x, host_out=None):
+        """Inference: ONE launch (plan.Graph.edm_head, csrc/edm.hip).  With gradients (train_edm.py) or shapes the fused kernel does
+        not take: the generic launches below."""
+        fused = g.edm_head(x, self.conv.weight, (self.edm[0], self.edm[2], self.edm[4]), host_out)
+        if fused is not None:
+            g.edm_fused = True
+            return fused
         y = Act(g.conv([x], self.conv.weight, 128, 3, 2, 1, 1, relu_in=True), None, True, g.want_grad)
         v = g.gap(y)
         for i, lin in enumerate((self.edm[0], self.edm[2], self.edm[4])):

@@ -1378,6 +1378,35 @@ class Graph:
             self._bwd_emitters.append(emit_bwd)
         return act
 
+    def edm_head(self, src, conv_w, lins, host_out=None):
+        """The whole Earlier-Decision-Maker head (ADD.py:502-525) as ONE launch (csrc/edm.hip): in-place ReLU, conv 3x3 stride 2 -> 128,
+        ReLU, global average pool, the three Linear layers.  Inference only.  `host_out`: pinned host tensor the confidence is also
+        written to (the gate of dynamic_inference reads it there: no device-to-host copy).  Returns the [N,1,1,1] Act, or None when the
+        kernel does not cover the arguments (the caller then emits the generic launches)."""
+        lib = self.lib
+        if self.want_grad or os.environ.get('ADDK_FUSE_EDM', '1') != '1':
+            return None
+        N, H, W = src.N, src.H, src.W
+        ar = L.EdmArgs()
+        ar.src = self.src(src, True)
+        ar.N, ar.H, ar.W = N, H, W
+        ar.conv_w = self.param(conv_w)
+        (l1, l2, l3) = lins
+        ar.w1, ar.b1, ar.w2, ar.b2, ar.w3, ar.b3 = (self.param(l1.weight), self.param(l1.bias), self.param(l2.weight), self.param(l2.bias),
+                                                    self.param(l3.weight), self.param(l3.bias))
+        out = self.tensor(N, 1, 1, 1)
+        ws = self.buf((int(lib.addk_edm_head_ws_bytes(N, H, W)) + 3) // 4, zero=True)
+        ar.out, ar.ws = out.ptr, ws.ptr
+        ar.out_host = host_out.data_ptr() if host_out is not None else None
+        shapes_ok = (tuple(conv_w.shape[:1]) == (128,) and conv_w.numel() == 128 * 9 * src.C and tuple(l1.weight.shape) == (64, 128)
+                     and tuple(l2.weight.shape) == (32, 64) and tuple(l3.weight.shape) == (1, 32))
+        if not shapes_ok or int(lib.addk_edm_head_supported(C.byref(ar))) != 1:
+            return None
+        self.keep += [ar, host_out]
+        self._add(self.fwd, 'edm_head', lib.addk_edm_head, C.byref(ar),
+                  rd=self.lz(src) + [conv_w, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias], wr=[out, ws])
+        return Act(out, None, False, False)
+
     def pool3(self, src, stride, mode):
         lib = self.lib
         N, H, W, Cc = src.N, src.H, src.W, src.C

@@ -398,6 +398,39 @@ def timed_region(ts, steps, warmup, world, rank, barrier, max_over_ranks, contra
     return dt, modes, losses
 
 
+def tail_x3_step(genotype, a, x, t, dev, steps=10):
+    """Second value beside the headline (NOT the headline): the same step with three product terms in the exit heads only (`tail_x3`: ASPP
+    and decoder forward, data and weight gradients; six terms everywhere else).  Its parity gates are the bf16x6 ones, unchanged
+    (tests/test_gpu_parity.py::test_tail_x3_..., tests/test_gpu_round3.py::test_tail_x3_...)."""
+    import addk
+    from addk.modeling.ADD import ADD
+    from addk.train import TrainStep
+    prev = addk.get_precision()
+    try:
+        addk.set_precision('tail_x3')
+        m = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F), 0)
+        init_weights(m)
+        m.to(dev)
+        ts = TrainStep(m, tuple(x.shape), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True)
+        ts.load_batch(x, t)
+        losses = []
+        for i in range(3):
+            ts.step()
+            if i < 2:
+                losses.append(float(ts.loss.item()))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ts.close()
+        return {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'first_step_losses': losses,
+                'what': 'three bf16 product terms in ASPP + decoder (fwd, dgrad, wgrad), six elsewhere; fp32 storage and accumulation'}
+    finally:
+        addk.set_precision(prev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -411,7 +444,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the segment roofline / per-exit latency / drop-in measurements')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--math', choices=['fp32', 'bf16x6', 'bf16x3'], default=None,
+    ap.add_argument('--math', choices=['fp32', 'bf16x6', 'bf16x3', 'tail_x3'], default=None,
                     help='arithmetic of the wide k x k contractions (default: the library default, see addk.get_precision())')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--extras-child', action='store_true', help=argparse.SUPPRESS)
@@ -473,6 +506,8 @@ def main():
             guarded('segment_train', lambda: segment_roofline(model, x, 'train'))
         guarded('per_exit_ms', lambda: per_exit_latency(model, dev))
         guarded('drop_in', lambda: drop_in_step(model, x, t))
+        if math == 'bf16x6':
+            guarded('tail_x3', lambda: tail_x3_step(genotype, a, x, t, dev))
         json_out.write(json.dumps(res) + '\n')
         json_out.flush()                               # before the last, least proven extra: a crash there keeps the others
         guarded('ddp_path_world1', lambda: ddp_path_world1(genotype, a, x, t, dev))
@@ -525,7 +560,7 @@ def main():
     tk = time_launch(top['cmd'])
     fwd_flops = sum(m['flops'] for m in convs)
     halo = bool(top.get('halo'))
-    terms = {'fp32': 1, 'bf16x6': 6, 'bf16x3': 3}[math] if halo else 1
+    terms = {'fp32': 1, 'bf16x6': 6, 'bf16x3': 3, 'tail_x3': 3}[math] if halo else 1          # (the dominant launch is a decoder conv: a tail launch)
     if terms == 1:
         peak, kern = PEAK_MFMA_F32_TFLOPS, ('conv3_kernel' if halo else 'conv_kernel') + ' (v_mfma_f32_16x16x4_f32)'
         peak_note = 'fp32 matrix peak'
@@ -611,6 +646,9 @@ def main():
             roof['segment'] = {'error': str(merged.get('segment_eval', merged.get('error', 'extras child produced no output')))}
         for key in ('per_exit_ms', 'drop_in', 'ddp_path_world1'):
             out[key] = merged.get(key, {'error': merged.get('error', 'extras child produced no output')})
+        if isinstance(merged.get('tail_x3'), dict) and 'ms_per_step' in merged['tail_x3']:
+            out['ms_per_step_by_mode']['tail_x3'] = merged['tail_x3']['ms_per_step']          # a second value; `value` / `dtype` stay the bf16x6 ones
+            out['tail_x3'] = merged['tail_x3']
     if not a.no_cpu_baseline and world == 1 and default_cfg:
         cb = cpu_baseline(n, h, w)
         out['cpu_baseline'] = cb

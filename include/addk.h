@@ -126,9 +126,12 @@ int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a);
  *   2 = split-bf16, six terms (default): every fp32 operand is x = h + m + l with h, m, l in bf16 (3 x 8 bits = fp32's 24, exact)
  *       and a product is the sum of its six largest bf16 x bf16 terms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation —
  *       as accurate as the fp32 MFMA chain (rms 5.6e-8 vs 6.8e-8 of sum|a*b| at K = 2048) at 2.5x its rate;
- *   1 = three terms (h*h, h*m, m*h): fast mode, rms ~5e-7.
+ *   1 = three terms (h*h, h*m, m*h): fast mode, rms ~5e-7;
+ *   3 = "tail_x3": three terms in the exit heads only (launches with >= 192 output / gradient channels: ASPP and decoder forward,
+ *       data gradient and weight gradient — decoder.py:14-21, aspp_train.py:16-25), six terms everywhere else.  The reference's own
+ *       GPU path is 16-bit throughout (apex O1, train.py:145-165); this mode spends the short products where nothing amplifies them.
  * Every other kernel computes in fp32.  Process-wide; set before plans are built (packed-weight buffers are sized per mode).
- * Environment: ADDK_MATH=fp32|bf16x6|bf16x3. */
+ * Environment: ADDK_MATH=fp32|bf16x6|bf16x3|tail_x3. */
 int addk_set_conv_precision(int mode);
 /* Split-bf16 modes: launches with fewer output channels than this stay on the exact fp32 kernel (default 0 = none, see
  * conv3.hip; 65 = round-2's first rule, kept for A/B runs).  c < 0 restores the default. */
@@ -483,6 +486,26 @@ int addk_ce_upsample_fwd_bwd(const addk_ce_upsample_args* a, void* stream);
  * ------------------------------------------------------------------------------------- */
 int addk_sgd_step(float* p, const float* g, float* buf, int64_t n, const float* lr_dev, float momentum,
                   float weight_decay, int32_t nesterov, int32_t first, float gscale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Earlier-Decision-Maker head in ONE launch (ADD.py:502-525, the gate of dynamic_inference ADD.py:420-423):
+ *   relu?(a*x+b) -> conv 3x3 stride 2 pad 1, C -> 128, no bias -> ReLU -> global average pool -> Linear 128-64 -> ReLU
+ *   -> Linear 64-32 -> ReLU -> Linear 32-1.   out[n] = confidence of image n.
+ * conv_w: [128][3][3][C] (a torch [128,C,3,3] tensor in channels_last memory); w1 [64][128], w2 [32][64], w3 [1][32] row-major
+ * (torch Linear weights), b1/b2/b3 their biases.  ws: addk_edm_head_ws_bytes() bytes, ZERO-initialised once (the kernel leaves its
+ * ticket word at zero, so the launch can be replayed from a hipGraph).  out_host: optional host-mapped (pinned) word the confidence is
+ * ALSO written to — the host gate then needs no device-to-host copy, only the completion of the launch.
+ * ------------------------------------------------------------------------------------- */
+typedef struct addk_edm_args {
+  addk_src src; int32_t N, H, W; int32_t _pad;
+  const float* conv_w;
+  const float* w1; const float* b1; const float* w2; const float* b2; const float* w3; const float* b3;
+  float* out; float* out_host;
+  void* ws;
+} addk_edm_args;
+int64_t addk_edm_head_ws_bytes(int32_t N, int32_t H, int32_t W);
+int addk_edm_head_supported(const addk_edm_args* a);
+int addk_edm_head(const addk_edm_args* a, void* stream);
 
 /* misc */
 int addk_fill(float* p, int64_t n, float v, void* stream);

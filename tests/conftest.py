@@ -11,6 +11,15 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle's thread pool: the GPU box grants a 16-core share of a much larger host, and torch's default (one thread per
+    # host core) oversubscribes it — the F = 4 oracle passes of the gradient gates took 20 s each there against 2 s in the 8-core
+    # build container
+    try:
+        import torch
+        n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(16, n)))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope='session')

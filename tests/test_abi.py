@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
                'addk_conv_wgrad_args': L.ConvWgradArgs, 'addk_dw_args': L.DwArgs, 'addk_sep_args': L.SepArgs, 'addk_sep_bwd_args': L.SepBwdArgs, 'addk_ce_upsample_args': L.CeUpsampleArgs, 'addk_dw_bwd_args': L.DwBwdArgs,
                'addk_bn_finalize_args': L.BnFinalizeArgs, 'addk_bn_bwd_args': L.BnBwdArgs,
                'addk_affine_sum_args': L.AffineSumArgs, 'addk_affine_sum_bwd_args': L.AffineSumBwdArgs,
-               'addk_resize_args': L.ResizeArgs, 'addk_resize_bwd_args': L.ResizeBwdArgs,
+               'addk_resize_args': L.ResizeArgs, 'addk_edm_args': L.EdmArgs, 'addk_resize_bwd_args': L.ResizeBwdArgs,
                'addk_dw_wreduce_item': L.DwWreduceItem, 'addk_bn_apply_item': L.BnApplyItem,
                'addk_slab_reduce_item': L.SlabReduceItem, 'addk_bn_coeffs_item': L.BnCoeffsItem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "addk.h"', 'int main(void){']

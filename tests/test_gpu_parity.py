@@ -388,6 +388,19 @@ def test_add_whole_net_frozen_bn_gradients(dev, Fv, hw):
         assert gm([r[0] for r in ratios]) <= 2 and gm([r[1] for r in ratios]) <= 1.75, ratios
 
 
+def test_tail_x3_mode_holds_the_frozen_bn_gradient_gate(dev):
+    """`tail_x3` (three product terms in the exit heads — ASPP and decoder forward, data and weight gradients — six everywhere else; VERDICT
+    r03 item 8): the 2x512x1024 frozen-BatchNorm gate at its UNCHANGED bounds (max / median of 440 conv-weight gradients within 3x / 2.5x the
+    fp32 oracle's own distance to the reference's fp64 per draw, every gradient elementwise to 1e-2).  The heads sit at the end of the
+    network, where nothing amplifies their rounding; the reference's own GPU path is 16-bit throughout (apex O1, train.py:145-165)."""
+    import addk
+    try:
+        addk.set_precision('tail_x3')
+        test_add_whole_net_frozen_bn_gradients(dev, 20, (512, 1024))
+    finally:
+        addk.set_precision('bf16x6')
+
+
 @pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])
 def test_add_f40_config5_eval(dev, gname):
     """BASELINE config 5 architecture (F=40, searched_arch/40_5e_38_lr genotypes, three unsorted pairs: Q1), eval forward

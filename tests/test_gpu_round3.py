@@ -121,6 +121,17 @@ def test_full_size_frozen_bn_gradients_on_sentinel_convs(dev):
     _log('config2 2x1024x2048 frozen-BN sentinel gradients: worst ratio to the fp32 oracle %.2f', worst)
 
 
+def test_tail_x3_mode_holds_the_full_size_sentinel_gate(dev):
+    """`tail_x3` at the headline shape: the 14 sentinel conv-weight gradients of config 2 at 2x1024x2048 within 4x the fp32 oracle's own error
+    against the reference's fp64 — the bf16x6 gate, unchanged."""
+    import addk
+    try:
+        addk.set_precision('tail_x3')
+        test_full_size_frozen_bn_gradients_on_sentinel_convs(dev)
+    finally:
+        addk.set_precision('bf16x6')
+
+
 def _structured_images(n, hw, seed):
     """Smooth random fields + a little noise: predictions get spatial structure (regions), like a street scene, not salt-and-pepper."""
     g = torch.Generator().manual_seed(seed)

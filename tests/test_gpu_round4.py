@@ -179,3 +179,69 @@ def test_whole_network_fold_on_equals_fold_off(dev, monkeypatch):
         assert torch.equal(ya, yb)
     assert a[1] == b[1]
     assert torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 128), (1, 65, 129), (2, 33, 65), (3, 8, 12)], ids=['config4_1024x2048', 'config4_1025x2049', 'bs2_odd', 'bs3_tiny'])
+def test_fused_edm_head_matches_oracle_and_generic_path(dev, shape, monkeypatch):
+    """The Earlier-Decision-Maker head as ONE launch (csrc/edm.hip; reference ADD.py:502-525) against oracle.EDM (pinned to the reference by
+    tests/golden/dynamic.npz) and against the five generic launches it replaces; the plan holds a single `edm_head` command, the result is
+    bit-identical run to run (the last-arriving workgroup adds the partial rows in a fixed order) and the ticket word is back at zero."""
+    import oracle
+    from _util import fill_params
+    from addk.modeling.ADD import EDM
+    N, H, W = shape
+    eo = oracle.EDM()
+    fill_params(eo, 701)
+    eo.eval()
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.randn(N, 400, H, W, generator=g)
+    with torch.no_grad():
+        ref = eo(x.clone())
+    outs = {}
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('ADDK_FUSE_EDM', fuse)
+        ea = EDM()
+        ea.load_state_dict(eo.state_dict())
+        ea.to(dev).eval()
+        with torch.no_grad():
+            y1 = ea(x.clone().to(dev)).clone()
+            y2 = ea(x.clone().to(dev)).clone()
+        plan = next(iter(ea._plans().values()))
+        names = [c.name for c in plan.g.fwd]
+        if fuse == '1':
+            assert names.count('edm_head') == 1 and not any(n.startswith(('conv', 'gap')) for n in names), names
+        else:
+            assert 'edm_head' not in names
+        assert torch.equal(y1, y2)
+        outs[fuse] = y1.cpu()
+    assert tuple(outs['1'].shape) == tuple(ref.shape) == (N, 1)
+    e_ref = float((outs['1'].double() - ref.double()).abs().max() / ref.double().abs().max())
+    e_gen = float((outs['1'].double() - outs['0'].double()).abs().max() / ref.double().abs().max())
+    assert e_ref < 1e-4 and e_gen < 1e-4, (e_ref, e_gen)
+
+
+def test_dynamic_inference_gate_reads_the_pinned_word_the_fused_head_writes(dev):
+    """config 4 plumbing: DynamicPlan hands the fused head a pinned host word; after the trunk segment's event the host reads the SAME value
+    the device tensor holds, for the eager calls and for the captured hipGraph replays alike, and the exit decision follows the threshold."""
+    import oracle
+    from _util import ARCH_C2, GENOTYPE_AUTODEEPLAB, fill_params, make_args, rand_tensor
+    from addk.modeling.ADD import ADD, EDM
+    m = ADD(ARCH_C2['network_arch'], ARCH_C2['C_index'], GENOTYPE_AUTODEEPLAB, 19, make_args(20), 0)
+    fill_params(m, 12)
+    m.to(dev).eval()
+    e = EDM(); fill_params(e, 701); e.to(dev).eval()
+    x = rand_tensor(9, 'dynx', (1, 3, 129, 257)).to(dev)
+    with torch.no_grad():
+        confs = []
+        for call in range(5):                      # calls 3+ replay captured graphs
+            y, early, secs, conf = m.dynamic_inference(x, threshold=1e9, confidence='edm', edm=e)
+            plan = m._dynamic_plan(x, e)
+            assert plan.conf_fused == [True]
+            assert early == 0 or early == 1
+            confs.append(float(conf.reshape(-1)[0]))
+            assert float(plan._conf_host[0]) == confs[-1], (float(plan._conf_host[0]), confs[-1])
+        assert len(set(confs)) == 1
+        c = confs[0]
+        # ADD.py:421: `if confidence_value > threshold` the image goes ON to the next cells; otherwise it leaves at this exit
+        assert m.dynamic_inference(x, threshold=c - 1.0, confidence='edm', edm=e)[1] == 0
+        assert m.dynamic_inference(x, threshold=c + 1.0, confidence='edm', edm=e)[1] == 1
