@@ -116,7 +116,7 @@ class AffineSumBwdArgs(C.Structure):
 
 
 class EdmArgs(C.Structure):
-    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('_pad', i32), ('conv_w', vp), ('w1', vp), ('b1', vp), ('w2', vp), ('b2', vp),
+    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('ldo', i32), ('conv_w', vp), ('w1', vp), ('b1', vp), ('w2', vp), ('b2', vp),
                 ('w3', vp), ('b3', vp), ('out', vp), ('out_host', vp), ('ws', vp)]
 
 

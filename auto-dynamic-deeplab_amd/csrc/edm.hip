@@ -29,7 +29,7 @@ struct EdmK {
   const float* w1; const float* b1; const float* w2; const float* b2; const float* w3; const float* b3;
   float* partial;                                  // [N][tiles_img][128]
   unsigned* counter;
-  float* out; float* out_host;
+  float* out; int ldo; float* out_host;
   int tiles_img, ngroups;                          // 16-pixel tiles per image; 16-channel groups per tap
 };
 
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) edm_head_kernel(const EdmK p) {
     if (t == 0) {
       float s = ((const gfloat*)p.b3)[0];
       for (int k = 0; k < EDM_H2; ++k) s = fmaf(((const gfloat*)p.w3)[k], v2[k], s);
-      ((gfloat*)p.out)[img] = s;
+      ((gfloat*)p.out)[(long)img * p.ldo] = s;
       if (p.out_host) { p.out_host[img] = s; }
     }
     __syncthreads();
@@ -149,7 +149,7 @@ bool edm_fill(const addk_edm_args* a, EdmK& k) {
   if (!a || a->N <= 0 || a->H <= 1 || a->W <= 1) return false;
   const addk_src& s = a->src;
   if (!s.x || s.C < 16 || s.rs_hw || !src_vec_ok(s) || (s.a == nullptr) != (s.b == nullptr)) return false;
-  if (!a->conv_w || !aligned16(a->conv_w) || (9 * s.C) % 4 || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->w3 || !a->b3 || !a->out || !a->ws) return false;
+  if (!a->conv_w || !aligned16(a->conv_w) || (9 * s.C) % 4 || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->w3 || !a->b3 || !a->out || a->ldo < 1 || !a->ws) return false;
   k = EdmK{};
   k.src = s; k.N = a->N; k.H = a->H; k.W = a->W; k.C = s.C;
   k.OH = (a->H + 2 - 3) / 2 + 1; k.OW = (a->W + 2 - 3) / 2 + 1;
@@ -159,7 +159,7 @@ bool edm_fill(const addk_edm_args* a, EdmK& k) {
   if ((long)a->N * k.tiles_img > 65535L * 16) return false;
   k.counter = (unsigned*)a->ws;
   k.partial = (float*)((char*)a->ws + 16);
-  k.out = a->out; k.out_host = a->out_host;
+  k.out = a->out; k.ldo = a->ldo; k.out_host = a->out_host;
   return true;
 }
 

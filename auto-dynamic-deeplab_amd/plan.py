@@ -1396,7 +1396,7 @@ class Graph:
                                                     self.param(l3.weight), self.param(l3.bias))
         out = self.tensor(N, 1, 1, 1)
         ws = self.buf((int(lib.addk_edm_head_ws_bytes(N, H, W)) + 3) // 4, zero=True)
-        ar.out, ar.ws = out.ptr, ws.ptr
+        ar.out, ar.ldo, ar.ws = out.ptr, out.ld, ws.ptr
         ar.out_host = host_out.data_ptr() if host_out is not None else None
         shapes_ok = (tuple(conv_w.shape[:1]) == (128,) and conv_w.numel() == 128 * 9 * src.C and tuple(l1.weight.shape) == (64, 128)
                      and tuple(l2.weight.shape) == (32, 64) and tuple(l3.weight.shape) == (1, 32))

@@ -490,14 +490,15 @@ int addk_sgd_step(float* p, const float* g, float* buf, int64_t n, const float* 
 /* ---------------------------------------------------------------------------------------
  * Earlier-Decision-Maker head in ONE launch (ADD.py:502-525, the gate of dynamic_inference ADD.py:420-423):
  *   relu?(a*x+b) -> conv 3x3 stride 2 pad 1, C -> 128, no bias -> ReLU -> global average pool -> Linear 128-64 -> ReLU
- *   -> Linear 64-32 -> ReLU -> Linear 32-1.   out[n] = confidence of image n.
+ *   -> Linear 64-32 -> ReLU -> Linear 32-1.   out[n * ldo] = confidence of image n.
  * conv_w: [128][3][3][C] (a torch [128,C,3,3] tensor in channels_last memory); w1 [64][128], w2 [32][64], w3 [1][32] row-major
  * (torch Linear weights), b1/b2/b3 their biases.  ws: addk_edm_head_ws_bytes() bytes, ZERO-initialised once (the kernel leaves its
  * ticket word at zero, so the launch can be replayed from a hipGraph).  out_host: optional host-mapped (pinned) word the confidence is
  * ALSO written to — the host gate then needs no device-to-host copy, only the completion of the launch.
  * ------------------------------------------------------------------------------------- */
 typedef struct addk_edm_args {
-  addk_src src; int32_t N, H, W; int32_t _pad;
+  addk_src src; int32_t N, H, W;
+  int32_t ldo;                /* out[n * ldo] = confidence of image n (an [N,1,1,1] NHWC tensor with a padded pixel stride); >= 1 */
   const float* conv_w;
   const float* w1; const float* b1; const float* w2; const float* b2; const float* w3; const float* b3;
   float* out; float* out_host;
