@@ -204,6 +204,9 @@ _SIGS = {
     'addk_bn_bwd_apply': (i32, [vp, i32, vp, i32, vp, vp, vp, i64, i32, vp, i32, vp]),
     'addk_resize_fwd': (i32, [C.POINTER(ResizeArgs), vp]),
     'addk_resize_bwd': (i32, [C.POINTER(ResizeBwdArgs), vp]),
+    'addk_resize_bwd_batch_key': (i32, [C.POINTER(ResizeBwdArgs)]),
+    'addk_resize_bwd_batch_prepare': (i64, [vp, i32, vp, i64, vp]),
+    'addk_resize_bwd_batch_run': (i32, [vp, vp, vp]),
     'addk_gap_fwd': (i32, [C.POINTER(Src), i32, i32, vp, i32, vp, i32, vp]),
     'addk_gap_bwd': (i32, [C.POINTER(Src), i32, i32, vp, i32, vp, i32, i32, vp, vp]),
     'addk_pool3_fwd': (i32, [C.POINTER(Src), i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),

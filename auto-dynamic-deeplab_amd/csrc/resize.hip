@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const RsK p) {
 constexpr int RT_MAXW = 128;
 // MT: taps per axis an input pixel can receive from — 5 up to x2 up-sampling, 9 up to x4, 17 up to x8 (the resizes in front of ASPP)
 template <int MT>
-__global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int tiles_per_row, int ntiles, int tw) {
+__device__ __forceinline__ void resize_bwd_tab_body(const RsK& p, int tiles_per_row, int ntiles, int tw, const int bx, const int gx) {      // workgroup bx of gx
   extern __shared__ double redt[];       // [npl][C4][2]
   __shared__ float wt_w[RT_MAXW][MT], wt_h[MT];
   __shared__ int lo_w[RT_MAXW], n_w[RT_MAXW], lo_h, n_h;
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int ti
   float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
   double sA[4] = {0.0, 0.0, 0.0, 0.0}, sB[4] = {0.0, 0.0, 0.0, 0.0};
   if (active && p.src.a) { av = ld4(p.src.a + c); bv = ld4(p.src.b + c); }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = bx; tile < ntiles; tile += gx) {
     const int rowid = tile / tiles_per_row, seg = tile - rowid * tiles_per_row;
     const int n = rowid / p.H, ih = rowid - n * p.H, iw0 = seg * tw;
     __syncthreads();                                   // the previous segment's readers are done with the tables
@@ -409,9 +409,23 @@ __global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int ti
       const int ch = k >> 1, ab = k & 1;
       double acc = 0.0;
       for (int r = 0; r < p.npl; ++r) acc += redt[((r * C4) + ch) * 2 + ab];
-      p.dab[(long)blockIdx.x * C * 2 + k] = acc;
+      p.dab[(long)bx * C * 2 + k] = acc;
     }
   }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(256) resize_bwd_tab_kernel(const RsK p, int tiles_per_row, int ntiles, int tw) {
+  resize_bwd_tab_body<MT>(p, tiles_per_row, ntiles, tw, blockIdx.x, gridDim.x);
+}
+// [r4] the mutually independent resize backwards of one dependency level (a dense-in cell receives up to ten resized feature maps,
+// ADD.py:84-90: ten gathers of 15-18 us, each little more than its launch floor) in ONE launch: block (x, z) = workgroup x of table entry z
+struct RsTabItem { RsK p; int tpr, ntiles, tw, rows; };
+template <int MT>
+__global__ void __launch_bounds__(256) resize_bwd_tab_batch_kernel(const RsTabItem* __restrict__ tab) {
+  const RsTabItem& e = tab[blockIdx.z];
+  if ((int)blockIdx.x >= e.rows) return;
+  resize_bwd_tab_body<MT>(e.p, e.tpr, e.ntiles, e.tw, blockIdx.x, e.rows);
 }
 
 int rs_rows(long P, int C) {
@@ -422,7 +436,65 @@ int rs_rows(long P, int C) {
   return (int)r;
 }
 
+// table-driven backward: 0 = not covered, else the taps-per-axis variant (5 / 9 / 17); fills the launch geometry
+int rs_tab_config(const addk_resize_bwd_args* a, RsK& k, RsTabItem& it, size_t& sh) {
+  if (!a || a->nchw_in || !a->dy || !a->g || a->src.C <= 0 || a->src.C > 1024 || a->ldg < a->src.C || a->lddy < a->src.C) return 0;
+  if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->OH <= 0 || a->OW <= 0) return 0;
+  if ((a->src.relu || a->dab) && !(a->src.x && a->src.ld >= a->src.C)) return 0;
+  if ((a->src.a == nullptr) != (a->src.b == nullptr)) return 0;
+  k = RsK{};
+  k.src = a->src; k.N = a->N; k.H = a->H; k.W = a->W; k.OH = a->OH; k.OW = a->OW;
+  k.dy = a->dy; k.lddy = a->lddy; k.dy_scale = a->dy_scale; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate; k.dab = (double*)a->dab;
+  k.P = (long)a->N * a->H * a->W;
+  EwMap m = ew_map(a->src.C); k.nq = m.nq; k.npl = m.npl;
+  k.vec = aligned16(a->dy) && a->lddy % 4 == 0 && aligned16(a->g) && a->ldg % 4 == 0 && a->src.C % 4 == 0 && (!a->src.x || src_vec_ok(a->src));
+  const bool up2 = a->OH <= 2 * a->H + 1 && a->OW <= 2 * a->W + 1, up4 = a->OH <= 4 * a->H + 1 && a->OW <= 4 * a->W + 1,
+             up8 = a->OH <= 8 * a->H + 1 && a->OW <= 8 * a->W + 1;
+  if (!(k.vec && a->src.C == m.nq * 4 && m.npl >= 2 && (up2 || up4 || up8) && (addk_get_fast_paths() & ADDK_FAST_DWTILE) && k.P < (1L << 30))) return 0;
+  int tw = m.npl >= 4 ? m.npl * 4 : m.npl * 8; if (tw > RT_MAXW) tw = RT_MAXW; if (tw > a->W) tw = a->W;      // (2-3 pixel lanes: 260-512 channels)
+  it.tpr = cdiv(a->W, tw); it.ntiles = a->N * a->H * it.tpr; it.tw = tw; it.rows = rs_rows(k.P, a->src.C);
+  it.p = k;
+  sh = (size_t)m.npl * m.nq * 4 * 2 * sizeof(double);
+  return up2 ? 5 : up4 ? 9 : 17;
+}
+
 }  // namespace
+
+// batched form: key >= 0 (the kernel variant) when the launch runs on the table-driven kernel and may share a batch
+extern "C" int addk_resize_bwd_batch_key(const addk_resize_bwd_args* a) {
+  RsK k; RsTabItem it; size_t sh;
+  return rs_tab_config(a, k, it, sh) > 0 ? rs_tab_config(a, k, it, sh) : -1;
+}
+// host_blob = NULL: returns the blob size in bytes.  meta[0..3] = variant, n, grid x, dynamic LDS bytes
+extern "C" int64_t addk_resize_bwd_batch_prepare(const addk_resize_bwd_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
+  if (!a || n <= 0 || !meta) { addk_set_error("resize_bwd_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
+  const int64_t total = (int64_t)n * sizeof(RsTabItem);
+  if (host_blob && blob_bytes < total) { addk_set_error("resize_bwd_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
+  int key0 = -1, gx = 0; size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    RsK k; RsTabItem it; size_t sh;
+    const int key = rs_tab_config(&a[i], k, it, sh);
+    if (key <= 0) { addk_set_error("resize_bwd_batch_prepare: launch %d is not a table-driven shape", i); return ADDK_ERR_INVALID; }
+    if (i == 0) key0 = key;
+    if (key != key0) { addk_set_error("resize_bwd_batch_prepare: mixed kernel variants"); return ADDK_ERR_INVALID; }
+    if (it.rows > gx) gx = it.rows;
+    if (sh > lds) lds = sh;
+    if (host_blob) reinterpret_cast<RsTabItem*>(host_blob)[i] = it;
+  }
+  meta[0] = key0; meta[1] = n; meta[2] = gx; meta[3] = (int64_t)lds;
+  return total;
+}
+extern "C" int addk_resize_bwd_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
+  ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "resize_bwd_batch_run: bad args");
+  const RsTabItem* tab = reinterpret_cast<const RsTabItem*>(dev_blob);
+  const dim3 grid((unsigned)meta[2], 1, (unsigned)meta[1]);
+  hipStream_t st = (hipStream_t)stream;
+  if (meta[0] == 5) hipLaunchKernelGGL(resize_bwd_tab_batch_kernel<5>, grid, dim3(256), (size_t)meta[3], st, tab);
+  else if (meta[0] == 9) hipLaunchKernelGGL(resize_bwd_tab_batch_kernel<9>, grid, dim3(256), (size_t)meta[3], st, tab);
+  else if (meta[0] == 17) hipLaunchKernelGGL(resize_bwd_tab_batch_kernel<17>, grid, dim3(256), (size_t)meta[3], st, tab);
+  else { addk_set_error("resize_bwd_batch_run: unknown variant %d", (int)meta[0]); return ADDK_ERR_INVALID; }
+  return addk_check_launch("resize_bwd_batch");
+}
 
 extern "C" int addk_resize_fwd(const addk_resize_args* a, void* stream) {
   if (a && a->src.C > 1024 && !a->nchw_out) {      // wide concat buffers (F=40, level 3: 1600 channels): 1024-channel slices

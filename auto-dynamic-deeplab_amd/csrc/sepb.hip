@@ -68,9 +68,32 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   const int ty = b % p.tiles_y; const int n = b / p.tiles_y;
   const int ih0 = ty * (4 * R), iw0 = tx * 16;
 
-  // ---- weights -> LDS ----
-  for (int i = t; i < G::DWL; i += 256) dwl[i] = 0.f;
-  __syncthreads();
+  // ---- [r4] the first stage-1 tile's dy quads are requested before anything else: they travel while the weights are staged ----
+  auto dy_geom = [&](int j, const float*& dp, const float*& yp, bool& ok) {
+    const int pix = 16 * j + li;
+    const int pr = pix / PW, pc = pix - pr * PW;
+    const int oh = ih0 - HK + pr, ow = iw0 - HK + pc;
+    ok = j < G::NT16 && pix < NPIX && (unsigned)oh < (unsigned)p.H && (unsigned)ow < (unsigned)p.W;
+    dp = p.dy + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.lddy : 0);
+    yp = (FOLD && p.fold.y) ? p.fold.y + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.fold.ldy : 0) : p.dy;
+  };
+  auto dy_load = [&](int j, float4 (&d)[KG]) {
+    const float* dp; const float* yp; bool ok;
+    dy_geom(j, dp, yp, ok);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const int k = 16 * g + 4 * kq;
+      d[g] = ld4(dp + ((ok && k < C) ? k : 0));
+    }
+  };
+  float4 dcur[KG], dnxt[KG];
+  dy_load(wave, dcur);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- weights -> LDS (the tap table's channels beyond C are zeroed by threads that write no weight there: no barrier in between) ----
+  for (int i = t; i < NT * (KG * 16 - C); i += 256) {
+    const int tp = i / (KG * 16 - C), c = C + i - tp * (KG * 16 - C);
+    dwl[tp * (KG * 16) + c] = 0.f;
+  }
   for (int i = t; i < C * NT; i += 256) {
     const int c = i / NT, tp = i - c * NT;
     dwl[(NT - 1 - tp) * (KG * 16) + c] = ((const gfloat*)p.dww)[i];
@@ -107,17 +130,15 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   }
   for (int j = wave; j < G::NT16; j += 4) {
     const int pix = 16 * j + li;
-    const int pr = pix / PW, pc = pix - pr * PW;
-    const int oh = ih0 - HK + pr, ow = iw0 - HK + pc;
-    const bool ok = pix < NPIX && (unsigned)oh < (unsigned)p.H && (unsigned)ow < (unsigned)p.W;
-    const float* dp = p.dy + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.lddy : 0);
-    const float* yp = fold ? p.fold.y + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.fold.ldy : 0) : p.dy;
+    const float* dp; const float* yp; bool ok;
+    dy_geom(j, dp, yp, ok);
+    dy_load(j + 4, dnxt);                                  // the next tile of this wave: in flight under this tile's matrix work (masked beyond the patch)
     float4 d[KG];
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const int k = 16 * g + 4 * kq;
       const bool okk = ok && k < C;
-      float4 v = ld4(dp + (okk ? k : 0));
+      float4 v = dcur[g];
       if (fold) {
         const float4 y = ld4(yp + (okk ? k : 0));
         v.x += fmaf(f2[g].x, y.x - fm[g].x, f1[g].x); v.y += fmaf(f2[g].y, y.y - fm[g].y, f1[g].y);
@@ -125,6 +146,7 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
       }
       v.x = okk ? v.x : 0.f; v.y = okk ? v.y : 0.f; v.z = okk ? v.z : 0.f; v.w = okk ? v.w : 0.f;
       d[g] = v;
+      dcur[g] = dnxt[g];
     }
     f32x4 acc[CT];
 #pragma unroll
@@ -161,6 +183,21 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   double (*rd)[KG * 16][2] = reinterpret_cast<double (*)[KG * 16][2]>(red);
   // real loops over the channel group and the kernel row: fully unrolled, hipcc hoists every LDS read of the 15 (group, row)
   // bodies to the top (234-256 VGPRs and scratch spills for KS = 5); one body at a time needs ~100
+  // [r4] the operands of the NEXT channel group (input values, the gradient to accumulate into) are requested at the top of a group's
+  // body and arrive under its LDS / VALU work: the loop used to open with a dependent round trip per group and close with another
+  float4 xn[R], on[R];
+  auto pre = [&](int g) {
+    const int q = 4 * g + kq;
+    const bool cok = g < KG && 4 * q < C;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool okx = pin[r] && cok;
+      xn[r] = ld4(p.src.x + (okx ? (long)pp[r] * p.src.ld + 4 * q : 0));
+      on[r] = zero4();
+      if (p.g && p.accumulate) on[r] = ld4(p.g + (okx ? (long)pp[r] * p.ldg + 4 * q : 0));
+    }
+  };
+  pre(0);
 #pragma unroll 1
   for (int g = 0; g < KG; ++g) {
     const int q = 4 * g + kq;
@@ -168,11 +205,13 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
     const bool cok = 4 * q < C;
     float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
     if (p.src.a && cok) { av = ld4(p.src.a + 4 * q); bv = ld4(p.src.b + 4 * q); }
-    float4 x[R], z[R], dz[R]; bool m[R][4];
+    float4 x[R], z[R], dz[R], oacc[R]; bool m[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { x[r] = xn[r]; oacc[r] = on[r]; }
+    pre(g + 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const bool okx = pin[r] && cok;
-      x[r] = ld4(p.src.x + (okx ? (long)pp[r] * p.src.ld + 4 * q : 0));
       const float4 zp = fma4b(av, x[r], bv);
 #pragma unroll
       for (int e = 0; e < 4; ++e) m[r][e] = okx && (!relu || get4(zp, e) > 0.f);
@@ -216,7 +255,7 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
       if (p.g && pin[r] && cok) {
         float4 gv = make_float4(gm.x * av.x, gm.y * av.y, gm.z * av.z, gm.w * av.w);
         float* gp = p.g + (long)pp[r] * p.ldg + 4 * q;
-        if (p.accumulate) { const float4 o = ld4(gp); gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
+        if (p.accumulate) { const float4 o = oacc[r]; gv.x += o.x; gv.y += o.y; gv.z += o.z; gv.w += o.w; }
         st4(gp, gv);
       }
     }

@@ -380,6 +380,7 @@ class Graph:
                 'dw_fwd': ('addk_dw_fwd_batch_prepare', 'addk_dw_batch_run'), 'dw_bwd': ('addk_dw_bwd_batch_prepare', 'addk_dw_batch_run'),
                 'sep_fwd': ('addk_sep_fwd_batch_prepare', 'addk_sep_batch_run'),
                 'sep_bwd': ('addk_sep_bwd_batch_prepare', 'addk_sep_bwd_batch_run'),
+                'resize_bwd': ('addk_resize_bwd_batch_prepare', 'addk_resize_bwd_batch_run'),
                 'allreduce': (None, None)}
 
     @staticmethod
@@ -1290,7 +1291,10 @@ class Graph:
                         ba.dab = slab.ptr
                         src.bn.slabs.append((slab, rows))
                 self.keep.append(ba)
-                self._add(self.bwd, 'resize_bwd', lib.addk_resize_bwd, C.byref(ba), rd=[dy] + self.lz(src), wr=[gs, slab])
+                crb = self._add(self.bwd, 'resize_bwd', lib.addk_resize_bwd, C.byref(ba), rd=[dy] + self.lz(src), wr=[gs, slab])
+                bk = int(lib.addk_resize_bwd_batch_key(C.byref(ba)))
+                if bk >= 0:
+                    crb.payload, crb.bkey = ba, bk
             self._bwd_emitters.append(emit_bwd)
         return res
 

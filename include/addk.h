@@ -416,6 +416,12 @@ typedef struct addk_resize_bwd_args {
   double* dab;                  /* fp64 [rows][C][2] or NULL (only with a lazy+relu prologue) */
 } addk_resize_bwd_args;
 int addk_resize_bwd(const addk_resize_bwd_args* a, void* stream);
+/* Batched form: the mutually independent resize backwards of one dependency level (the up to ten resized dense inputs of a cell,
+ * ADD.py:84-90) as ONE launch.  key >= 0: the launch runs on the table-driven kernel with that variant (equal keys may share a batch);
+ * prepare(host_blob = NULL) returns the blob size; meta[8] carries the launch geometry from prepare to run. */
+int addk_resize_bwd_batch_key(const addk_resize_bwd_args* a);
+int64_t addk_resize_bwd_batch_prepare(const addk_resize_bwd_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
+int addk_resize_bwd_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Global average pool with lazy prologue (AdaptiveAvgPool2d(1), aspp_train.py:13,50; ADD.py:506).
