@@ -1101,6 +1101,79 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
 #pragma unroll
     for (int f = 0; f < LB; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if (!FOLD) {
+    // [r4] The loop used to spend 6-11 vector instructions per MFMA (r03 counters: 6892 VALU / 1148 MFMA per wave, 66-70 % issue stall; 52 of
+    // the 84 VALU of the compute block were v_cndmask, the load blocks re-derived (n, oh, ow) by integer division for every k-step): with
+    // 24 issue cycles free per 32-cycle fp32 MFMA the kernel was bound by VALU issue, not by HBM.  Now
+    //   * this lane's pixel walks incrementally (4 pixels per k-step: offsets by addition, (n, oh, ow) by carries, no division);
+    //   * channel-validity selects are gone: an operand element of a channel beyond the tile only feeds accumulator rows / columns that
+    //     are never stored (the combine below masks them), and its load address is clamped as before;
+    //   * pixel validity (tail of the range, zero padding) is applied to ONE operand only, the activation: 0 * dy adds nothing, and dy of a
+    //     masked pixel is read from a valid address.
+    // Same products, same summation order: results are bit-identical to the previous form for finite gradients.
+    int pp = pbeg + 4 * s_beg + kq;
+    int n_ = 0, oh_ = 0, ow_ = 0;
+    if (!same) { n_ = pp / ohw; const int rem = pp - n_ * ohw; oh_ = rem / p.OW; ow_ = rem - oh_ * p.OW; }
+    const int ylane = LA == 4 ? (y4 ? 4 * li : 0) : (y2 ? 2 * li : 0), ylane1 = (LA == 3 && y1) ? 32 + li : 0;
+    const int zlane = LB == 4 ? (z4 ? 4 * li : 0) : (z2 ? 2 * li : 0), zlane1 = (LB == 3 && z1) ? 32 + li : 0;
+    auto ldA = [&](const float* b) {
+      RsFrag<LA> f;
+      if (LA == 4) { const float4 x = ld4(b + ylane); f.v[0] = x.x; f.v[1] = x.y; f.v[2] = x.z; f.v[3 % LA] = x.w; }
+      else {
+        typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+        const rs_f32x2 x = *(const __attribute__((address_space(1))) rs_f32x2*)(b + ylane);
+        f.v[0] = x.x; f.v[1] = x.y; f.v[2] = ((const gfloat*)b)[ylane1];
+      }
+      return f;
+    };
+    auto ldB = [&](const float* b) {
+      RsFrag<LB> f;
+      if (LB == 4) { const float4 x = ld4(b + zlane); f.v[0] = x.x; f.v[1] = x.y; f.v[2] = x.z; f.v[3 % LB] = x.w; }
+      else {
+        typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+        const rs_f32x2 x = *(const __attribute__((address_space(1))) rs_f32x2*)(b + zlane);
+        f.v[0] = x.x; f.v[1] = x.y; f.v[2] = ((const gfloat*)b)[zlane1];
+      }
+      return f;
+    };
+    for (int s0 = s_beg; s0 < s_end; s0 += RS_U) {
+      RsFrag<LA> dy4[RS_U]; RsFrag<LB> z4v[RS_U];
+      bool zv[RS_U];
+#pragma unroll
+      for (int u = 0; u < RS_U; ++u) {
+        const bool pv_ = (s0 + u) < s_end && pp < pend;
+        dy4[u] = ldA(ybase + (pv_ ? (long)pp * p.lddy : 0));
+        long zoff = 0; bool okz = pv_;
+        if (same) zoff = (long)pp * p.src.ld;
+        else {
+          const int ih = oh_ * p.stride - p.pad + kh * p.dil, iw = ow_ * p.stride - p.pad + kw * p.dil;
+          okz = okz && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          zoff = ((long)(n_ * p.H + ih) * p.W + iw) * p.src.ld;
+          ow_ += 4;                                          // the lane's next pixel: 4 further along the flattened (n, oh, ow) order
+          while (ow_ >= p.OW) { ow_ -= p.OW; if (++oh_ >= p.OH) { oh_ = 0; ++n_; } }
+        }
+        z4v[u] = ldB(zbase + (okz ? zoff : 0));
+        zv[u] = okz;
+        pp += 4;
+      }
+#pragma unroll
+      for (int u = 0; u < RS_U; ++u) {
+        RsFrag<LB> v = z4v[u];
+        const bool ok = zv[u];
+#pragma unroll
+        for (int f = 0; f < LB; ++f) {
+          float x = fmaf(za.v[f], v.v[f], zb.v[f]);
+          if (zrelu) x = fmaxf(x, 0.f);
+          v.v[f] = ok ? x : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < LA; ++e)
+#pragma unroll
+          for (int f = 0; f < LB; ++f)
+            acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy4[u].v[e], v.v[f], acc[e][f], 0, 0, 0);
+      }
+    }
+  } else
   for (int s0 = s_beg; s0 < s_end; s0 += RS_U) {
     RsFrag<LA> dy4[RS_U]; RsFrag<LB> z4v[RS_U];
     bool zv[RS_U];
