@@ -72,7 +72,8 @@ struct SepfGeo {
   static constexpr int UN = NLD <= UNMAX ? NLD : (NLD + 1) / 2;                      // ... per round: one round where 10 loads in flight suffice
   static constexpr int TPX = 4 * R * 16, TLD = TPX * KP;                             // first sum term of the inference epilogue, staged like the patch
   static constexpr int NTL = (TPX + NPL - 1) / NPL;
-  static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + RED + EAB + TLD) * 4;
+  static constexpr int PAB = 2 * KG * 16;                                            // prologue coefficients (a, b) of the input
+  static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + RED + EAB + TLD + PAB) * 4;
 };
 
 #ifdef ADDK_SEPF_DIAG
@@ -101,30 +102,22 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   const int ty = b % p.tiles_y; const int n = b / p.tiles_y;
   const int oh0 = ty * (4 * R), ow0 = tx * 16;
 
-  // ---- stage.  Round 4: EVERY global load of the tile is issued before anything waits — the first round of patch loads, the operands
-  // of the inference epilogue (other branches of the cell block) and the weights are ONE round trip to memory; they used to be three
-  // dependent ones (weights -> patch -> epilogue operands: 2.5 + 1.7 + 2.7 us of a 9.8 us workgroup, profiles/r04_sepf_phases.txt). ----
-  constexpr int NPL = G::NPL, UN = G::UN;
+  // ---- stage (round 4).  Every global load of the tile is requested before anything waits — weights, the first sum term of the inference
+  // epilogue, and the whole input patch — and the patch then moves to LDS ONE 16-CHANNEL GROUP AT A TIME, each group's depthwise + matrix
+  // work running while the later groups' loads are still arriving (vmcnt is in order: using group g's registers waits for nothing younger).
+  // The three dependent round trips of round 3 (weights -> patch -> epilogue operands: 2.5 + 1.7 + 2.7 us of a 9.8 us workgroup,
+  // profiles/r04_sepf_phases.txt) are one, and the memory system stays busy under the compute phase. ----
+  constexpr bool PIPE = KG == 5;                                 // the group pipeline pays at 80 channels (one workgroup per CU: 16.4 -> 15.2, 18.8 -> 17.6 us per
+                                                                 // launch); at 40 channels two workgroups per CU already overlap each other and its registers cost
+                                                                 // them occupancy (24.2 -> 27.0 us measured): those variants issue everything up front and store once
+  constexpr int NU = PIPE ? (NPIX + 63) / 64 : 1, KGP = PIPE ? KG : 1;   // patch quads per thread and channel group: thread = (pixel lane pl of 64, quad qq of the group)
+  constexpr int NWD = (KG * 16 * KS * KS + 255) / 256, NWP = (KG * CT * 64 + 255) / 256, NTU = G::TPX / 64;
   float* eab = reinterpret_cast<float*>(red) + G::RED;
-  const int q = t % KQ, pl = t / KQ;
-  const bool qact = pl < NPL && q < nq;
-  const long xq = qact ? 4 * q : 0;
+  float* tl = eab + G::EAB;                                      // [4R x 16 pixels][KP]: first sum term
+  float* pab = tl + G::TLD;                                      // [2][KG*16]: prologue coefficients
+  const int qq = t & 3;
   const int ih0 = oh0 - HK, iw0 = ow0 - HK;
-  float4 pv[UN]; bool pok[UN];
-  auto patch_issue = [&](int base) {
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int pix = base + u * NPL;
-      const int pr = pix / PW, pc = pix - pr * PW;
-      const int ih = ih0 + pr, iw = iw0 + pc;
-      pok[u] = qact && pix < NPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      pv[u] = ldx<IO16>(p.src.x, xq + (pok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
-    }
-  };
-  patch_issue(pl);
-  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
-  if (p.src.a && qact) { av = ld4(p.src.a + 4 * q); bv = ld4(p.src.b + 4 * q); }
-  // epilogue operands: the first two sum terms of this lane's output elements (a cell block has two branches: one term)
+  const bool t0 = p.nterm > 0;
   int pp[R]; bool pin[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -132,73 +125,200 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
     pin[r] = oh < p.H && ow < p.W;
     pp[r] = (n * p.H + oh) * p.W + ow;
   }
-  // the first sum term (a cell block has two branches: one term) travels with the patch: loaded now, parked in LDS, read by the epilogue
-  float* tl = eab + G::EAB;                                    // [4R x 16 pixels][KP]
-  constexpr int NTL = G::NTL;
-  float4 tq[NTL];
-  const bool t0 = p.nterm > 0;
-  if (t0) {
-#pragma unroll
-    for (int u = 0; u < NTL; ++u) {
-      const int pix = pl + u * NPL;
-      const int oh = oh0 + (pix >> 4), ow = ow0 + (pix & 15);
-      const bool ok = qact && pix < G::TPX && oh < p.H && ow < p.W;
-      tq[u] = ldx<IO16>(p.term[0].x, ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0);
+  float4 pv[KGP][NU]; unsigned pokm[KGP];
+  if constexpr (PIPE) {
+    const int pl = t >> 2;
+    // (1) weights and coefficient vectors -> registers
+    float wd[NWD]; float4 wp[NWP];
+  #pragma unroll
+    for (int j = 0; j < NWD; ++j) {
+      const int i = t + 256 * j;
+      wd[j] = ((const gfloat*)p.dww)[i < C * KS * KS ? i : 0];
     }
-  }
-  __builtin_amdgcn_sched_barrier(0);             // the loads above stay above: hipcc otherwise sinks each one to its first use
-  // weights (tiny, L2-resident).  Channels beyond C of the tap table are zeroed by the threads that do not write a weight there (no
-  // barrier between a zero fill and the weights any more)
-  for (int i = t; i < KS * KS * (KG * 16 - C); i += 256) {
-    const int tp = i / (KG * 16 - C), c = C + i - tp * (KG * 16 - C);
-    dwl[tp * (KG * 16) + c] = 0.f;
-  }
-  for (int i = t; i < C * KS * KS; i += 256) {                 // coalesced read of [C][KS*KS], transposed into [tap][channel]
-    const int c = i / (KS * KS), tp = i - c * (KS * KS);
-    dwl[tp * (KG * 16) + c] = ((const gfloat*)p.dww)[i];
-  }
-  for (int s = t; s < KG * CT * 64; s += 256) {
-    const int g = s / (CT * 64), rem = s - g * (CT * 64), ct = rem >> 6, ln = rem & 63;
-    const int nn = ct * 16 + (ln & 15), k = 16 * g + 4 * (ln >> 4);
-    const bool ok = nn < C && k < C;
-    float4 v = ld4(ok ? p.pww + (long)nn * p.ldw + k : p.pww);
-    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-    lds_st4(pwl + s * 4, v);
-  }
-  if (t0 && qact) {
-#pragma unroll
-    for (int u = 0; u < NTL; ++u) {
-      const int pix = pl + u * NPL;
-      if (pix < G::TPX) lds_st4(tl + pix * KP + 4 * q, tq[u]);
+  #pragma unroll
+    for (int j = 0; j < NWP; ++j) {
+      const int s = t + 256 * j;
+      const int g = s / (CT * 64), rem = s - g * (CT * 64), ct = rem >> 6, ln = rem & 63;
+      const int nn = ct * 16 + (ln & 15), k = 16 * g + 4 * (ln >> 4);
+      const bool ok = s < KG * CT * 64 && nn < C && k < C;
+      float4 v = ld4(ok ? p.pww + (long)nn * p.ldw + k : p.pww);
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      wp[j] = v;
     }
-  }
-  if (p.ea && t < 2 * nq) {                                    // frozen-BatchNorm coefficients of the inference epilogue -> LDS
-    const int which = t / nq, qq = t - which * nq;
-    lds_st4(eab + which * (KG * 16) + 4 * qq, ld4((which ? p.eb : p.ea) + 4 * qq));
-  }
-  SEPF_STAMP(1);
-  {
-    const bool relu = p.src.relu != 0;
-    if (pl < NPL) {
-      for (int base = pl; base < NPIX; base += UN * NPL) {
-        if (base != pl) patch_issue(base);
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const int pix = base + u * NPL;
-          float4 z = fma4(av, pv[u], bv);
-          if (relu) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
-          z.x = pok[u] ? z.x : 0.f; z.y = pok[u] ? z.y : 0.f; z.z = pok[u] ? z.z : 0.f; z.w = pok[u] ? z.w : 0.f;
-          if (pix < NPIX) lds_st4(patch + pix * KP + 4 * q, z);
+    float4 cab = make_float4(1.f, 1.f, 1.f, 1.f), ceab = zero4();
+    if (t < 2 * nq) {
+      const int which = t / nq, cq = t - which * nq;
+      cab = which ? zero4() : cab;
+      if (p.src.a) cab = ld4((which ? p.src.b : p.src.a) + 4 * cq);
+      if (p.ea) ceab = ld4((which ? p.eb : p.ea) + 4 * cq);
+    }
+    // (2) the first sum term (a cell block has two branches: one term): parked in LDS, read by the epilogue
+    float4 tq[KG][NTU];
+    if (t0) {
+  #pragma unroll
+      for (int g = 0; g < KG; ++g)
+  #pragma unroll
+        for (int u = 0; u < NTU; ++u) {
+          const int pix = pl + 64 * u, q = 4 * g + qq;
+          const int oh = oh0 + (pix >> 4), ow = ow0 + (pix & 15);
+          const bool ok = 4 * q < C && oh < p.H && ow < p.W;
+          tq[g][u] = ldx<IO16>(p.term[0].x, ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0);
         }
+    }
+    // (3) the input patch, group by group
+  #pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      pokm[g] = 0;
+  #pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int pix = pl + 64 * u, q = 4 * g + qq;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        const bool ok = pix < NPIX && 4 * q < C && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        pv[g][u] = ldx<IO16>(p.src.x, ok ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + 4 * q : 0);
+        pokm[g] |= (ok ? 1u : 0u) << u;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);             // the loads above stay above: hipcc otherwise sinks each one to its first use
+    // (4) weights, coefficients and the sum term -> LDS; zero fill of what nobody writes (channels beyond C of the tap table, padding quads of the patch)
+    for (int i = t; i < KS * KS * (KG * 16 - C); i += 256) {
+      const int tp = i / (KG * 16 - C), c = C + i - tp * (KG * 16 - C);
+      dwl[tp * (KG * 16) + c] = 0.f;
+    }
+  #pragma unroll
+    for (int j = 0; j < NWD; ++j) {                                // [C][KS*KS] transposed into [tap][channel]
+      const int i = t + 256 * j;
+      if (i < C * KS * KS) { const int c = i / (KS * KS), tp = i - c * (KS * KS); dwl[tp * (KG * 16) + c] = wd[j]; }
+    }
+  #pragma unroll
+    for (int j = 0; j < NWP; ++j) {
+      const int s = t + 256 * j;
+      if (s < KG * CT * 64) lds_st4(pwl + s * 4, wp[j]);
+    }
+    if (t < 2 * nq) {
+      const int which = t / nq, cq = t - which * nq;
+      lds_st4(pab + which * (KG * 16) + 4 * cq, cab);
+      if (p.ea) lds_st4(eab + which * (KG * 16) + 4 * cq, ceab);
+    }
+    if (KQ > 4 * KG) {                                             // padding quads beyond the last channel group (KP = 56, 88)
+      for (int i = t; i < NPIX * (KQ - 4 * KG); i += 256) {
+        const int px = i / (KQ - 4 * KG), q = 4 * KG + i - px * (KQ - 4 * KG);
+        lds_st4(patch + px * KP + 4 * q, zero4());
       }
     }
     if (t < 8) patch[NPIX * KP + t] = 0.f;
-  }
-  SEPF_STAMP(2);
-  __syncthreads();
-  SEPF_STAMP(3);
+    if (t0) {
+  #pragma unroll
+      for (int g = 0; g < KG; ++g)
+  #pragma unroll
+        for (int u = 0; u < NTU; ++u) {
+          const int pix = pl + 64 * u, q = 4 * g + qq;
+          if (q < KQ) lds_st4(tl + pix * KP + 4 * q, tq[g][u]);
+        }
+    }
+    __syncthreads();
+  } else {
+    constexpr int NPL = G::NPL, UN = G::UN;
+    const int q = t % KQ, pl = t / KQ;
+    const bool qact = pl < NPL && q < nq;
+    const long xq = qact ? 4 * q : 0;
+      float4 pv[UN]; bool pok[UN];
+    auto patch_issue = [&](int base) {
+  #pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int pix = base + u * NPL;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        pok[u] = qact && pix < NPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        pv[u] = ldx<IO16>(p.src.x, xq + (pok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
+      }
+    };
+    patch_issue(pl);
+    float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+    if (p.src.a && qact) { av = ld4(p.src.a + 4 * q); bv = ld4(p.src.b + 4 * q); }
+    // the first sum term (a cell block has two branches: one term) travels with the patch: loaded now, parked in LDS, read by the epilogue
+    constexpr int NTL = G::NTL;
+    float4 tq[NTL];
+    if (t0) {
+  #pragma unroll
+      for (int u = 0; u < NTL; ++u) {
+        const int pix = pl + u * NPL;
+        const int oh = oh0 + (pix >> 4), ow = ow0 + (pix & 15);
+        const bool ok = qact && pix < G::TPX && oh < p.H && ow < p.W;
+        tq[u] = ldx<IO16>(p.term[0].x, ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);             // the loads above stay above: hipcc otherwise sinks each one to its first use
+    // weights (tiny, L2-resident).  Channels beyond C of the tap table are zeroed by the threads that do not write a weight there (no
+    // barrier between a zero fill and the weights any more)
+    for (int i = t; i < KS * KS * (KG * 16 - C); i += 256) {
+      const int tp = i / (KG * 16 - C), c = C + i - tp * (KG * 16 - C);
+      dwl[tp * (KG * 16) + c] = 0.f;
+    }
+    for (int i = t; i < C * KS * KS; i += 256) {                 // coalesced read of [C][KS*KS], transposed into [tap][channel]
+      const int c = i / (KS * KS), tp = i - c * (KS * KS);
+      dwl[tp * (KG * 16) + c] = ((const gfloat*)p.dww)[i];
+    }
+    for (int s = t; s < KG * CT * 64; s += 256) {
+      const int g = s / (CT * 64), rem = s - g * (CT * 64), ct = rem >> 6, ln = rem & 63;
+      const int nn = ct * 16 + (ln & 15), k = 16 * g + 4 * (ln >> 4);
+      const bool ok = nn < C && k < C;
+      float4 v = ld4(ok ? p.pww + (long)nn * p.ldw + k : p.pww);
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      lds_st4(pwl + s * 4, v);
+    }
+    if (t0 && qact) {
+  #pragma unroll
+      for (int u = 0; u < NTL; ++u) {
+        const int pix = pl + u * NPL;
+        if (pix < G::TPX) lds_st4(tl + pix * KP + 4 * q, tq[u]);
+      }
+    }
+    if (p.ea && t < 2 * nq) {                                    // frozen-BatchNorm coefficients of the inference epilogue -> LDS
+      const int which = t / nq, qq = t - which * nq;
+      lds_st4(eab + which * (KG * 16) + 4 * qq, ld4((which ? p.eb : p.ea) + 4 * qq));
+    }
+    {
+      const bool relu = p.src.relu != 0;
+      if (pl < NPL) {
+        for (int base = pl; base < NPIX; base += UN * NPL) {
+          if (base != pl) patch_issue(base);
+  #pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const int pix = base + u * NPL;
+            float4 z = fma4(av, pv[u], bv);
+            if (relu) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
+            z.x = pok[u] ? z.x : 0.f; z.y = pok[u] ? z.y : 0.f; z.z = pok[u] ? z.z : 0.f; z.w = pok[u] ? z.w : 0.f;
+            if (pix < NPIX) lds_st4(patch + pix * KP + 4 * q, z);
+          }
+        }
+      }
+      if (t < 8) patch[NPIX * KP + t] = 0.f;
+    }
 
-  // ---- compute: wave = rows [wave*R, wave*R + R) x 16 pixels ----
+    __syncthreads();
+  }
+  SEPF_STAMP(1);
+  const bool relu = p.src.relu != 0;
+  auto patch_store = [&](int g) {                                // prologue (lazy BatchNorm / ReLU), zero padding, group g of the patch -> LDS
+    const int q = 4 * g + qq, pl = t >> 2;
+    if (q >= KQ) return;
+    const float4 av = lds_ld4(pab + 4 * q), bv = lds_ld4(pab + KG * 16 + 4 * q);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int pix = pl + 64 * u;
+      const bool ok = (pokm[g] >> u) & 1u;
+      float4 z = fma4(av, pv[g][u], bv);
+      if (relu) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
+      z.x = ok ? z.x : 0.f; z.y = ok ? z.y : 0.f; z.z = ok ? z.z : 0.f; z.w = ok ? z.w : 0.f;
+      if (pix < NPIX) lds_st4(patch + pix * KP + 4 * q, z);
+    }
+  };
+
+  // ---- compute: wave = rows [wave*R, wave*R + R) x 16 pixels; group g's patch slice is stored, the workgroup meets, group g is consumed ----
+#ifdef ADDK_SEPF_DIAG
+  unsigned long long diag_t23 = 0;
+#endif
   f32x4 macc[R][CT];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -206,6 +326,11 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
     for (int i = 0; i < CT; ++i) macc[r][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
+    if (PIPE) { patch_store(g); __syncthreads(); }
+#ifdef ADDK_SEPF_DIAG
+    const unsigned long long diag_tg = __builtin_amdgcn_s_memrealtime();
+    if (g == 0) { diag_t23 = diag_tg; }
+#endif
     const int q = 4 * g + kq;
     const int qr = q < KQ ? q : q - 2;             // quads past the padded pixel (only when KP < 16 KG): re-read a valid quad, its tap weights are 0
     float4 wr[KS * KS];
@@ -279,8 +404,8 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   if (t == 0) {
     const unsigned long long diag_t5 = __builtin_amdgcn_s_memrealtime();
     unsigned long long* d = g_sepf_diag[blockIdx.x & 63];
-    atomicAdd(&d[0], diag_t1 - diag_t0); atomicAdd(&d[1], diag_t2 - diag_t1); atomicAdd(&d[2], diag_t3 - diag_t2);
-    atomicAdd(&d[3], diag_t4 - diag_t3); atomicAdd(&d[4], diag_t5 - diag_t4); atomicAdd(&d[5], 1ull);
+    atomicAdd(&d[0], diag_t1 - diag_t0); atomicAdd(&d[1], diag_t23 - diag_t1); atomicAdd(&d[2], 0ull);
+    atomicAdd(&d[3], diag_t4 - diag_t23); atomicAdd(&d[4], diag_t5 - diag_t4); atomicAdd(&d[5], 1ull);
     atomicMin(&g_sepf_span[0], diag_t0); atomicMax(&g_sepf_span[1], diag_t5);
   }
 #endif

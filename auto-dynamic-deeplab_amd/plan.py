@@ -1292,7 +1292,7 @@ class Graph:
                         src.bn.slabs.append((slab, rows))
                 self.keep.append(ba)
                 crb = self._add(self.bwd, 'resize_bwd', lib.addk_resize_bwd, C.byref(ba), rd=[dy] + self.lz(src), wr=[gs, slab])
-                bk = int(lib.addk_resize_bwd_batch_key(C.byref(ba)))
+                bk = int(lib.addk_resize_bwd_batch_key(C.byref(ba))) if os.environ.get('ADDK_BATCH_RESIZE_BWD', '1') == '1' else -1
                 if bk >= 0:
                     crb.payload, crb.bkey = ba, bk
             self._bwd_emitters.append(emit_bwd)
