@@ -570,11 +570,10 @@ def main():
         peak_note = 'dense bf16 MFMA peak %.0f TFLOP/s / %d matrix instructions per fp32 multiply-add' % (PEAK_MFMA_BF16_TFLOPS, terms)
     ach = top['flops'] / tk / 1e12
     # HBM-side traffic of that launch: PMC passes cannot run inside this process; the committed rocprofv3 --pmc measurement of the
-    # same kernel and shape (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes: scripts/refresh_profiles_r02.sh) is quoted, labelled
+    # same kernel and shape (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes: scripts/refresh_profiles_r04.sh) is quoted, labelled
     traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_decoder_conv3b.json')
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_decoder_conv3b.json')
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_pmc_traffic_decoder_conv3b.json' % r) for r in (4, 3, 2)) if os.path.exists(q)),
+                 os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_decoder_conv3b.json'))
     if halo and math == 'bf16x6' and (n, h, w, a.F, a.genotype) == (2, 1024, 2048, 20, 'autodeeplab/genotype') and os.path.exists(tpath):
         try:
             traffic, tsrc = json.load(open(tpath)).get('traffic_bytes_per_launch'), 'profiles/%s (rocprofv3 --pmc passes of the same kernel and shape; not measured in this run)' % os.path.basename(tpath)
