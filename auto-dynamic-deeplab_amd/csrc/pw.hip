@@ -216,6 +216,20 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
       pp = tile * 16 + li;
       pin = pp < p.P;
     }
+    // [r4] data gradient: the epilogue's operands (the forward input for the ReLU mask and the (dA, dB) sums, the gradient to
+    // accumulate into) do not depend on the matrix product — they are requested with the tile, not after it: one dependent
+    // round trip per tile instead of two or three (these launches are latency chains: 2 TB/s of their algorithmic bytes before)
+    float4 dxp[CT], dop[CT];
+    if (MODE == PW_DGRAD) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int c = n0 + i * 16 + kq * 4;
+        const int nrem = pin ? p.Cn - c : 0;
+        dxp[i] = ld4g(p.dst.x + (pin ? (long)pp * p.dst.ld + c : 0), nrem, true);
+        dop[i] = zero4();
+        if (p.accumulate) dop[i] = ld4g(p.y + (pin ? (long)pp * p.ldy + c : 0), nrem, true);
+      }
+    }
     if (pro && !SEP) {
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
@@ -275,9 +289,9 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
             for (int e = 0; e < 4; ++e) { const red_t f = e < nrem ? (red_t)get4(v, e) : (red_t)0; s1[i][e] += f; s2[i][e] += f * f; }
           }
         } else {
-          float4 x = ld4g(p.dst.x + (long)pp * p.dst.ld + c, nrem, true);
+          const float4 x = dxp[i];
           float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
-          if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, true); bv = ld4g(p.dst.b + c, nrem, true); }
+          if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, true); bv = ld4g(p.dst.b + c, nrem, true); }      // (C-length vectors: L1 hits)
           float4 g4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -287,7 +301,7 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
             if (p.slab && m) { s1[i][e] += (red_t)dz * (red_t)xe; s2[i][e] += (red_t)dz; }
           }
           float* gp = p.y + (long)pp * p.ldy + c;
-          if (p.accumulate) { float4 o = ld4g(gp, nrem, true); g4.x += o.x; g4.y += o.y; g4.z += o.z; g4.w += o.w; }
+          if (p.accumulate) { const float4 o = dop[i]; g4.x += o.x; g4.y += o.y; g4.z += o.z; g4.w += o.w; }
           st4g(gp, g4, nrem, true);
         }
       }
@@ -318,13 +332,13 @@ __device__ __forceinline__ void pw_body(const PwK& p, double (*red)[CT * 16][2],
 }
 
 template <int CT, int KG, int MODE, bool RED32, bool RS = false>
-__global__ void __launch_bounds__(256, (KG <= 3 && !RS ? 4 : 3)) pw_kernel(const PwK p) {
+__global__ void __launch_bounds__(256, (KG <= 3 && !RS && MODE == PW_FWD ? 4 : 3)) pw_kernel(const PwK p) {
   __shared__ double red[4][CT * 16][2];
   pw_body<CT, KG, MODE, RED32, 0, RS>(p, red);
 }
 // several independent pointwise convs of one dependency level in ONE launch: block (x, y, z) runs descriptor z
 template <int CT, int KG, int MODE, bool RED32, bool RS = false>
-__global__ void __launch_bounds__(256, (KG <= 3 && !RS ? 4 : 3)) pw_batch_kernel(const PwK* __restrict__ tab) {
+__global__ void __launch_bounds__(256, (KG <= 3 && !RS && MODE == PW_FWD ? 4 : 3)) pw_batch_kernel(const PwK* __restrict__ tab) {
   __shared__ double red[4][CT * 16][2];
   const PwK p = tab[blockIdx.z];
   if ((int)blockIdx.x >= p.gx || (int)blockIdx.y >= p.gy) return;
