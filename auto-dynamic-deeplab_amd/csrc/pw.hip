@@ -505,7 +505,11 @@ static bool pw_config(PwK& k, int rows, PwCfg& c) {
   if (c.ct < 1) c.ct = 1;
   k.rows = rows;
   c.gx = rows;
-  if (c.gx > cdiv(k.ntiles16, 4)) c.gx = cdiv(k.ntiles16, 4);
+  // [r4] two 16-pixel tiles per wave: a wave's fixed cost (the weight panel — 36 strided scalar loads per lane in the data gradient —, the
+  // prologue coefficients, the statistics reduction) was paid for ONE tile; with two the level-batched launches (up to ~9000 workgroups
+  // queueing on 256 CUs) do half of it: step 35.0 -> 34.5-34.7 ms, inference segment unchanged (ADDK_PW_TILES=1 restores one tile, 4 measured 34.65)
+  static int tpw = 0; if (!tpw) { const char* e = getenv("ADDK_PW_TILES"); tpw = e ? atoi(e) : 2; if (tpw < 1) tpw = 1; }
+  if (c.gx > cdiv(k.ntiles16, 4 * tpw)) c.gx = cdiv(k.ntiles16, 4 * tpw);
   if (c.gx < 1) c.gx = 1;
   c.gy = cdiv(k.Cn, 16 * c.ct);
   c.red32 = k.P >= 4096;
@@ -517,7 +521,7 @@ template <int MODE>
 int pw_launch(PwK& k, int rows, hipStream_t st) {
   PwCfg c;
   if (!pw_config(k, rows, c)) return 1;                  // no instantiation: caller falls back to the general kernel
-  dim3 grid(c.gx, c.gy);          // measured: fewer, fatter workgroups are slower (14 -> 36 us); parallelism wins
+  dim3 grid(c.gx, c.gy);          // (round 1 measured far fewer, fatter workgroups slower, 14 -> 36 us: the grid keeps >= ~500 workgroups on the large maps)
 #define ADDK_PW(CT_, KG_) \
   if (c.ct == CT_ && c.kg == KG_) { \
     if (MODE == PW_FWD && c.rs) { \
