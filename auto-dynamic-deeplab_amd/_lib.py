@@ -55,6 +55,12 @@ class SepArgs(C.Structure):
                 ('term', Src * MAX_TERMS), ('fin', BnFinalizeArgs), ('fin_counter', vp), ('io16', i32), ('_pad', i32)]
 
 
+class SepConvArgs(C.Structure):
+    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('ldw', i32), ('ldy', i32), ('dw1_w', vp), ('pw1_w', vp),
+                ('mid_a', vp), ('mid_b', vp), ('dw2_w', vp), ('pw2_w', vp), ('y', vp), ('ea', vp), ('eb', vp), ('nterm', i32), ('_pad', i32),
+                ('term', Src * MAX_TERMS)]
+
+
 class SepBwdArgs(C.Structure):
     _fields_ = [('dy', vp), ('lddy', i32), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('src', Src), ('Cout', i32), ('ldw', i32),
                 ('dw_w', vp), ('pw_w', vp), ('g', vp), ('ldg', i32), ('accumulate', i32), ('dab', vp), ('ws', vp), ('fold', BnFold)]
@@ -169,6 +175,8 @@ _SIGS = {
     'addk_sep_fwd_supported': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_rows': (i32, [C.POINTER(SepArgs)]),
     'addk_bn_fin_ws_bytes': (i64, [i32, i32]),
+    'addk_sepconv_fwd_supported': (i32, [C.POINTER(SepConvArgs)]),
+    'addk_sepconv_fwd': (i32, [C.POINTER(SepConvArgs), vp]),
     'addk_sep_bwd_rows': (i32, [C.POINTER(SepBwdArgs)]),
     'addk_sep_bwd': (i32, [C.POINTER(SepBwdArgs), vp]),
     'addk_sep_bwd_batch_key': (i32, [C.POINTER(SepBwdArgs)]),

@@ -1195,6 +1195,54 @@ class Graph:
             c.payload, c.bkey = ar, bk
         return act
 
+    def sepconv_whole(self, src, dw1, pw1, bn1, dw2, pw2, bn2, sum_terms=None, out=None):
+        """A WHOLE SepConv (operations.py:46-62) as ONE inference launch (addk_sepconv_fwd, csrc/sepw.hip): both halves, the frozen BatchNorm
+        + ReLU between them, and — when this op closes a cell block — its own frozen BatchNorm plus the other branches of the block
+        (ADD.py:108).  The intermediate tensor never exists.  Returns the Act, or None where the kernel does not cover the op (training,
+        gradients, other shapes): the caller then emits the two halves (sep_half)."""
+        lib = self.lib
+        # BUILT, MEASURED, OFF BY DEFAULT (profiles/r04_sepconv_whole_vs_halves.txt): one launch takes 26.8 / 31.2 us against 2 x 14.5 / 2 x 18 us
+        # for the 3x3 SepConvs at 80 / 40 channels and 52.6 / 57.2 us against 2 x 17 / 2 x 20 us for the 5x5 ones (x2.5 recomputed mid pixels in three
+        # rounds per wave, pointwise weights streamed from L2 because the 101 KB patch fills the LDS); the inference segment: 7.90 ms with every
+        # SepConv in one launch, 7.08-7.12 ms with the 3x3 ones only, 6.85-6.90 ms with the two fused halves.  '3': 3x3 only, '1': all, '0' (default): never
+        mode = os.environ.get('ADDK_FUSE_SEPCONV', '0')
+        if self.training or self.want_grad or mode == '0':
+            return None
+        k = dw1.kernel_size[0]
+        if k != 3 and mode != '1':
+            return None
+        same = all(m.stride[0] == 1 and m.dilation[0] == 1 and m.padding[0] == k // 2 and m.kernel_size[0] == k for m in (dw1, dw2))
+        if not same or pw1.kernel_size[0] != 1 or pw2.kernel_size[0] != 1 or pw1.out_channels != src.C or pw2.out_channels != src.C:
+            return None
+        N, H, W, Cc = src.N, src.H, src.W, src.C
+        raw = out if (out is not None and sum_terms is not None) else self.tensor(N, H, W, Cc)
+        ar = L.SepConvArgs()
+        ar.src = self.src(src, True)
+        ar.N, ar.H, ar.W, ar.K, ar.ldw, ar.ldy = N, H, W, k, Cc, raw.ld
+        ar.dw1_w, ar.pw1_w, ar.dw2_w, ar.pw2_w = self.param(dw1.weight), self.param(pw1.weight), self.param(dw2.weight), self.param(pw2.weight)
+        ar.y = raw.ptr
+        ar.nterm = 0
+        if int(lib.addk_sepconv_fwd_supported(C.byref(ar))) != 1:
+            return None
+        st1 = self.bn(TRef(None, 0, N, H, W, Cc, Cc), bn1, None, 0).bn          # frozen BatchNorm of half 1: (a, b) only, the tensor never exists
+        ar.mid_a, ar.mid_b = st1.a.ptr, st1.b.ptr
+        rd = self.lz(src) + [dw1.weight, pw1.weight, dw2.weight, pw2.weight, st1.a, st1.b]
+        res = None
+        if sum_terms is not None:
+            st2 = self.bn(raw, bn2, None, 0).bn
+            terms = [tm for tm in sum_terms if not tm.zero]
+            assert len(terms) <= L.MAX_TERMS and out is not None
+            ar.ea, ar.eb, ar.nterm = st2.a.ptr, st2.b.ptr, len(terms)
+            for i, tm in enumerate(terms):
+                assert (tm.N, tm.H, tm.W, tm.C) == (N, H, W, Cc), 'branch shapes differ'
+                ar.term[i] = self.src(tm)
+                rd += self.lz(tm)
+            rd += [st2.a, st2.b]
+            res = Act(raw, None, False, False)
+        self.keep.append(ar)
+        self._add(self.fwd, 'sepconv_fwd', lib.addk_sepconv_fwd, C.byref(ar), rd=rd, wr=[raw])
+        return res if res is not None else self.bn(raw, bn2, None, 0)
+
     def affine_sum(self, terms, out=None, relu_out=False):
         """Materialise sum_i relu_i?(a_i*x_i+b_i) (optionally ReLU'd) into `out`."""
         lib = self.lib

@@ -257,6 +257,27 @@ int addk_sep_fwd_batch_key(const addk_sep_args* a);
 int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
 int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 
+/* A WHOLE SepConv in one launch, inference form (csrc/sepw.hip; operations.py:46-62 with both BatchNorms frozen):
+ *   relu?(a*x+b) -> depthwise K x K -> pointwise -> mid_a*(.)+mid_b -> ReLU -> depthwise K x K -> pointwise
+ *   -> y = ea*acc + eb + sum_i relu_i?(a_i*term_i + b_i)      (ea == NULL: plain y = acc: the caller's lazy BatchNorm follows)
+ * The intermediate tensor never exists: the first half is computed on the second half's halo inside the workgroup.  Same covered
+ * shapes as addk_sep_fwd (K in {3,5}, channels in (32,48] or (64,80]); addk_sepconv_fwd_supported says so; results agree with two
+ * addk_sep_fwd launches to fp32 rounding (same products, same summation order per output element). */
+typedef struct addk_sepconv_args {
+  addk_src src;                       /* lazy input (x, a, b, relu) */
+  int32_t N, H, W, K;                 /* output size == input size; depthwise kernel size of both halves */
+  int32_t ldw, ldy;                   /* pointwise weight row stride (both halves); output pixel stride */
+  const float* dw1_w; const float* pw1_w;     /* half 1: depthwise [C][K*K], pointwise [C][ldw] */
+  const float* mid_a; const float* mid_b;     /* frozen BatchNorm of half 1 (both NULL = identity); ReLU follows */
+  const float* dw2_w; const float* pw2_w;     /* half 2 */
+  float* y;
+  const float* ea; const float* eb;           /* own frozen BatchNorm of half 2 (both NULL = none) */
+  int32_t nterm; int32_t _pad;
+  addk_src term[ADDK_MAX_TERMS];
+} addk_sepconv_args;
+int addk_sepconv_fwd_supported(const addk_sepconv_args* a);
+int addk_sepconv_fwd(const addk_sepconv_args* a, void* stream);
+
 /* Fused BACKWARD of a SepConv half (csrc/sepb.hip): pointwise data gradient (dt = W^T dy, matrix cores) and depthwise backward
  * (dx, depthwise weight-gradient partials, (dA, dB) of the input's lazy BatchNorm) in one launch; dt stays on chip.  dy is the
  * gradient wrt the pointwise output with the BatchNorm backward already applied (addk_bn_bwd_apply) or, with `fold`, applied here.  The pointwise WEIGHT
