@@ -505,6 +505,12 @@ __device__ __forceinline__ unsigned wg_cvt2(float a, float b) {
 template <int NP>
 __device__ __forceinline__ void wg_split4(const float4 v, uint2 (&pl)[NP]) {
   float a = v.x, b = v.y, c = v.z, d = v.w;
+#ifdef ADDK_WG_FAKE_SPLIT      // upper-bound experiment (scripts/wgrad_split_bound.sh): WRONG numbers — the planes m, l are copies of h, i.e. the split costs one conversion
+  { const unsigned p0 = wg_cvt2(a, b), p1 = wg_cvt2(c, d);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) pl[k] = make_uint2(p0, p1);
+    return; }
+#endif
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const unsigned p0 = wg_cvt2(a, b), p1 = wg_cvt2(c, d);
