@@ -45,6 +45,12 @@ __device__ __forceinline__ float4 ld4(const float* p) {
   const addk_f32x4 v = *(const __attribute__((address_space(1))) addk_f32x4*)p;
   return make_float4(v.x, v.y, v.z, v.w);
 }
+// 16-byte load at a 32-bit BYTE offset from a wave-uniform base: the `global_load_dwordx4 v, v_off, s[base]` form (one address register, no 64-bit
+// vector arithmetic) — for loops whose base moves in scalar registers while every thread's offset stays put
+__device__ __forceinline__ float4 ld4so(const float* sbase, unsigned byte_off) {
+  const addk_f32x4 v = *(const __attribute__((address_space(1))) addk_f32x4*)((const __attribute__((address_space(1))) char*)sbase + byte_off);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void st4(float* p, float4 v) {
   const addk_f32x4 t = {v.x, v.y, v.z, v.w};
   *(__attribute__((address_space(1))) addk_f32x4*)p = t;

@@ -524,6 +524,14 @@ __device__ __forceinline__ void wg_split4(const float4 v, uint2 (&pl)[NP]) {
 // byte offset of pixel row p inside a [pixel][16 ch] bf16 tile image
 __device__ __forceinline__ int wg_prow(int p) { return (p << 5) ^ (((p >> 3) & 1) << 7); }
 
+#ifdef ADDK_WG_DIAG
+// diagnostic build (scripts/wgrad_phases.sh): every wave of wgrad_h3b_kernel adds its lifetime in shader-clock ticks (s_memtime) and in 100 MHz reference ticks
+// (s_memrealtime) — their ratio is the clock the CUs ran at inside the kernel — and the shader ticks it spent in each phase of the segment loop:
+// [0] life (shader) [1] life (reference) [2] waves [3] issuing the next segment's loads [4] matrix phase (fragment reads + MFMA) [5] waiting at the barrier
+// after it [6] split + LDS stores (including the wait for the loads) [7] waiting at the barrier after them
+__device__ unsigned long long g_wg_diag[64][8];
+#define WG_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#endif
 template <int NT, bool BATCH, int NP>
 __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
   int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
@@ -534,7 +542,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
   const WgK p = wg_desc<BATCH>(pv, ops, op);
   constexpr int BCO = 64 * NT, YT = BCO / 16, YQ = BCO / 4, YRS = 256 / YQ;
   constexpr int NYJ = H3_KP / YRS;
-  constexpr int NZJ = (3 * H3_ZW * 4 + 255) / 256;
   constexpr int ZWP = 104;                                        // patch row pitch in pixels (>= 64 + 2*18, multiple of 8: the swizzle works on 8-pixel blocks)
   // bytes per dy tile image / per activation patch row (one plane).  The tile images are 32 bytes apart from a multiple of
   // the 256-byte bank period: the 8 tiles x 4 channel quads a half-wave stores for one pixel row then cover all 64 banks once
@@ -553,13 +560,30 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
   const int sbeg = blk_y * p.chunkP;
   int send = sbeg + p.chunkP; if (send > nseg) send = nseg;
 
+#ifdef ADDK_WG_ABL       // ablation builds (scripts/wgrad_ablate.sh): WRONG numbers.  bit 0: no staging inside the loop; bit 1: no fragment reads inside the
+  constexpr int ABL = ADDK_WG_ABL;      // loop; bit 2: no global loads (the split + LDS stores run on stale registers); bit 3: loads only (no split, no LDS stores);
+#else                                   // bit 4: the split without its LDS stores; bit 5: the LDS stores without the split
+  constexpr int ABL = 0;
+#endif
+  // Staging geometry.  Everything a thread needs per segment is a THREAD CONSTANT (a byte offset from a segment-uniform base pointer, an LDS
+  // offset) plus segment scalars: no per-slot divisions, address arithmetic or validity bits in vector registers (the kernel is bound by
+  // the SIMD's issue port — 8 cycles per MFMA, 4 per vector instruction: scripts/wgrad_ablate.sh — so every vector instruction saved is time).
+  //   dy: thread (yq, yrow0) owns channel quad yq of rows yrow0 + k YRS of the 64-pixel segment;
+  //   patch: thread (zq, zj0) owns channel quad zq of patch columns zj0 and 64 + zj0 (the latter only below 2 d) of each of the 3 rows.
   const int yq = t & (YQ - 1), yrow0 = t / YQ;
-  const int co = co0 + 4 * yq;
-  const bool co_ok = co < p.Cout;
-  const int zq = t & 3, zc = c0 + 4 * zq, nremz = p.src.C - zc;
+  const int co = co0 + 4 * yq;                                      // < Cout: BCO divides Cout (wg_fill)
+  const unsigned yoff = ((unsigned)yrow0 * (unsigned)p.lddy + (unsigned)co) * 4u;
+  const long ystep = (long)YRS * p.lddy;
+  // LDS offset of row yrow0 + k YRS = (k even ? ysw0 : ysw1) + k YRS 32: the swizzle bit (bit 3 of the row) alternates with k when YRS = 8
+  const int ytile = (yq >> 2) * YIMG + 8 * (yq & 3);
+  const int ysw0 = ytile + wg_prow(yrow0), ysw1 = ytile + wg_prow(yrow0 + YRS) - (YRS << 5);
+  const int zq = t & 3, zj0 = t >> 2, zc = c0 + 4 * zq, nremz = p.src.C - zc;
+  const unsigned zoff = ((unsigned)zj0 * (unsigned)p.src.ld + (unsigned)zc) * 4u;
+  const int zsw = wg_prow(zj0) + 8 * zq;                            // second half: + 64 * 32 (bit 3 of 64 + zj0 is bit 3 of zj0)
+  const bool zhalf1 = zj0 < 2 * d;                                  // this thread has a column in the second half (64 + zj0 < ZW)
   float4 za = make_float4(1.f, 1.f, 1.f, 1.f), zb = zero4();
   if (p.src.a && nremz > 0) { za = ld4g(p.src.a + zc, nremz, p.vecZ); zb = ld4g(p.src.b + zc, nremz, p.vecZ); }
-  const bool zrelu = p.src.relu != 0;
+  const bool zrelu = p.src.relu != 0, zaff = p.src.a != nullptr;
   // transposed-read lane geometry: lane 16g + 4q + pp supplies (pixel row q of the block, channels 4pp..4pp+3)
   const int tq = li >> 2, tp = li & 3;
   const int lrow = 8 * kq + tq;                                   // this lane's pixel row inside a 32-pixel k-step (first read; second +4)
@@ -570,59 +594,74 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 ry[NYJ], rz[NZJ];
-  unsigned ymask = 0, zmask = 0;
-  auto load_step = [&](int seg) {
-    const int rowid = seg / spr, sx = seg - rowid * spr;
-    const int n = rowid / p.OH, oh = rowid - n * p.OH;
-    const int ow0 = sx * H3_KP;
-    const long pp0 = (long)rowid * p.OW + ow0;
-    const float* yb = p.dy + pp0 * p.lddy + co;
-    ymask = 0; zmask = 0;
+  float4 ry[NYJ], rz[6];
 #pragma unroll
-    for (int k = 0; k < NYJ; ++k) {
-      const int row = yrow0 + k * YRS;
-      const bool ok = co_ok && ow0 + row < p.OW;
-      ry[k] = ld4(ok ? yb + (long)row * p.lddy : p.dy);
-      ymask |= (ok ? 1u : 0u) << k;
-    }
+  for (int k = 0; k < 6; ++k) rz[k] = zero4();
+  // coordinates of the segment load_step fetches next (scalars, advanced incrementally), and the validity of the one in flight
+  int l_sx, l_oh, l_n;
+  { const int rowid = sbeg / spr; l_sx = sbeg - rowid * spr; l_n = rowid / p.OH; l_oh = rowid - l_n * p.OH; }
+  int st_skip = 0;                                                  // leading pixels of the segment in flight that belong to its left neighbour
+  unsigned zrows = 0;                                               // bit r: patch row r lies inside the image
+  unsigned long long zcm0 = 0, zcm1 = 0;                            // lane masks: this lane's first / second column lies inside the image (and its channels exist)
+  auto load_step = [&]() {
+    // the last segment of an image row is moved left to end at the row's end (OW >= 64: h3_ok); the st_skip pixels it then shares with its
+    // neighbour get dy = 0 in store_step — every segment is a full one, the loads never leave the row and need no per-lane condition
+    int ow0 = l_sx * H3_KP;
+    st_skip = ow0 + H3_KP - p.OW; if (st_skip < 0) st_skip = 0;
+    ow0 -= st_skip;
+    const long rowid = (long)l_n * p.OH + l_oh;
+    const float* yseg = p.dy + (rowid * p.OW + ow0) * p.lddy;
 #pragma unroll
-    for (int k = 0; k < NZJ; ++k) {
-      const int pix = (t + 256 * k) >> 2;
-      const int zr = pix / ZW, zj = pix - zr * ZW;
-      const int ih = oh + (zr - 1) * d, iw = ow0 - d + zj;
-      const bool ok = zr < 3 && nremz > 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      rz[k] = ld4(ok ? p.src.x + ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + zc : p.src.x);
-      zmask |= (ok ? 1u : 0u) << k;
+    for (int k = 0; k < NYJ; ++k) ry[k] = ld4so(yseg + k * ystep, yoff);
+    const int iw0 = ow0 - d;                                        // image column of patch column 0
+    const bool c0ok = nremz > 0 && (unsigned)(iw0 + zj0) < (unsigned)p.W;
+    const bool c1ok = nremz > 0 && zhalf1 && (unsigned)(iw0 + H3_KP + zj0) < (unsigned)p.W;
+    zcm0 = __ballot(c0ok); zcm1 = __ballot(c1ok);
+    zrows = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ih = l_oh + (r - 1) * d;
+      if ((unsigned)ih < (unsigned)p.H) {
+        zrows |= 1u << r;
+        const float* zrow = p.src.x + (((long)l_n * p.H + ih) * p.W + iw0) * p.src.ld;
+        if (c0ok) rz[2 * r] = ld4so(zrow, zoff);
+        if (c1ok) rz[2 * r + 1] = ld4so(zrow + (long)H3_KP * p.src.ld, zoff);
+      }
     }
+    if (++l_sx == spr) { l_sx = 0; if (++l_oh == p.OH) { l_oh = 0; ++l_n; } }
   };
   auto store_step = [&]() {
+    if (st_skip) {
 #pragma unroll
-    for (int k = 0; k < NYJ; ++k) {
-      float4 v = ry[k];
-      const bool ok = (ymask >> k) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      uint2 pl[NP];
-      wg_split4<NP>(v, pl);
-      const int off = (yq >> 2) * YIMG + wg_prow(yrow0 + k * YRS) + 8 * (yq & 3);
-#pragma unroll
-      for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(Yb + m * YPL + off) = pl[m];
+      for (int k = 0; k < NYJ; ++k) if (yrow0 + k * YRS < st_skip) ry[k] = zero4();
     }
 #pragma unroll
-    for (int k = 0; k < NZJ; ++k) {
-      float4 v = rz[k];
-      v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
-      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const bool ok = (zmask >> k) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      const int pix = (t + 256 * k) >> 2;
-      const int zr = pix / ZW, zj = pix - zr * ZW;
-      if (zr < 3) {
-        uint2 pl[NP];
-        wg_split4<NP>(v, pl);
-        const int off = zr * ZROW + wg_prow(zj) + 8 * zq;
+    for (int k = 0; k < NYJ; ++k) {
+      uint2 pl[NP];
+      if (ABL & 32) { for (int m = 0; m < NP; ++m) pl[m] = make_uint2(__float_as_uint(ry[k].x), __float_as_uint(ry[k].y)); } else
+      wg_split4<NP>(ry[k], pl);
+      unsigned char* o = Yb + ((k & 1) ? ysw1 : ysw0) + k * (YRS << 5);
 #pragma unroll
-        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(Zb + m * ZPL + off) = pl[m];
+      for (int m = 0; m < NP; ++m) { if (ABL & 16) asm volatile("" :: "v"(pl[m].x), "v"(pl[m].y)); else *reinterpret_cast<uint2*>(o + m * YPL) = pl[m]; }
+    }
+    const bool c0ok = __builtin_amdgcn_inverse_ballot_w64(zcm0), c1ok = __builtin_amdgcn_inverse_ballot_w64(zcm1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool rok = (zrows >> r) & 1u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !zhalf1) continue;
+        float4 v = rz[2 * r + h];
+        if (zaff) { v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w); }
+        if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const bool ok = rok && (h ? c1ok : c0ok);
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        uint2 pl[NP];
+        if (ABL & 32) { for (int m = 0; m < NP; ++m) pl[m] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); } else
+        wg_split4<NP>(v, pl);
+        unsigned char* o = Zb + zsw + r * ZROW + h * (H3_KP * 32);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) { if (ABL & 16) asm volatile("" :: "v"(pl[m].x), "v"(pl[m].y)); else *reinterpret_cast<uint2*>(o + m * ZPL) = pl[m]; }
       }
     }
   };
@@ -647,15 +686,46 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
 #undef WG_TERM
   };
 
+#ifdef ADDK_WG_DIAG
+  const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long dph[5] = {0, 0, 0, 0, 0};
+#endif
   if (sbeg < send) {
-    load_step(sbeg);
+    load_step();
     store_step();
     __syncthreads();
+    wg_bf16x8 yf0[NT][NP], zf0[NP];
+    if (ABL & 2) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) rd(Yb + (wave * NT + i) * YIMG, YPL, 0, yf0[i]);
+      rd(Zb, ZPL, 0, zf0);
+    }
     for (int seg = sbeg; seg < send; ++seg) {
       const bool more = seg + 1 < send;
-      if (more) load_step(seg + 1);
+#ifdef ADDK_WG_DIAG
+      WG_STAMP(dt0);
+#endif
+      if (more && !(ABL & 1) && !(ABL & 4)) load_step();
+#ifdef ADDK_WG_DIAG
+      WG_STAMP(dt1);
+#endif
+      if (ABL & 4) {
+#pragma unroll
+        for (int k = 0; k < NYJ; ++k) asm volatile("" : "+v"(ry[k].x), "+v"(ry[k].y), "+v"(ry[k].z), "+v"(ry[k].w));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(rz[k].x), "+v"(rz[k].y), "+v"(rz[k].z), "+v"(rz[k].w));
+      }
 #pragma unroll
       for (int ks = 0; ks < H3_KP / 32; ++ks) {
+        if (ABL & 2) {
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma(acc, tap, yf0, zf0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          continue;
+        }
         wg_bf16x8 yf[NT][NP];
 #pragma unroll
         for (int i = 0; i < NT; ++i) rd(Yb + (wave * NT + i) * YIMG, YPL, ks * 32, yf[i]);
@@ -669,10 +739,36 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#ifdef ADDK_WG_DIAG
+      WG_STAMP(dt2);
+#endif
       __syncthreads();
-      if (more) { store_step(); __syncthreads(); }
+#ifdef ADDK_WG_DIAG
+      WG_STAMP(dt3);
+      if (more) { store_step(); }
+      WG_STAMP(dt4);
+      if (more) __syncthreads();
+      WG_STAMP(dt5);
+      dph[0] += dt1 - dt0; dph[1] += dt2 - dt1; dph[2] += dt3 - dt2; dph[3] += dt4 - dt3; dph[4] += dt5 - dt4;
+      continue;
+#endif
+      if (more && (ABL & 8)) {
+#pragma unroll
+        for (int k = 0; k < NYJ; ++k) asm volatile("" :: "v"(ry[k].x), "v"(ry[k].y), "v"(ry[k].z), "v"(ry[k].w));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" :: "v"(rz[k].x), "v"(rz[k].y), "v"(rz[k].z), "v"(rz[k].w));
+        __syncthreads();
+      } else
+      if (more && !(ABL & 1)) { store_step(); __syncthreads(); }
     }
   }
+#ifdef ADDK_WG_DIAG
+  if (lane == 0) {
+    unsigned long long* dslot = g_wg_diag[(blockIdx.x * 4 + wave) & 63];
+    atomicAdd(&dslot[0], __builtin_amdgcn_s_memtime() - diag_c0); atomicAdd(&dslot[1], __builtin_amdgcn_s_memrealtime() - diag_r0); atomicAdd(&dslot[2], 1ull);
+    for (int i = 0; i < 5; ++i) atomicAdd(&dslot[3 + i], dph[i]);
+  }
+#endif
   const int C = p.src.C;
   gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * 9 * C;
   const int c = c0 + li;
@@ -1450,7 +1546,7 @@ bool use_output_split(int Cout, int C) { return os_kind(Cout, C) != 0; }
 // 5: halo-patch kernel (3x3, stride 1, 'same' padding, wide): tiles are (64*NT co) x (16 c), the nine taps live in the block
 bool h3_ok(const addk_conv_wgrad_args* a) {
   return (addk_get_fast_paths() & ADDK_FAST_WGRAD3) && a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == a->dil && a->dil >= 1 && a->dil <= 18 &&
-         a->OH == a->H && a->OW == a->W && a->Cout % 64 == 0 && a->src.C >= 16 &&
+         a->OH == a->H && a->OW == a->W && a->W >= 64 && a->Cout % 64 == 0 && a->src.C >= 16 &&
          aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) && (long)a->N * a->H * a->W >= 8192;
 }
 // 6: register-streaming kernel for the narrow cell convolutions
@@ -1526,6 +1622,16 @@ int pick_splits(long P, int tiles, int budget = 1536, int min_steps = 1) {
 
 }  // namespace
 
+#ifdef ADDK_WG_DIAG
+// the eight counters summed over the waves since the last call; resets them
+extern "C" int addk_wg_diag(unsigned long long* out8) {
+  unsigned long long h[64][8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wg_diag), sizeof h) != hipSuccess) return ADDK_ERR_INVALID;
+  for (int k = 0; k < 8; ++k) { out8[k] = 0; for (int i = 0; i < 64; ++i) out8[k] += h[i][k]; }
+  for (int i = 0; i < 64; ++i) for (int k = 0; k < 8; ++k) h[i][k] = 0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_diag), h, sizeof h) == hipSuccess ? ADDK_OK : ADDK_ERR_INVALID;
+}
+#endif
 extern "C" int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_t taps) {
   int cty, ctz; pick_tiles(Cout, C, &cty, &ctz);
   int tiles = cdiv(Cout, 16 * cty) * taps * cdiv(C, 16 * ctz);
@@ -1669,7 +1775,9 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
   const int wg_np = wg_prec == 2 ? 3 : wg_prec == 1 ? 2 : wg_prec == 3 ? (cty == 8 ? 2 : 3) : 0;
 #define ADDK_H3B_(N_, B_, P_) { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; \
+      if (getenv("ADDK_WG_OCC")) { int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_>), 256, wg_h3b_lds(N_, P_)); \
+        fprintf(stderr, "addk: wgrad_h3b<%d,%d,%d> lds %zu B, grid %u x %u: %d workgroups per CU\n", N_, (int)B_, P_, wg_h3b_lds(N_, P_), grid.x, grid.y, nb); } } \
     hipLaunchKernelGGL((wgrad_h3b_kernel<N_, B_, P_>), grid, dim3(256), wg_h3b_lds(N_, P_), st, k, ops, work); done = true; }
   if (kind == 5 && cty == 8 && wg_np && wgrad_split_enabled()) {
     if (ops) { if (wg_np == 3) ADDK_H3B_(2, true, 3) else ADDK_H3B_(2, true, 2) }

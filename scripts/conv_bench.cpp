@@ -130,6 +130,14 @@ int main(int argc, char** argv) {
       if (diag && mode < 2 && diag(dv) == 0 && dv[1])
         printf("      in-kernel clock: %.0f MHz (s_memtime / s_memrealtime over %llu workgroups, mean workgroup life %.1f us)\n",
                100.0 * (double)dv[0] / (double)dv[1], dv[2], (double)dv[1] / (double)dv[2] / 100.0);
+      // (-DADDK_WG_DIAG): clock and phase split inside wgrad_h3b_kernel
+      static diag_fn wdiag = (diag_fn)dlsym(RTLD_DEFAULT, "addk_wg_diag");
+      unsigned long long wv[8];
+      if (wdiag && mode == 2 && wdiag(wv) == 0 && wv[1]) {
+        const double life = (double)wv[0];
+        printf("      in-kernel clock: %.0f MHz over %llu waves, mean wave life %.1f us; of it: load issue %.1f %%, matrix phase %.1f %%, barrier %.1f %%, split + LDS stores %.1f %%, barrier %.1f %%\n",
+               100.0 * life / (double)wv[1], wv[2], (double)wv[1] / (double)wv[2] / 100.0, 100.0 * wv[3] / life, 100.0 * wv[4] / life, 100.0 * wv[5] / life, 100.0 * wv[6] / life, 100.0 * wv[7] / life);
+      }
     }
     hipFree(x); hipFree(a); hipFree(b); hipFree(w); hipFree(y); hipFree(g); hipFree(slab); hipFree(dab); hipFree(wg.dw); hipFree(wg.ws);
   }
