@@ -527,49 +527,55 @@ __device__ __forceinline__ int wg_prow(int p) { return (p << 5) ^ (((p >> 3) & 1
 #ifdef ADDK_WG_DIAG
 // diagnostic build (scripts/wgrad_phases.sh): every wave of wgrad_h3b_kernel adds its lifetime in shader-clock ticks (s_memtime) and in 100 MHz reference ticks
 // (s_memrealtime) — their ratio is the clock the CUs ran at inside the kernel — and the shader ticks it spent in each phase of the segment loop:
-// [0] life (shader) [1] life (reference) [2] waves [3] issuing the next segment's loads [4] matrix phase (fragment reads + MFMA) [5] waiting at the barrier
+// [0] life (shader) [1] life (reference) [2] waves [3] preparing the next segment's addresses [4] matrix phase (fragment reads + MFMA + the next segment's loads) [5] waiting at the barrier
 // after it [6] split + LDS stores (including the wait for the loads) [7] waiting at the barrier after them
 __device__ unsigned long long g_wg_diag[64][8];
+#ifdef ADDK_WG_DIAG2
+__device__ unsigned long long g_wg_diag2[64][2];
+#endif
 #define WG_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #endif
-template <int NT, bool BATCH, int NP>
-__global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+// NG = 2: a 512-thread workgroup of two wave groups, one per 16-channel input tile, which SHARE the staged dy tile (two 256-thread workgroups of
+// neighbouring input tiles — which sit on one CU and run their phases together anyway: scripts/wgrad_phases.sh — split and store the same dy twice)
+template <int NT, bool BATCH, int NP, int NG>
+__global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
   int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
   if (BATCH) {
     const int4 wk = work[blockIdx.x];
     op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
   }
   const WgK p = wg_desc<BATCH>(pv, ops, op);
-  constexpr int BCO = 64 * NT, YT = BCO / 16, YQ = BCO / 4, YRS = 256 / YQ;
+  constexpr int NTHR = 256 * NG, BCO = 64 * NT, YT = BCO / 16, YQ = BCO / 4, YRS = NTHR / YQ;
   constexpr int NYJ = H3_KP / YRS;
   constexpr int ZWP = 104;                                        // patch row pitch in pixels (>= 64 + 2*18, multiple of 8: the swizzle works on 8-pixel blocks)
   // bytes per dy tile image / per activation patch row (one plane).  The tile images are 32 bytes apart from a multiple of
   // the 256-byte bank period: the 8 tiles x 4 channel quads a half-wave stores for one pixel row then cover all 64 banks once
   constexpr int YIMG = H3_KP * 32 + 32, ZROW = ZWP * 32;
-  constexpr int YPL = YT * YIMG, ZPL = 3 * ZROW;                  // bytes per plane
+  constexpr int ZTILE = 3 * ZROW;                                 // one input-channel tile of the patch (one plane)
+  constexpr int YPL = YT * YIMG, ZPL = NG * ZTILE;                // bytes per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   unsigned char* Yb = wsm;                                        // [NP][YT][64 px][16 co]
-  unsigned char* Zb = wsm + NP * YPL;                             // [NP][3 rows][ZWP px][16 ci]
+  unsigned char* Zb = wsm + NP * YPL;                             // [NP][NG tiles][3 rows][ZWP px][16 ci]
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
+  const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6), wave = wave8 & 3, grp = wave8 >> 2;      // output-channel tiles of this wave; its input-channel tile
   const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
-  const int co0 = yt * BCO, c0 = zt * 16;
+  const int co0 = yt * BCO, c0 = zt * 16 * NG;
   const int d = p.dil, ZW = H3_KP + 2 * d;
   const int spr = (p.OW + H3_KP - 1) / H3_KP;
   const int nseg = p.N * p.OH * spr;
   const int sbeg = blk_y * p.chunkP;
   int send = sbeg + p.chunkP; if (send > nseg) send = nseg;
 
-#ifdef ADDK_WG_ABL       // ablation builds (scripts/wgrad_ablate.sh): WRONG numbers.  bit 0: no staging inside the loop; bit 1: no fragment reads inside the
-  constexpr int ABL = ADDK_WG_ABL;      // loop; bit 2: no global loads (the split + LDS stores run on stale registers); bit 3: loads only (no split, no LDS stores);
-#else                                   // bit 4: the split without its LDS stores; bit 5: the LDS stores without the split
-  constexpr int ABL = 0;
-#endif
   // Staging geometry.  Everything a thread needs per segment is a THREAD CONSTANT (a byte offset from a segment-uniform base pointer, an LDS
-  // offset) plus segment scalars: no per-slot divisions, address arithmetic or validity bits in vector registers (the kernel is bound by
-  // the SIMD's issue port — 8 cycles per MFMA, 4 per vector instruction: scripts/wgrad_ablate.sh — so every vector instruction saved is time).
+  // offset) plus segment scalars: no per-slot divisions, address arithmetic or validity bits in vector registers.
   //   dy: thread (yq, yrow0) owns channel quad yq of rows yrow0 + k YRS of the 64-pixel segment;
   //   patch: thread (zq, zj0) owns channel quad zq of patch columns zj0 and 64 + zj0 (the latter only below 2 d) of each of the 3 rows.
+  // The NEXT segment's global loads are issued one per tap INSIDE the matrix phase (they are branch-free: a lane without a valid element
+  // reads element 0 of a valid row and is masked when the patch is stored): measured with the in-kernel phase clock (scripts/wgrad_phases.sh),
+  // issuing 14 KB of loads per wave in one burst held every wave for 11 % of its life at the CU's 64 B/clk address path.
+  constexpr int NIT = NYJ + 6;                                      // load items per segment: NYJ dy rows, 3 patch rows x 2 halves
+  static_assert(NIT <= 18, "one load item per (k-step, tap)");
   const int yq = t & (YQ - 1), yrow0 = t / YQ;
   const int co = co0 + 4 * yq;                                      // < Cout: BCO divides Cout (wg_fill)
   const unsigned yoff = ((unsigned)yrow0 * (unsigned)p.lddy + (unsigned)co) * 4u;
@@ -577,9 +583,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
   // LDS offset of row yrow0 + k YRS = (k even ? ysw0 : ysw1) + k YRS 32: the swizzle bit (bit 3 of the row) alternates with k when YRS = 8
   const int ytile = (yq >> 2) * YIMG + 8 * (yq & 3);
   const int ysw0 = ytile + wg_prow(yrow0), ysw1 = ytile + wg_prow(yrow0 + YRS) - (YRS << 5);
-  const int zq = t & 3, zj0 = t >> 2, zc = c0 + 4 * zq, nremz = p.src.C - zc;
-  const unsigned zoff = ((unsigned)zj0 * (unsigned)p.src.ld + (unsigned)zc) * 4u;
-  const int zsw = wg_prow(zj0) + 8 * zq;                            // second half: + 64 * 32 (bit 3 of 64 + zj0 is bit 3 of zj0)
+  constexpr int ZQ = 4 * NG;                                        // channel quads per patch pixel
+  const int zq = t & (ZQ - 1), zj0 = t / ZQ, zc = c0 + 4 * zq, nremz = p.src.C - zc;
+  const unsigned zldb = (unsigned)p.src.ld * 4u;
+  const unsigned zoff = (unsigned)zj0 * zldb + (unsigned)zc * 4u;     // byte offset of (patch column zj0, channel zc) from the patch row's column 0
+  const int zsw = (zq >> 2) * ZTILE + wg_prow(zj0) + 8 * (zq & 3);  // second half: + 64 * 32 (bit 3 of 64 + zj0 is bit 3 of zj0)
   const bool zhalf1 = zj0 < 2 * d;                                  // this thread has a column in the second half (64 + zj0 < ZW)
   float4 za = make_float4(1.f, 1.f, 1.f, 1.f), zb = zero4();
   if (p.src.a && nremz > 0) { za = ld4g(p.src.a + zc, nremz, p.vecZ); zb = ld4g(p.src.b + zc, nremz, p.vecZ); }
@@ -595,42 +603,54 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
     for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float4 ry[NYJ], rz[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) rz[k] = zero4();
-  // coordinates of the segment load_step fetches next (scalars, advanced incrementally), and the validity of the one in flight
-  int l_sx, l_oh, l_n;
-  { const int rowid = sbeg / spr; l_sx = sbeg - rowid * spr; l_n = rowid / p.OH; l_oh = rowid - l_n * p.OH; }
-  int st_skip = 0;                                                  // leading pixels of the segment in flight that belong to its left neighbour
+  // l_*: the segment load_prep turns to next; c_*: the one it prepared last (scalars, advanced incrementally)
+  int l_sx, l_oh, l_n, c_sx, c_oh, c_n;
+  { const int rowid = sbeg / spr; l_sx = sbeg - rowid * spr; l_n = rowid / p.OH; l_oh = rowid - l_n * p.OH; c_sx = l_sx; c_oh = l_oh; c_n = l_n; }
+  // what the load items of the prepared segment need, and the validity the store of that segment needs
+  const float* yseg = p.dy; const float* zrowp[3] = {p.src.x, p.src.x, p.src.x};
+  unsigned zo0 = 0, zo1 = 0;                                        // this lane's byte offsets in a patch row's image row (0: no valid element)
+  int st_skip = 0;                                                  // leading pixels of the segment that belong to its left neighbour
   unsigned zrows = 0;                                               // bit r: patch row r lies inside the image
   unsigned long long zcm0 = 0, zcm1 = 0;                            // lane masks: this lane's first / second column lies inside the image (and its channels exist)
-  auto load_step = [&]() {
+#ifdef ADDK_WG_DIAG2
+  unsigned long long dsub[2] = {0, 0};        // shader ticks inside store_step: waiting for the loads, the dy part (split + LDS stores, drained)
+#endif
+  auto load_prep = [&](bool next) {                                 // next == false: prepare the last segment again (a harmless reload behind the block's final matrix phase)
+    if (next) { c_sx = l_sx; c_oh = l_oh; c_n = l_n; if (++l_sx == spr) { l_sx = 0; if (++l_oh == p.OH) { l_oh = 0; ++l_n; } } }
     // the last segment of an image row is moved left to end at the row's end (OW >= 64: h3_ok); the st_skip pixels it then shares with its
-    // neighbour get dy = 0 in store_step — every segment is a full one, the loads never leave the row and need no per-lane condition
-    int ow0 = l_sx * H3_KP;
+    // neighbour get dy = 0 in store_step — every segment is a full one
+    int ow0 = c_sx * H3_KP;
     st_skip = ow0 + H3_KP - p.OW; if (st_skip < 0) st_skip = 0;
     ow0 -= st_skip;
-    const long rowid = (long)l_n * p.OH + l_oh;
-    const float* yseg = p.dy + (rowid * p.OW + ow0) * p.lddy;
-#pragma unroll
-    for (int k = 0; k < NYJ; ++k) ry[k] = ld4so(yseg + k * ystep, yoff);
+    const long rowid = (long)c_n * p.OH + c_oh;
+    yseg = p.dy + (rowid * p.OW + ow0) * p.lddy;
     const int iw0 = ow0 - d;                                        // image column of patch column 0
     const bool c0ok = nremz > 0 && (unsigned)(iw0 + zj0) < (unsigned)p.W;
     const bool c1ok = nremz > 0 && zhalf1 && (unsigned)(iw0 + H3_KP + zj0) < (unsigned)p.W;
     zcm0 = __ballot(c0ok); zcm1 = __ballot(c1ok);
+    const unsigned zbase = (unsigned)iw0 * zldb;                    // (wraps for iw0 < 0; a valid lane's sum does not)
+    zo0 = c0ok ? zbase + zoff : 0u;
+    zo1 = c1ok ? zbase + H3_KP * zldb + zoff : 0u;
     zrows = 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const int ih = l_oh + (r - 1) * d;
-      if ((unsigned)ih < (unsigned)p.H) {
-        zrows |= 1u << r;
-        const float* zrow = p.src.x + (((long)l_n * p.H + ih) * p.W + iw0) * p.src.ld;
-        if (c0ok) rz[2 * r] = ld4so(zrow, zoff);
-        if (c1ok) rz[2 * r + 1] = ld4so(zrow + (long)H3_KP * p.src.ld, zoff);
-      }
+      const int ih = c_oh + (r - 1) * d;
+      const bool rok = (unsigned)ih < (unsigned)p.H;
+      zrows |= (rok ? 1u : 0u) << r;
+      zrowp[r] = rok ? p.src.x + (((long)c_n * p.H + ih) * p.W) * p.src.ld : p.src.x;
     }
-    if (++l_sx == spr) { l_sx = 0; if (++l_oh == p.OH) { l_oh = 0; ++l_n; } }
+  };
+  auto load_item = [&](int i) {
+    if (i < NYJ) ry[i] = ld4so(yseg + i * ystep, yoff);
+    else if (i < NIT) rz[i - NYJ] = ld4so(zrowp[(i - NYJ) >> 1], ((i - NYJ) & 1) ? zo1 : zo0);
   };
   auto store_step = [&]() {
+#ifdef ADDK_WG_DIAG2
+    WG_STAMP(sa);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_STAMP(sb);
+    dsub[0] += sb - sa;
+#endif
     if (st_skip) {
 #pragma unroll
       for (int k = 0; k < NYJ; ++k) if (yrow0 + k * YRS < st_skip) ry[k] = zero4();
@@ -638,12 +658,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
 #pragma unroll
     for (int k = 0; k < NYJ; ++k) {
       uint2 pl[NP];
-      if (ABL & 32) { for (int m = 0; m < NP; ++m) pl[m] = make_uint2(__float_as_uint(ry[k].x), __float_as_uint(ry[k].y)); } else
       wg_split4<NP>(ry[k], pl);
       unsigned char* o = Yb + ((k & 1) ? ysw1 : ysw0) + k * (YRS << 5);
 #pragma unroll
-      for (int m = 0; m < NP; ++m) { if (ABL & 16) asm volatile("" :: "v"(pl[m].x), "v"(pl[m].y)); else *reinterpret_cast<uint2*>(o + m * YPL) = pl[m]; }
+      for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * YPL) = pl[m];
     }
+#ifdef ADDK_WG_DIAG2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WG_STAMP(sc);
+    dsub[1] += sc - sb;
+#endif
     const bool c0ok = __builtin_amdgcn_inverse_ballot_w64(zcm0), c1ok = __builtin_amdgcn_inverse_ballot_w64(zcm1);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -657,11 +681,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
         const bool ok = rok && (h ? c1ok : c0ok);
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
         uint2 pl[NP];
-        if (ABL & 32) { for (int m = 0; m < NP; ++m) pl[m] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); } else
         wg_split4<NP>(v, pl);
         unsigned char* o = Zb + zsw + r * ZROW + h * (H3_KP * 32);
 #pragma unroll
-        for (int m = 0; m < NP; ++m) { if (ABL & 16) asm volatile("" :: "v"(pl[m].x), "v"(pl[m].y)); else *reinterpret_cast<uint2*>(o + m * ZPL) = pl[m]; }
+        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * ZPL) = pl[m];
       }
     }
   };
@@ -690,50 +713,33 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
   const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long dph[5] = {0, 0, 0, 0, 0};
 #endif
+  const unsigned char* Zg = Zb + grp * ZTILE;
   if (sbeg < send) {
-    load_step();
+    load_prep(true);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_item(i);
     store_step();
     __syncthreads();
-    wg_bf16x8 yf0[NT][NP], zf0[NP];
-    if (ABL & 2) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) rd(Yb + (wave * NT + i) * YIMG, YPL, 0, yf0[i]);
-      rd(Zb, ZPL, 0, zf0);
-    }
     for (int seg = sbeg; seg < send; ++seg) {
       const bool more = seg + 1 < send;
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt0);
 #endif
-      if (more && !(ABL & 1) && !(ABL & 4)) load_step();
+      load_prep(more);
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt1);
 #endif
-      if (ABL & 4) {
-#pragma unroll
-        for (int k = 0; k < NYJ; ++k) asm volatile("" : "+v"(ry[k].x), "+v"(ry[k].y), "+v"(ry[k].z), "+v"(ry[k].w));
-#pragma unroll
-        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(rz[k].x), "+v"(rz[k].y), "+v"(rz[k].z), "+v"(rz[k].w));
-      }
 #pragma unroll
       for (int ks = 0; ks < H3_KP / 32; ++ks) {
-        if (ABL & 2) {
-#pragma unroll
-          for (int tap = 0; tap < 9; ++tap) {
-            __builtin_amdgcn_sched_barrier(0);
-            mma(acc, tap, yf0, zf0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          continue;
-        }
         wg_bf16x8 yf[NT][NP];
 #pragma unroll
         for (int i = 0; i < NT; ++i) rd(Yb + (wave * NT + i) * YIMG, YPL, ks * 32, yf[i]);
         wg_bf16x8 zf[2][NP];
-        rd(Zb, ZPL, ks * 32, zf[0]);                              // tap 0: patch row 0, shift 0
+        rd(Zg, ZPL, ks * 32, zf[0]);                              // tap 0: patch row 0, shift 0
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          if (tap + 1 < 9) rd(Zb + ((tap + 1) / 3) * ZROW, ZPL, ks * 32 + ((tap + 1) % 3) * d, zf[(tap + 1) & 1]);
+          load_item(ks * 9 + tap);
+          if (tap + 1 < 9) rd(Zg + ((tap + 1) / 3) * ZROW, ZPL, ks * 32 + ((tap + 1) % 3) * d, zf[(tap + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
           mma(acc, tap, yf, zf[tap & 1]);
           __builtin_amdgcn_sched_barrier(0);
@@ -745,33 +751,31 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
       __syncthreads();
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt3);
-      if (more) { store_step(); }
+#endif
+      if (more) store_step();
+#ifdef ADDK_WG_DIAG
       WG_STAMP(dt4);
+#endif
       if (more) __syncthreads();
+#ifdef ADDK_WG_DIAG
       WG_STAMP(dt5);
       dph[0] += dt1 - dt0; dph[1] += dt2 - dt1; dph[2] += dt3 - dt2; dph[3] += dt4 - dt3; dph[4] += dt5 - dt4;
-      continue;
 #endif
-      if (more && (ABL & 8)) {
-#pragma unroll
-        for (int k = 0; k < NYJ; ++k) asm volatile("" :: "v"(ry[k].x), "v"(ry[k].y), "v"(ry[k].z), "v"(ry[k].w));
-#pragma unroll
-        for (int k = 0; k < 6; ++k) asm volatile("" :: "v"(rz[k].x), "v"(rz[k].y), "v"(rz[k].z), "v"(rz[k].w));
-        __syncthreads();
-      } else
-      if (more && !(ABL & 1)) { store_step(); __syncthreads(); }
     }
   }
 #ifdef ADDK_WG_DIAG
   if (lane == 0) {
-    unsigned long long* dslot = g_wg_diag[(blockIdx.x * 4 + wave) & 63];
+    unsigned long long* dslot = g_wg_diag[(blockIdx.x * 4 + wave8) & 63];
     atomicAdd(&dslot[0], __builtin_amdgcn_s_memtime() - diag_c0); atomicAdd(&dslot[1], __builtin_amdgcn_s_memrealtime() - diag_r0); atomicAdd(&dslot[2], 1ull);
     for (int i = 0; i < 5; ++i) atomicAdd(&dslot[3 + i], dph[i]);
+#ifdef ADDK_WG_DIAG2
+    atomicAdd(&dslot[1], 0ull); atomicAdd(&g_wg_diag2[(blockIdx.x * 4 + wave8) & 63][0], dsub[0]); atomicAdd(&g_wg_diag2[(blockIdx.x * 4 + wave8) & 63][1], dsub[1]);
+#endif
   }
 #endif
   const int C = p.src.C;
   gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * 9 * C;
-  const int c = c0 + li;
+  const int c = c0 + 16 * grp + li;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -786,7 +790,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_h3b_kernel(const WgK pv, const W
 }
 inline bool wgrad_split_narrow() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT_NARROW"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 inline bool wgrad_split_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
-constexpr size_t wg_h3b_lds(int nt, int np) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + 3 * 104 * 32); }
+constexpr size_t wg_h3b_lds(int nt, int np, int ng) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + ng * 3 * 104 * 32); }
 
 // Halo-patch weight gradient of the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5: 40/80/160 channels,
 // dilation <= 2).  Same staging as wgrad_h3_kernel — per 64-pixel row segment dy [64][16*CT] and the KS activation rows
@@ -1583,17 +1587,27 @@ int kind_of(const addk_conv_wgrad_args* a) { return st_ok(a) ? 8 : h3_ok(a) ? 5 
 // (2 resident blocks per CU at NT=2, 3 at NT=1), so what matters is that the LAST round of blocks is nearly full:
 // pick the segment count per block that minimises  ceil(blocks / slots) * (steps + start-up)  over the whole launch.
 struct H3Op { int tiles; long nseg; };
+// precision of the split-bf16 weight-gradient kernels for a launch of cty output-channel tiles per workgroup (0: fp32 kernels); tail_x3 (mode 3): the
+// 128-channel blocks are the exit heads (decoder, ASPP) -> three terms; stem1's 64-channel blocks keep six
+inline int wg_np_of(int cty) { const int m = addk_get_conv_precision(); return m == 2 ? 3 : m == 1 ? 2 : m == 3 ? (cty == 8 ? 2 : 3) : 0; }
+inline bool h3b_runs(int cty) { return wg_np_of(cty) && wgrad_split_enabled() && (cty == 8 || wgrad_split_narrow()); }
+// input-channel tiles per workgroup of the 3x3 halo-patch kernel: 2 (512 threads sharing one staged dy tile) on the split-bf16 kernel when the channels fill
+// whole pairs of tiles (a half-empty pair costs what the shared dy saves: 304 and 400 channels measured equal, 256 -7 %, stem1's 64 -> 64 -14 %)
+inline int h3_ng(int Cout, int C) {
+  static int dis = -1; if (dis < 0) { const char* e = getenv("ADDK_WGRAD_NG"); dis = (e && e[0] == '1') ? 1 : 0; }
+  return (!dis && C % 32 == 0 && h3b_runs(Cout % 128 == 0 ? 8 : 4)) ? 2 : 1;
+}
 inline int h3_tiles(int Cout, int C) { const int nt = Cout % 128 == 0 ? 2 : 1; return (Cout / (64 * nt)) * cdiv(C, 16); }
 // at most 32 workspace slices, or as many as it takes for the op alone to offer one block per slot (few-tile convs: stem1)
 inline int h3_max_splits(int tiles) { const int s = cdiv(768, tiles); return s > 32 ? s : 32; }
-inline int h3_splits(long nseg, int steps, int tiles) {
+inline int h3_splits(long nseg, int steps, int tiles, int cap_tiles = 0) {      // cap_tiles: the tile count the workspace was sized with
   int sp = cdiv(nseg, steps);
-  const int cap = h3_max_splits(tiles);
+  const int cap = h3_max_splits(cap_tiles ? cap_tiles : tiles);
   if (sp > cap) sp = cap;
   return cdiv(nseg, cdiv(nseg, sp));
 }
-int h3_pick_steps(const H3Op* ops, int n, int nt) {
-  const long slots = nt == 2 ? 512 : 768;
+int h3_pick_steps(const H3Op* ops, int n, int nt, int ng = 1) {
+  const long slots = ng == 2 ? 256 : nt == 2 ? 512 : 768;
   int best = 64; double best_cost = -1.0;
   for (int steps = 8; steps <= 256; ++steps) {
     long blocks = 0; long longest = 0;
@@ -1628,6 +1642,12 @@ extern "C" int addk_wg_diag(unsigned long long* out8) {
   unsigned long long h[64][8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wg_diag), sizeof h) != hipSuccess) return ADDK_ERR_INVALID;
   for (int k = 0; k < 8; ++k) { out8[k] = 0; for (int i = 0; i < 64; ++i) out8[k] += h[i][k]; }
+#ifdef ADDK_WG_DIAG2
+  { unsigned long long h2[64][2]; (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_wg_diag2), sizeof h2); unsigned long long a = 0, b = 0;
+    for (int i = 0; i < 64; ++i) { a += h2[i][0]; b += h2[i][1]; h2[i][0] = h2[i][1] = 0; }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_diag2), h2, sizeof h2);
+    fprintf(stderr, "      inside split + LDS stores: waiting for the loads %.1f %% of wave life, dy part %.1f %%\n", 100.0 * a / out8[0], 100.0 * b / out8[0]); }
+#endif
   for (int i = 0; i < 64; ++i) for (int k = 0; k < 8; ++k) h[i][k] = 0;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_diag), h, sizeof h) == hipSuccess ? ADDK_OK : ADDK_ERR_INVALID;
 }
@@ -1667,13 +1687,13 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   ADDK_REQUIRE(!check_ws || h3_ok(a) || hk_ok(a) || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   k.chunkP = cdiv(cdiv(k.P, k.splits), KP) * KP;
   if (h3_ok(a)) {      // halo-patch kernel: pixel range in 64-pixel row segments, never more slices than the workspace bound
-    const int nt = a->Cout % 128 == 0 ? 2 : 1;
-    cty = 4 * nt; ctz = 1;
-    k.nyt = a->Cout / (64 * nt); k.nzt = cdiv(a->src.C, 16);
+    const int nt = a->Cout % 128 == 0 ? 2 : 1, ng = h3_ng(a->Cout, a->src.C);
+    cty = 4 * nt; ctz = ng;
+    k.nyt = a->Cout / (64 * nt); k.nzt = cdiv(a->src.C, 16 * ng);
     tiles = k.nyt * k.nzt;
     const long nseg = (long)a->N * a->OH * cdiv(a->OW, H3_KP);
-    if (h3_steps <= 0) { H3Op o{tiles, nseg}; h3_steps = h3_pick_steps(&o, 1, nt); }
-    k.splits = h3_splits(nseg, h3_steps, tiles);
+    if (h3_steps <= 0) { H3Op o{tiles, nseg}; h3_steps = h3_pick_steps(&o, 1, nt, ng); }
+    k.splits = h3_splits(nseg, h3_steps, tiles, h3_tiles(a->Cout, a->src.C));
     k.chunkP = cdiv(nseg, k.splits);
     ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   }
@@ -1770,23 +1790,20 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
 #undef ADDK_RS
   // 3x3 convolutions in a split-bf16 mode: the transposed-read kernel — the 128-channel blocks (decoder, ASPP) and the
   // 64-channel blocks (stem1: 0.76 -> 0.61 ms alone; ADDK_WGRAD_SPLIT_NARROW=0 keeps stem1 and the cells' dilated convs on fp32)
-  const int wg_prec = addk_get_conv_precision();
-  // tail_x3 (mode 3): the 128-channel blocks are the exit heads (decoder, ASPP) -> three terms; stem1's 64-channel blocks keep six
-  const int wg_np = wg_prec == 2 ? 3 : wg_prec == 1 ? 2 : wg_prec == 3 ? (cty == 8 ? 2 : 3) : 0;
-#define ADDK_H3B_(N_, B_, P_) { \
+  const int wg_np = wg_np_of(cty);
+  if (kind == 5 && ctz == 2 && !h3b_runs(cty)) { addk_set_error("conv_wgrad: launch prepared for the split-bf16 kernel, but the precision mode / ADDK_WGRAD_SPLIT changed since"); return ADDK_ERR_INVALID; }
+#define ADDK_H3B_(N_, B_, P_, G_) { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; \
-      if (getenv("ADDK_WG_OCC")) { int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_>), 256, wg_h3b_lds(N_, P_)); \
-        fprintf(stderr, "addk: wgrad_h3b<%d,%d,%d> lds %zu B, grid %u x %u: %d workgroups per CU\n", N_, (int)B_, P_, wg_h3b_lds(N_, P_), grid.x, grid.y, nb); } } \
-    hipLaunchKernelGGL((wgrad_h3b_kernel<N_, B_, P_>), grid, dim3(256), wg_h3b_lds(N_, P_), st, k, ops, work); done = true; }
-  if (kind == 5 && cty == 8 && wg_np && wgrad_split_enabled()) {
-    if (ops) { if (wg_np == 3) ADDK_H3B_(2, true, 3) else ADDK_H3B_(2, true, 2) }
-    else { if (wg_np == 3) ADDK_H3B_(2, false, 3) else ADDK_H3B_(2, false, 2) }
-  }
-  if (kind == 5 && cty == 4 && wg_np && wgrad_split_enabled() && wgrad_split_narrow()) {
-    if (ops) { if (wg_np == 3) ADDK_H3B_(1, true, 3) else ADDK_H3B_(1, true, 2) }
-    else { if (wg_np == 3) ADDK_H3B_(1, false, 3) else ADDK_H3B_(1, false, 2) }
-  }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; \
+      if (getenv("ADDK_WG_OCC")) { int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_, G_>), 256 * G_, wg_h3b_lds(N_, P_, G_)); \
+        fprintf(stderr, "addk: wgrad_h3b<%d,%d,%d,%d> lds %zu B, grid %u x %u: %d workgroups per CU\n", N_, (int)B_, P_, G_, wg_h3b_lds(N_, P_, G_), grid.x, grid.y, nb); } } \
+    hipLaunchKernelGGL((wgrad_h3b_kernel<N_, B_, P_, G_>), grid, dim3(256 * G_), wg_h3b_lds(N_, P_, G_), st, k, ops, work); done = true; }
+#define ADDK_H3B(N_, G_) \
+    if (ops) { if (wg_np == 3) ADDK_H3B_(N_, true, 3, G_) else ADDK_H3B_(N_, true, 2, G_) } \
+    else { if (wg_np == 3) ADDK_H3B_(N_, false, 3, G_) else ADDK_H3B_(N_, false, 2, G_) }
+  if (kind == 5 && cty == 8 && h3b_runs(cty)) { if (ctz == 2) { ADDK_H3B(2, 2) } else { ADDK_H3B(2, 1) } }
+  if (kind == 5 && cty == 4 && h3b_runs(cty)) { if (ctz == 2) { ADDK_H3B(1, 2) } else { ADDK_H3B(1, 1) } }
+#undef ADDK_H3B
 #undef ADDK_H3B_
 #define ADDK_H3(NT_) \
   if (!done && kind == 5 && cty == 4 * NT_) { \
@@ -1853,13 +1870,13 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
   }
   if (h3_ok(&a[0])) {
     H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
-    const int nt = a[0].Cout % 128 == 0 ? 2 : 1;
+    const int nt = a[0].Cout % 128 == 0 ? 2 : 1, ng = h3_ng(a[0].Cout, a[0].src.C);
     for (int i = 0; i < n; ++i) {
       const int nti = a[i].Cout % 128 == 0 ? 2 : 1;
-      ho[i].tiles = (a[i].Cout / (64 * nti)) * cdiv(a[i].src.C, 16);
+      ho[i].tiles = (a[i].Cout / (64 * nti)) * cdiv(a[i].src.C, 16 * h3_ng(a[i].Cout, a[i].src.C));
       ho[i].nseg = (long)a[i].N * a[i].OH * cdiv(a[i].OW, H3_KP);
     }
-    h3_steps = h3_pick_steps(ho, n, nt);
+    h3_steps = h3_pick_steps(ho, n, nt, ng);
     free(ho);
   }
   for (int i = 0; i < n; ++i) {

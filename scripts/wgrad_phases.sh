@@ -10,4 +10,4 @@ rm -f $D/pkg/csrc/wgrad.o
 (cd $D/pkg/csrc && make -j16 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-result -ffp-contract=off -DADDK_WG_DIAG ${WG_EXTRA_DEFINES}" 2>&1 | tail -3)
 cd $GRAFT_REPO_ROOT
 hipcc -O2 --offload-arch=gfx950 -Iinclude scripts/conv_bench.cpp -L$D/pkg -laddk -ldl -Wl,-rpath,$D/pkg -o /tmp/conv_bench_wgdiag 2>&1 | grep -v warning | tail -5
-for sh in "decoder 3x3 304" "decoder 3x3 256" "aspp 3x3" "stem 3x3"; do SHAPES="$sh" ADDK_MATH=bf16x6 /tmp/conv_bench_wgdiag 20 2>&1 | grep -v amdgpu.ids | grep -A1 wgrad; done
+for sh in "decoder 3x3 304" "decoder 3x3 256" "aspp 3x3" "stem 3x3"; do SHAPES="$sh" ADDK_MATH=bf16x6 /tmp/conv_bench_wgdiag 20 2>&1 | grep -v amdgpu.ids | grep -E -A1 "wgrad|inside split"; done
