@@ -527,8 +527,8 @@ __device__ __forceinline__ int wg_prow(int p) { return (p << 5) ^ (((p >> 3) & 1
 #ifdef ADDK_WG_DIAG
 // diagnostic build (scripts/wgrad_phases.sh): every wave of wgrad_h3b_kernel adds its lifetime in shader-clock ticks (s_memtime) and in 100 MHz reference ticks
 // (s_memrealtime) — their ratio is the clock the CUs ran at inside the kernel — and the shader ticks it spent in each phase of the segment loop:
-// [0] life (shader) [1] life (reference) [2] waves [3] preparing the next segment's addresses [4] matrix phase (fragment reads + MFMA + the next segment's loads) [5] waiting at the barrier
-// after it [6] split + LDS stores (including the wait for the loads) [7] waiting at the barrier after them
+// [0] life (shader) [1] life (reference) [2] waves [3] preparing the next segment's addresses [4] matrix phase (fragment reads + MFMA + the next segment's loads) [5] the split into registers
+// (including the wait for the loads) [6] waiting at the barrier behind it [7] LDS stores and the barrier behind them
 __device__ unsigned long long g_wg_diag[64][8];
 #ifdef ADDK_WG_DIAG2
 __device__ unsigned long long g_wg_diag2[64][2];
@@ -644,30 +644,12 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
     if (i < NYJ) ry[i] = ld4so(yseg + i * ystep, yoff);
     else if (i < NIT) rz[i - NYJ] = ld4so(zrowp[(i - NYJ) >> 1], ((i - NYJ) & 1) ? zo1 : zo0);
   };
-  auto store_step = [&]() {
-#ifdef ADDK_WG_DIAG2
-    WG_STAMP(sa);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WG_STAMP(sb);
-    dsub[0] += sb - sa;
-#endif
-    if (st_skip) {
-#pragma unroll
-      for (int k = 0; k < NYJ; ++k) if (yrow0 + k * YRS < st_skip) ry[k] = zero4();
-    }
-#pragma unroll
-    for (int k = 0; k < NYJ; ++k) {
-      uint2 pl[NP];
-      wg_split4<NP>(ry[k], pl);
-      unsigned char* o = Yb + ((k & 1) ? ysw1 : ysw0) + k * (YRS << 5);
-#pragma unroll
-      for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * YPL) = pl[m];
-    }
-#ifdef ADDK_WG_DIAG2
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    WG_STAMP(sc);
-    dsub[1] += sc - sb;
-#endif
+  // The split runs BEFORE the barrier that ends the matrix phase, into registers (the SIMD's arbiter serves the older of its two waves first: the wave that
+  // leaves the matrix phase early splits under the other one's MFMAs instead of waiting at the barrier), the LDS stores behind it.
+  constexpr bool PRE_Z = !(NT == 2 && (NP == 3 || NG == 1));      // (the two-tile six-term forms have no registers for the patch's planes: only dy is split early,
+  constexpr bool PRE_Y = !(NT == 2 && NP == 3 && NG == 1);      //  and nothing at all in the 256-thread form, whose threads hold eight dy rows)
+  uint2 py[NYJ][NP], pz[6][NP];
+  auto split_z = [&]() {
     const bool c0ok = __builtin_amdgcn_inverse_ballot_w64(zcm0), c1ok = __builtin_amdgcn_inverse_ballot_w64(zcm1);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -680,13 +662,54 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
         if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         const bool ok = rok && (h ? c1ok : c0ok);
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-        uint2 pl[NP];
-        wg_split4<NP>(v, pl);
-        unsigned char* o = Zb + zsw + r * ZROW + h * (H3_KP * 32);
+        wg_split4<NP>(v, pz[2 * r + h]);
+        if (!PRE_Z) {
+          unsigned char* o = Zb + zsw + r * ZROW + h * (H3_KP * 32);
 #pragma unroll
-        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * ZPL) = pl[m];
+          for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * ZPL) = pz[2 * r + h][m];
+        }
       }
     }
+  };
+  auto split_step = [&]() {
+#ifdef ADDK_WG_DIAG2
+    WG_STAMP(sa);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_STAMP(sb);
+    dsub[0] += sb - sa;
+#endif
+    if (st_skip) {
+#pragma unroll
+      for (int k = 0; k < NYJ; ++k) if (yrow0 + k * YRS < st_skip) ry[k] = zero4();
+    }
+    if (PRE_Y) {
+#pragma unroll
+      for (int k = 0; k < NYJ; ++k) wg_split4<NP>(ry[k], py[k]);
+    }
+#ifdef ADDK_WG_DIAG2
+    WG_STAMP(sc);
+    dsub[1] += sc - sb;
+#endif
+    if (PRE_Z) split_z();
+  };
+  auto write_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      if (!PRE_Y) wg_split4<NP>(ry[k], py[k]);
+      unsigned char* o = Yb + ((k & 1) ? ysw1 : ysw0) + k * (YRS << 5);
+#pragma unroll
+      for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * YPL) = py[k][m];
+    }
+    if (!PRE_Z) { split_z(); return; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !zhalf1) continue;
+        unsigned char* o = Zb + zsw + r * ZROW + h * (H3_KP * 32);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * ZPL) = pz[2 * r + h][m];
+      }
   };
   // fragment of one 32-pixel k-step: 8 consecutive pixels of this lane's channel = two transposed reads, per plane
   auto rd = [&](const unsigned char* base, int plane_bytes, int pix0, wg_bf16x8* f) {
@@ -718,7 +741,8 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
     load_prep(true);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_item(i);
-    store_step();
+    split_step();
+    write_step();
     __syncthreads();
     for (int seg = sbeg; seg < send; ++seg) {
       const bool more = seg + 1 < send;
@@ -748,15 +772,15 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt2);
 #endif
-      __syncthreads();
+      if (more) split_step();
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt3);
 #endif
-      if (more) store_step();
+      __syncthreads();
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt4);
 #endif
-      if (more) __syncthreads();
+      if (more) { write_step(); __syncthreads(); }
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt5);
       dph[0] += dt1 - dt0; dph[1] += dt2 - dt1; dph[2] += dt3 - dt2; dph[3] += dt4 - dt3; dph[4] += dt5 - dt4;

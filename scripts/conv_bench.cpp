@@ -135,7 +135,7 @@ int main(int argc, char** argv) {
       unsigned long long wv[8];
       if (wdiag && mode == 2 && wdiag(wv) == 0 && wv[1]) {
         const double life = (double)wv[0];
-        printf("      in-kernel clock: %.0f MHz over %llu waves, mean wave life %.1f us; of it: address preparation %.1f %%, matrix phase %.1f %%, barrier %.1f %%, split + LDS stores %.1f %%, barrier %.1f %%\n",
+        printf("      in-kernel clock: %.0f MHz over %llu waves, mean wave life %.1f us; of it: address preparation %.1f %%, matrix phase %.1f %%, split %.1f %%, barrier %.1f %%, LDS stores + barrier %.1f %%\n",
                100.0 * life / (double)wv[1], wv[2], (double)wv[1] / (double)wv[2] / 100.0, 100.0 * wv[3] / life, 100.0 * wv[4] / life, 100.0 * wv[5] / life, 100.0 * wv[6] / life, 100.0 * wv[7] / life);
       }
     }
