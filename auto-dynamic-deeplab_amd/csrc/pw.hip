@@ -757,9 +757,98 @@ extern "C" int addk_conv_fwd_resample_ok(const addk_conv_args* a) {
   bool rs;
   return pwk_covers(a, rs) ? 1 : 0;
 }
+// Data gradient of a 1x1 convolution with FEW output channels into a wide input — the classifier (decoder.py last_conv, 256 -> 19 classes):
+// 0.6 GF against 2 x 67 MB at config 2.  On the generic implicit-GEMM kernel (LDS tiles, 32-channel chunks with 19 live k slots) it took 110 us;
+// here a lane owns four input channels (64 lanes = 256 channels), keeps its K x 4 weights in registers, and a wave walks pixels: the K values of
+// dy of a pixel are loaded by K lanes and broadcast by v_readlane, the product is K x 4 fp32 FMAs per lane, the ReLU mask / (dA, dB) sums / store
+// follow as in pw_kernel's data gradient.  Two pixels per trip (all loads of both before any use).
+struct K1sK {
+  const float* dy; int lddy, K;
+  const float* w; int ldw, w_off;
+  addk_src dst; float* g; int ldg, accumulate;
+  double* slab; int P, rows, gx, Cn;
+};
+template <int KMAX>
+__global__ void __launch_bounds__(256) k1s_dgrad_kernel(const K1sK p) {
+  __shared__ double red[4][256][2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int c = 4 * lane;
+  const bool cok = c < p.Cn;
+  float4 wq[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) wq[k] = (k < p.K && cok) ? ld4(p.w + (long)k * p.ldw + p.w_off + c) : zero4();
+  float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
+  if (p.dst.a && cok) { av = ld4(p.dst.a + c); bv = ld4(p.dst.b + c); }
+  const bool relu = p.dst.relu != 0, acc = p.accumulate != 0;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  const gfloat* dyg = (const gfloat*)p.dy;
+  auto finish = [&](int pp, const float4 dz, const float4 x, const float4 old) {
+    float4 g4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), d = get4(dz, e);
+      const bool m = !relu || fmaf(ae, xe, be) > 0.f;
+      set4(g4, e, m ? d * ae : 0.f);
+      if (m) { s1[e] += (double)d * (double)xe; s2[e] += (double)d; }
+    }
+    if (acc) { g4.x += old.x; g4.y += old.y; g4.z += old.z; g4.w += old.w; }
+    st4(p.g + (long)pp * p.ldg + c, g4);
+  };
+  const int nw = p.gx * 4;
+  for (int p0 = blockIdx.x * 4 + wave; p0 < p.P; p0 += 2 * nw) {
+    const int p1 = p0 + nw;
+    const bool ok1 = p1 < p.P;
+    const float d0 = lane < p.K ? dyg[(long)p0 * p.lddy + lane] : 0.f;
+    const float d1 = (ok1 && lane < p.K) ? dyg[(long)p1 * p.lddy + lane] : 0.f;
+    float4 x0 = zero4(), x1 = zero4(), o0 = zero4(), o1 = zero4();
+    if (cok) {
+      x0 = ld4(p.dst.x + (long)p0 * p.dst.ld + c);
+      if (ok1) x1 = ld4(p.dst.x + (long)p1 * p.dst.ld + c);
+      if (acc) { o0 = ld4(p.g + (long)p0 * p.ldg + c); if (ok1) o1 = ld4(p.g + (long)p1 * p.ldg + c); }
+    }
+    float4 a0 = zero4(), a1 = zero4();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), k)), u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), k));
+      a0.x = fmaf(u0, wq[k].x, a0.x); a0.y = fmaf(u0, wq[k].y, a0.y); a0.z = fmaf(u0, wq[k].z, a0.z); a0.w = fmaf(u0, wq[k].w, a0.w);
+      a1.x = fmaf(u1, wq[k].x, a1.x); a1.y = fmaf(u1, wq[k].y, a1.y); a1.z = fmaf(u1, wq[k].z, a1.z); a1.w = fmaf(u1, wq[k].w, a1.w);
+    }
+    if (cok) { finish(p0, a0, x0, o0); if (ok1) finish(p1, a1, x1, o1); }
+  }
+  if (p.slab) {      // the four waves through LDS in a fixed order; one slab row per workgroup, rows no workgroup owns zeroed
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][c + e][0] = s1[e]; red[wave][c + e][1] = s2[e]; }
+    __syncthreads();
+    if (t < p.Cn) {
+      gdouble* o = (gdouble*)p.slab + ((long)blockIdx.x * p.Cn + t) * 2;
+      o[0] = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
+      o[1] = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
+      for (int r = blockIdx.x + p.gx; r < p.rows; r += p.gx) {
+        gdouble* z = (gdouble*)p.slab + ((long)r * p.Cn + t) * 2;
+        z[0] = 0.0; z[1] = 0.0;
+      }
+    }
+  }
+}
+static int k1s_try_dgrad(const addk_conv_dgrad_args* a, int rows, hipStream_t st) {
+  static int en = -1; if (en < 0) { const char* e = getenv("ADDK_K1S"); en = (e && e[0] == '0') ? 0 : 1; }
+  if (!en || a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->H != a->OH || a->W != a->OW) return 1;
+  if (a->Cout > 32 || a->dst.C < 128 || a->dst.C > 256 || a->dst.C % 4) return 1;
+  if (!src_vec_ok(a->dst) || !aligned16(a->g) || a->ldg % 4 || !aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return 1;
+  if (a->dst.a && (!aligned16(a->dst.a) || !aligned16(a->dst.b))) return 1;
+  K1sK k{};
+  k.dy = a->dy; k.lddy = a->lddy; k.K = a->Cout; k.w = a->w; k.ldw = a->ldw; k.w_off = a->w_choff;
+  k.dst = a->dst; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate; k.slab = a->dab;
+  k.P = a->N * a->H * a->W; k.rows = rows; k.gx = rows; k.Cn = a->dst.C;
+  if (k.gx > cdiv(k.P, 8)) k.gx = cdiv(k.P, 8);
+  if (k.gx < 1) k.gx = 1;
+  if (a->Cout <= 20) hipLaunchKernelGGL((k1s_dgrad_kernel<20>), dim3(k.gx), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((k1s_dgrad_kernel<32>), dim3(k.gx), dim3(256), 0, st, k);
+  return addk_check_launch("conv_dgrad (1x1, few output channels)");
+}
 int addk_pw_try_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream) {
   PwK k;
-  if (!pw_fill_dgrad(a, k)) return 1;
+  if (!pw_fill_dgrad(a, k)) return k1s_try_dgrad(a, rows, (hipStream_t)stream);
   return pw_launch<PW_DGRAD>(k, rows, (hipStream_t)stream);
 }
 

@@ -347,3 +347,51 @@ def test_inference_plan_uses_one_launch_per_sepconv_and_equals_the_two_half_plan
     for a, b in zip(outs['1'], outs['0']):
         e = float((a.double() - b.double()).abs().max() / b.double().abs().max())
         assert e < 2e-5, e
+
+
+# ---- data gradient of the classifier (1x1, 256 -> 19): the register-weights / readlane kernel (pw.hip k1s_dgrad_kernel) -------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 33, 65, 256, 19, True, False), (1, 40, 50, 128, 19, False, True), (2, 17, 31, 256, 32, True, True),
+                                   (1, 128, 256, 256, 19, True, False)], ids=['c256_k19', 'c128_noaffine_acc', 'c256_k32_acc', 'classifier_full_map'])
+def test_classifier_data_gradient_matches_fp64_and_the_generic_kernel(shape):
+    """decoder.py last_conv backward: g = relu'(a x + b) * a * (dy W), (dA, dB) = sum over pixels of (m dz x, m dz); odd pixel counts (a wave's
+    second pixel of the last trip missing), accumulate, no lazy BatchNorm on the destination; against fp64 and against ADDK_K1S-less dispatch."""
+    import ctypes as C
+    import torch
+    from addk import _lib as L
+    N, H, W, Cn, K, affine, accumulate = shape
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(sum(map(int, shape[:5])))
+    P = N * H * W
+    dy = torch.randn(P, K, device=dev)
+    w = 0.1 * torch.randn(K, Cn, device=dev)
+    x = torch.randn(P, Cn, device=dev)
+    a = torch.rand(Cn, device=dev) + 0.5
+    b = 0.2 * torch.randn(Cn, device=dev)
+    g0 = torch.randn(P, Cn, device=dev)
+    rows = lib.addk_conv_rows(P, Cn)
+
+    def run():
+        da = L.ConvDgradArgs()
+        da.dy, da.lddy, da.Cout = dy.data_ptr(), K, K
+        da.N, da.H, da.W, da.OH, da.OW, da.KH, da.KW, da.stride, da.pad, da.dil = N, H, W, H, W, 1, 1, 1, 0, 1
+        da.w, da.ldw, da.cin_total, da.w_choff = w.data_ptr(), Cn, Cn, 0
+        da.dst.x, da.dst.ld, da.dst.C, da.dst.relu = x.data_ptr(), Cn, Cn, 1
+        if affine:
+            da.dst.a, da.dst.b = a.data_ptr(), b.data_ptr()
+        g = g0.clone() if accumulate else torch.full((P, Cn), float('nan'), device=dev)
+        dab = torch.full((rows, Cn, 2), float('nan'), device=dev, dtype=torch.float64)
+        da.g, da.ldg, da.accumulate, da.dab = g.data_ptr(), Cn, int(accumulate), dab.data_ptr()
+        L.check(lib.addk_conv_dgrad(C.byref(da), torch.cuda.current_stream().cuda_stream), 'conv_dgrad')
+        torch.cuda.synchronize()
+        return g, dab.sum(0)
+    g, dab = run()
+    a64, b64 = (a.double(), b.double()) if affine else (torch.ones(Cn, device=dev, dtype=torch.float64), torch.zeros(Cn, device=dev, dtype=torch.float64))
+    dz = dy.double() @ w.double()
+    m = (a64 * x.double() + b64) > 0
+    ref_g = torch.where(m, dz * a64, torch.zeros_like(dz)) + (g0.double() if accumulate else 0)
+    ref_dab = torch.stack([(dz * x.double() * m).sum(0), (dz * m).sum(0)], 1)
+    assert torch.isfinite(g).all() and torch.isfinite(dab).all()
+    assert float((g.double() - ref_g).abs().max() / ref_g.abs().max()) < 2e-6
+    assert float((dab - ref_dab).abs().max() / ref_dab.abs().max()) < 2e-6
