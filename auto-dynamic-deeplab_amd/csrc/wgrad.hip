@@ -551,7 +551,9 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
   // bytes per dy tile image / per activation patch row (one plane).  The tile images are 32 bytes apart from a multiple of
   // the 256-byte bank period: the 8 tiles x 4 channel quads a half-wave stores for one pixel row then cover all 64 banks once
   constexpr int YIMG = H3_KP * 32 + 32, ZROW = ZWP * 32;
-  constexpr int ZTILE = 3 * ZROW;                                 // one input-channel tile of the patch (one plane)
+  // one input-channel tile of the patch (one plane); with two tiles, 64 bytes off the 256-byte bank period: the two 32-byte halves a pixel's eight
+  // channel quads store then hit different banks (SQ_LDS_BANK_CONFLICT 9.5 % of the LDS cycles without)
+  constexpr int ZTILE = 3 * ZROW + (NG > 1 ? 64 : 0);
   constexpr int YPL = YT * YIMG, ZPL = NG * ZTILE;                // bytes per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   unsigned char* Yb = wsm;                                        // [NP][YT][64 px][16 co]
@@ -814,7 +816,7 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
 }
 inline bool wgrad_split_narrow() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT_NARROW"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 inline bool wgrad_split_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
-constexpr size_t wg_h3b_lds(int nt, int np, int ng) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + ng * 3 * 104 * 32); }
+constexpr size_t wg_h3b_lds(int nt, int np, int ng) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + ng * (3 * 104 * 32 + (ng > 1 ? 64 : 0))); }
 
 // Halo-patch weight gradient of the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5: 40/80/160 channels,
 // dilation <= 2).  Same staging as wgrad_h3_kernel — per 64-pixel row segment dy [64][16*CT] and the KS activation rows
