@@ -113,6 +113,86 @@ __global__ void __launch_bounds__(256) affine_sum_bwd_kernel(const SumK p) {
   }
 }
 
+// Vector-aligned form of affine_sum_bwd_kernel with the term count a template parameter: plain 16-byte loads, TWO pixels per trip with every load of
+// both requested before anything is used (the generic kernel's 2-3 trips per thread were 2-3 dependent round trips on launches that move 15-30 MB).
+// Same per-thread pixel order and arithmetic as the generic kernel: bit-identical results.
+template <int NT>
+__global__ void __launch_bounds__(256) affine_sum_bwd_vec_kernel(const SumK p) {
+  extern __shared__ double redt[];       // [npl][C4][2]
+  const int q = threadIdx.x % p.nq, pl = threadIdx.x / p.nq;
+  const bool active = pl < p.npl;
+  const int c = 4 * q;
+  float4 av[NT], bv[NT];
+  double sA[NT][4], sB[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    av[i] = make_float4(1.f, 1.f, 1.f, 1.f); bv[i] = zero4();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sA[i][e] = 0.0; sB[i][e] = 0.0; }
+    if (active && p.term[i].a) { av[i] = ld4(p.term[i].a + c); bv[i] = ld4(p.term[i].b + c); }
+  }
+  if (active) {
+    const long stride = (long)gridDim.x * p.npl;
+    auto finish = [&](long pp, float4 d, const float4 o, const float4 (&x)[NT], const float4 (&gold)[NT]) {
+      if (p.relu_out) { if (!(o.x > 0.f)) d.x = 0.f; if (!(o.y > 0.f)) d.y = 0.f; if (!(o.z > 0.f)) d.z = 0.f; if (!(o.w > 0.f)) d.w = 0.f; }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        if (p.g[i] || p.dab[i]) {
+          float4 dm = d;
+          if (p.term[i].relu) {
+            if (!(fmaf(av[i].x, x[i].x, bv[i].x) > 0.f)) dm.x = 0.f;
+            if (!(fmaf(av[i].y, x[i].y, bv[i].y) > 0.f)) dm.y = 0.f;
+            if (!(fmaf(av[i].z, x[i].z, bv[i].z) > 0.f)) dm.z = 0.f;
+            if (!(fmaf(av[i].w, x[i].w, bv[i].w) > 0.f)) dm.w = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sA[i][e] += (double)get4(dm, e) * (double)get4(x[i], e); sB[i][e] += (double)get4(dm, e); }
+          if (p.g[i]) {
+            float4 gv = make_float4(dm.x * av[i].x, dm.y * av[i].y, dm.z * av[i].z, dm.w * av[i].w);
+            if (p.acc[i]) { gv.x += gold[i].x; gv.y += gold[i].y; gv.z += gold[i].z; gv.w += gold[i].w; }
+            st4(p.g[i] + pp * p.ldg[i] + c, gv);
+          }
+        }
+      }
+    };
+    for (long p0 = (long)blockIdx.x * p.npl + pl; p0 < p.P; p0 += 2 * stride) {
+      const long p1 = p0 + stride;
+      const bool ok1 = p1 < p.P;
+      const long q1 = ok1 ? p1 : p0;                       // (the second pixel's loads fall on the first when there is none)
+      const float4 d0 = ld4(p.dout + p0 * p.lddo + c), d1 = ld4(p.dout + q1 * p.lddo + c);
+      float4 o0 = zero4(), o1 = zero4();
+      if (p.relu_out) { o0 = ld4(p.fout + p0 * p.ldfo + c); o1 = ld4(p.fout + q1 * p.ldfo + c); }
+      float4 x0[NT], x1[NT], g0[NT], g1[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        x0[i] = zero4(); x1[i] = zero4(); g0[i] = zero4(); g1[i] = zero4();
+        if (p.g[i] || p.dab[i]) { x0[i] = ld4(p.term[i].x + p0 * p.term[i].ld + c); x1[i] = ld4(p.term[i].x + q1 * p.term[i].ld + c); }
+        if (p.g[i] && p.acc[i]) { g0[i] = ld4(p.g[i] + p0 * p.ldg[i] + c); g1[i] = ld4(p.g[i] + q1 * p.ldg[i] + c); }
+      }
+      finish(p0, d0, o0, x0, g0);
+      if (ok1) finish(p1, d1, o1, x1, g1);
+    }
+  }
+  const int C4 = p.nq * 4;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    if (p.dab[i]) {          // block-uniform
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { redt[((pl * C4) + c + e) * 2] = sA[i][e]; redt[((pl * C4) + c + e) * 2 + 1] = sB[i][e]; }
+      }
+      __syncthreads();
+      for (int k = threadIdx.x; k < p.C * 2; k += 256) {
+        const int ch = k >> 1, ab = k & 1;
+        double acc = 0.0;
+        for (int r = 0; r < p.npl; ++r) acc += redt[((r * C4) + ch) * 2 + ab];
+        p.dab[i][(long)blockIdx.x * p.C * 2 + k] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // vector-aligned form: every load is a plain 16-byte load issued up front (coefficients and data are one round trip)
 __global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* g, int ldg, const float* x, int ldx, const float* mean,
                                                                const float* c1, const float* c2, long P, float* out, int ldo,
@@ -247,7 +327,20 @@ extern "C" int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stre
   k.nterm = a->nterm; k.P = a->P; k.C = a->C; k.dout = a->dout; k.lddo = a->lddo; k.fout = a->out; k.ldfo = a->ldo; k.relu_out = a->relu_out;
   EwMap m = ew_map(a->C); k.nq = m.nq; k.npl = m.npl;
   size_t sh = (size_t)m.npl * m.nq * 4 * 2 * sizeof(double);
-  hipLaunchKernelGGL(affine_sum_bwd_kernel, dim3(ew_rows(a->P, a->C)), dim3(256), sh, (hipStream_t)stream, k);
+  static int vec2 = -1; if (vec2 < 0) { const char* e = getenv("ADDK_SUM_BWD_VEC"); vec2 = (e && e[0] == '0') ? 0 : 1; }
+  bool vec_ok = vec2 && k.vec && a->C % 4 == 0 && a->C == m.nq * 4;
+  for (int i = 0; i < a->nterm && vec_ok; ++i) if (a->term[i].a && (!aligned16(a->term[i].a) || !aligned16(a->term[i].b))) vec_ok = false;
+  const dim3 grid(ew_rows(a->P, a->C));
+  if (vec_ok) {
+    switch (a->nterm) {
+      case 1: hipLaunchKernelGGL(affine_sum_bwd_vec_kernel<1>, grid, dim3(256), sh, (hipStream_t)stream, k); break;
+      case 2: hipLaunchKernelGGL(affine_sum_bwd_vec_kernel<2>, grid, dim3(256), sh, (hipStream_t)stream, k); break;
+      case 3: hipLaunchKernelGGL(affine_sum_bwd_vec_kernel<3>, grid, dim3(256), sh, (hipStream_t)stream, k); break;
+      default: hipLaunchKernelGGL(affine_sum_bwd_vec_kernel<4>, grid, dim3(256), sh, (hipStream_t)stream, k); break;
+    }
+    return addk_check_launch("affine_sum_bwd");
+  }
+  hipLaunchKernelGGL(affine_sum_bwd_kernel, grid, dim3(256), sh, (hipStream_t)stream, k);
   return addk_check_launch("affine_sum_bwd");
 }
 

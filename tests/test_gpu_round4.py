@@ -395,3 +395,56 @@ def test_classifier_data_gradient_matches_fp64_and_the_generic_kernel(shape):
     assert torch.isfinite(g).all() and torch.isfinite(dab).all()
     assert float((g.double() - ref_g).abs().max() / ref_g.abs().max()) < 2e-6
     assert float((dab - ref_dab).abs().max() / ref_dab.abs().max()) < 2e-6
+
+
+# ---- backward of the cell block sum (ADD.py:108): the two-pixels-per-trip vector form (elementwise.hip affine_sum_bwd_vec_kernel) ----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(16002, 80, 2, False, (1, 0), (0, 0)), (63250, 40, 2, True, (1, 1), (0, 1)), (4097, 160, 3, False, (0, 1, 1), (0, 0, 1)),
+                                   (777, 40, 4, True, (1, 1, 1, 1), (1, 0, 1, 0)), (16002, 80, 1, False, (1,), (1,))],
+                         ids=['l2_two_terms', 'l1_relu_out_acc', 'l3_three_terms', 'four_terms_odd', 'one_term'])
+def test_block_sum_backward_matches_fp64(shape):
+    """g_i (+)= a_i mask_i dout, (dA_i, dB_i) = sum over pixels of (mask dout x_i, mask dout): pixel counts that leave the last trip's second pixel
+    missing, terms without a gradient output (statistics only), with accumulation, with a ReLU on the block output."""
+    import ctypes as C
+    import torch
+    from addk import _lib as L
+    P, Cc, nterm, relu_out, want_g, acc = shape
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(P + Cc + nterm)
+    dout = torch.randn(P, Cc, device=dev)
+    xs = [torch.randn(P, Cc, device=dev) for _ in range(nterm)]
+    a_ = [torch.rand(Cc, device=dev) + 0.5 for _ in range(nterm)]
+    b_ = [0.3 * torch.randn(Cc, device=dev) for _ in range(nterm)]
+    relu_t = [(i % 2) == 0 for i in range(nterm)]
+    out = sum(torch.relu(a_[i] * xs[i] + b_[i]) if relu_t[i] else a_[i] * xs[i] + b_[i] for i in range(nterm))
+    if relu_out:
+        out = torch.relu(out)
+    g0 = [torch.randn(P, Cc, device=dev) for _ in range(nterm)]
+    rows = lib.addk_ew_rows(P, Cc)
+    ba = L.AffineSumBwdArgs()
+    gs, dabs = [], []
+    for i in range(nterm):
+        ba.term[i].x, ba.term[i].a, ba.term[i].b, ba.term[i].ld, ba.term[i].C, ba.term[i].relu = xs[i].data_ptr(), a_[i].data_ptr(), b_[i].data_ptr(), Cc, Cc, int(relu_t[i])
+        g = g0[i].clone() if acc[i] else torch.full((P, Cc), float('nan'), device=dev)
+        dab = torch.full((rows, Cc, 2), float('nan'), device=dev, dtype=torch.float64)
+        gs.append(g); dabs.append(dab)
+        if want_g[i]:
+            ba.g[i], ba.ldg[i], ba.accumulate[i] = g.data_ptr(), Cc, int(acc[i])
+        ba.dab[i] = dab.data_ptr()
+    ba.nterm, ba.P, ba.C, ba.dout, ba.lddo = nterm, P, Cc, dout.data_ptr(), Cc
+    ba.out, ba.ldo, ba.relu_out = out.data_ptr(), Cc, int(relu_out)
+    L.check(lib.addk_affine_sum_bwd(C.byref(ba), torch.cuda.current_stream().cuda_stream), 'affine_sum_bwd')
+    torch.cuda.synchronize()
+    d = dout.double() * ((out > 0).double() if relu_out else 1.0)
+    for i in range(nterm):
+        m = ((a_[i] * xs[i] + b_[i]) > 0).double() if relu_t[i] else torch.ones_like(d)      # the kernel's mask is fmaf(a, x, b) > 0: same sign except within an ulp of 0
+        dm = d * m
+        ref_dab = torch.stack([(dm * xs[i].double()).sum(0), dm.sum(0)], 1)
+        got = dabs[i].sum(0)
+        assert torch.isfinite(got).all()
+        assert float((got - ref_dab).abs().max() / ref_dab.abs().max()) < 1e-6, i
+        if want_g[i]:
+            ref_g = dm * a_[i].double() + (g0[i].double() if acc[i] else 0)
+            assert torch.isfinite(gs[i]).all()
+            assert float((gs[i].double() - ref_g).abs().max() / ref_g.abs().max()) < 1e-6, i
