@@ -436,11 +436,17 @@ class Graph:
         buckets = collections.defaultdict(list)
         for i, c in enumerate(lst):
             buckets[level[i]].append(c)
+        # [r4] kinds left as single launches.  In the TRAINING step the fused SepConv halves run better one by one (33.6-33.7 vs 33.95-34.0 ms per
+        # step, ABAB on one box): a merged launch waits for its latest input and holds every consumer back, and these launches are long enough
+        # (15-70 us) for the two streams to overlap them; every other kind measured slower or equal un-merged (bn_bwd +1.3 ms, bn_bwd_apply +0.9,
+        # conv_dgrad +0.4), and inference (exit latency, forward segment) is equal or better with the halves merged.  ADDK_NO_BATCH=kind,... overrides.
+        env = os.environ.get('ADDK_NO_BATCH')
+        single = set(filter(None, env.split(','))) if env is not None else ({'sep_fwd', 'sep_bwd'} if (getattr(self, 'training', False) and getattr(self, 'want_grad', False)) else set())
         out = []
         for lv in sorted(buckets):
             groups = collections.defaultdict(list)
             for c in buckets[lv]:
-                if c.name in self._BATCHED and c.payload is not None:
+                if c.name in self._BATCHED and c.payload is not None and c.name not in single:
                     groups[(c.name, c.bkey)].append(c)
                 else:
                     out.append(c)
