@@ -814,6 +814,168 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
       }
     }
 }
+// [r4] The same arithmetic and LDS images for the wide 1x1 heads (ASPP's 1x1 branch and its 1280 -> 256 concat conv, 256 <- 256..400 channels at
+// 64x128: aspp_train.py:34-58): no halo, so the nine accumulator "taps" of wgrad_h3b_kernel become FOUR 16-channel input tiles per workgroup
+// (128 output x 64 input channels, 96 MFMA per wave and 64-pixel segment).  These weight gradients ran on the fp32 MFMA kernel (wgrad_os_kernel<4,2>:
+// 11.9 GF per exit in 200 us = 60 TFLOP/s) while their forward and data gradient already used the split-bf16 kernel.
+constexpr int H1_TP = 4;
+template <bool BATCH, int NP>
+__global__ void __launch_bounds__(256, 2) wgrad_h1b_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
+  if (BATCH) {
+    const int4 wk = work[blockIdx.x];
+    op = __builtin_amdgcn_readfirstlane(wk.x); blk_x = __builtin_amdgcn_readfirstlane(wk.y); blk_y = __builtin_amdgcn_readfirstlane(wk.z);
+  }
+  const WgK p = wg_desc<BATCH>(pv, ops, op);
+  constexpr int NT = 2, TP = H1_TP, BCO = 64 * NT, YT = BCO / 16, YQ = BCO / 4, YRS = 256 / YQ, NYJ = H3_KP / YRS;
+  constexpr int YIMG = H3_KP * 32 + 32;                              // a [64 px][16 ch] bf16 tile image, 32 bytes off the bank period (see wgrad_h3b_kernel)
+  constexpr int YPL = YT * YIMG, ZPL = TP * YIMG;
+  constexpr int NIT = NYJ + TP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  unsigned char* Yb = wsm;                                           // [NP][YT][64 px][16 co]
+  unsigned char* Zb = wsm + NP * YPL;                                // [NP][TP][64 px][16 ci]
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
+  const int co0 = yt * BCO, c0 = zt * 16 * TP;
+  const int spr = (p.OW + H3_KP - 1) / H3_KP;
+  const int nseg = p.N * p.OH * spr;
+  const int sbeg = blk_y * p.chunkP;
+  int send = sbeg + p.chunkP; if (send > nseg) send = nseg;
+  // staging geometry: thread constants + segment scalars (wgrad_h3b_kernel); the activation tile needs no row / column validity, only the channel tail
+  const int yq = t & (YQ - 1), yrow0 = t / YQ;
+  const int co = co0 + 4 * yq;
+  const unsigned yoff = ((unsigned)yrow0 * (unsigned)p.lddy + (unsigned)co) * 4u;
+  const long ystep = (long)YRS * p.lddy;
+  const int ytile = (yq >> 2) * YIMG + 8 * (yq & 3);
+  const int ysw0 = ytile + wg_prow(yrow0), ysw1 = ytile + wg_prow(yrow0 + YRS) - (YRS << 5);
+  const int zq = t & 3, zj0 = t >> 2;
+  const int zsw = wg_prow(zj0) + 8 * zq;
+  unsigned zoffk[TP]; unsigned zvalid = 0;
+  float4 za[TP], zb[TP];
+  const bool zrelu = p.src.relu != 0, zaff = p.src.a != nullptr;
+#pragma unroll
+  for (int k = 0; k < TP; ++k) {
+    const int zc = c0 + 16 * k + 4 * zq;
+    const bool ok = zc < p.src.C;                                   // whole quads: C % 4 == 0 (h1_ok)
+    zvalid |= (ok ? 1u : 0u) << k;
+    zoffk[k] = ok ? ((unsigned)zj0 * (unsigned)p.src.ld + (unsigned)zc) * 4u : 0u;
+    za[k] = make_float4(1.f, 1.f, 1.f, 1.f); zb[k] = zero4();
+    if (zaff && ok) { za[k] = ld4(p.src.a + zc); zb[k] = ld4(p.src.b + zc); }
+  }
+  const int tq = li >> 2, tp = li & 3;
+  const int lrow = 8 * kq + tq;
+  f32x4 acc[NT][TP];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ry[NYJ], rz[TP];
+  int l_sx, l_oh, l_n, c_sx, c_oh, c_n;
+  { const int rowid = sbeg / spr; l_sx = sbeg - rowid * spr; l_n = rowid / p.OH; l_oh = rowid - l_n * p.OH; c_sx = l_sx; c_oh = l_oh; c_n = l_n; }
+  const float* yseg = p.dy; const float* zseg = p.src.x;
+  int st_skip = 0;
+  auto load_prep = [&](bool next) {
+    if (next) { c_sx = l_sx; c_oh = l_oh; c_n = l_n; if (++l_sx == spr) { l_sx = 0; if (++l_oh == p.OH) { l_oh = 0; ++l_n; } } }
+    int ow0 = c_sx * H3_KP;
+    st_skip = ow0 + H3_KP - p.OW; if (st_skip < 0) st_skip = 0;      // the last segment of an image row is moved left; the pixels it shares get dy = 0
+    ow0 -= st_skip;
+    const long pix = ((long)c_n * p.OH + c_oh) * p.OW + ow0;
+    yseg = p.dy + pix * p.lddy;
+    zseg = p.src.x + pix * p.src.ld;
+  };
+  auto load_item = [&](int i) {
+    if (i < NYJ) ry[i] = ld4so(yseg + i * ystep, yoff);
+    else if (i < NIT) rz[i - NYJ] = ld4so(zseg, zoffk[i - NYJ]);
+  };
+  auto store_step = [&]() {
+    if (st_skip) {
+#pragma unroll
+      for (int k = 0; k < NYJ; ++k) if (yrow0 + k * YRS < st_skip) ry[k] = zero4();
+    }
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      uint2 pl[NP];
+      wg_split4<NP>(ry[k], pl);
+      unsigned char* o = Yb + ((k & 1) ? ysw1 : ysw0) + k * (YRS << 5);
+#pragma unroll
+      for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * YPL) = pl[m];
+    }
+#pragma unroll
+    for (int k = 0; k < TP; ++k) {
+      float4 v = rz[k];
+      if (zaff) { v.x = fmaf(za[k].x, v.x, zb[k].x); v.y = fmaf(za[k].y, v.y, zb[k].y); v.z = fmaf(za[k].z, v.z, zb[k].z); v.w = fmaf(za[k].w, v.w, zb[k].w); }
+      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const bool ok = (zvalid >> k) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      uint2 pl[NP];
+      wg_split4<NP>(v, pl);
+      unsigned char* o = Zb + k * YIMG + zsw;
+#pragma unroll
+      for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * ZPL) = pl[m];
+    }
+  };
+  auto rd = [&](const unsigned char* base, int plane_bytes, int pix0, wg_bf16x8* f) {
+    const int o0 = wg_prow(pix0 + lrow) + 8 * tp, o1 = wg_prow(pix0 + lrow + 4) + 8 * tp;
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o0));
+      const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4*)(base + m * plane_bytes + o1));
+      struct { wg_s16x4 a, b; } pr = {lo, hi};          // whole-register reinterpretation (see wgrad_h3b_kernel)
+      f[m] = __builtin_bit_cast(wg_bf16x8, pr);
+    }
+  };
+  auto mma = [&](f32x4 (&c)[NT][TP], int j, const wg_bf16x8 (&y)[NT][NP], const wg_bf16x8* z) {
+#define WG_TERM(YI, ZI) _Pragma("unroll") for (int i = 0; i < NT; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i][YI], z[ZI], c[i][j], 0, 0, 0);
+    if (NP == 3) { WG_TERM(2, 0) WG_TERM(0, 2) WG_TERM(1, 1) }
+    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0)
+#undef WG_TERM
+  };
+  if (sbeg < send) {
+    load_prep(true);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_item(i);
+    store_step();
+    __syncthreads();
+    for (int seg = sbeg; seg < send; ++seg) {
+      const bool more = seg + 1 < send;
+      load_prep(more);
+#pragma unroll
+      for (int ks = 0; ks < H3_KP / 32; ++ks) {
+        wg_bf16x8 yf[NT][NP];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rd(Yb + (wave * NT + i) * YIMG, YPL, ks * 32, yf[i]);
+        wg_bf16x8 zf[2][NP];
+        rd(Zb, ZPL, ks * 32, zf[0]);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+          load_item(2 * (ks * TP + j)); load_item(2 * (ks * TP + j) + 1);      // the next segment's loads, two per input tile (NIT <= 16)
+          if (j + 1 < TP) rd(Zb + (j + 1) * YIMG, ZPL, ks * 32, zf[(j + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(acc, j, yf, zf[j & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      if (more) { store_step(); __syncthreads(); }
+    }
+  }
+  const int C = p.src.C;
+  gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * C;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cow = co0 + (wave * NT + i) * 16 + kq * 4 + r;
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+        const int c = c0 + 16 * j + li;
+        if (cow < p.Cout && c < C) wsb[(long)cow * C + c] = acc[i][j][r];
+      }
+    }
+}
+constexpr size_t wg_h1b_lds(int np) { return (size_t)np * ((128 / 16) + H1_TP) * (H3_KP * 32 + 32); }
+
 inline bool wgrad_split_narrow() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT_NARROW"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 inline bool wgrad_split_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
 constexpr size_t wg_h3b_lds(int nt, int np, int ng) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + ng * (3 * 104 * 32 + (ng > 1 ? 64 : 0))); }
@@ -1579,6 +1741,14 @@ bool h3_ok(const addk_conv_wgrad_args* a) {
          a->OH == a->H && a->OW == a->W && a->W >= 64 && a->Cout % 64 == 0 && a->src.C >= 16 &&
          aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) && (long)a->N * a->H * a->W >= 8192;
 }
+// 9: the split-bf16 halo-patch arithmetic for the wide 1x1 heads (wgrad_h1b_kernel), when the split kernels are in use
+inline bool h3b_runs(int cty);
+bool h1_ok(const addk_conv_wgrad_args* a) {
+  static int en = -1; if (en < 0) { const char* e = getenv("ADDK_WGRAD_H1"); en = (e && e[0] == '0') ? 0 : 1; }
+  return en && (addk_get_fast_paths() & ADDK_FAST_WGRAD3) && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->OH == a->H && a->OW == a->W &&
+         a->W >= 64 && a->Cout % 128 == 0 && a->src.C >= 64 && a->src.C % 4 == 0 && aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) &&
+         (!a->src.a || (aligned16(a->src.a) && aligned16(a->src.b))) && (long)a->N * a->H * a->W >= 8192 && h3b_runs(8);
+}
 // 6: register-streaming kernel for the narrow cell convolutions
 bool rs_ok(const addk_conv_wgrad_args* a) {
   return (addk_get_fast_paths() & ADDK_FAST_WGRAD_RS) && a->Cout <= 160 && a->Cout >= 16 && a->src.C >= 16 && a->KH * a->KW <= 25 &&
@@ -1608,7 +1778,7 @@ bool st_ok(const addk_conv_wgrad_args* a) {
   return (addk_get_fast_paths() & ADDK_FAST_WGRAD_RS) && a->src.C <= 4 && a->KH * a->KW * a->src.C <= 32 && a->Cout <= 64 && a->Cout % 4 == 0 &&
          aligned16(a->dy) && a->lddy % 4 == 0 && (long)a->N * a->OH * a->OW >= 65536;
 }
-int kind_of(const addk_conv_wgrad_args* a) { return st_ok(a) ? 8 : h3_ok(a) ? 5 : hk_ok(a) ? 7 : rs_ok(a) ? 6 : os_kind(a->Cout, a->src.C); }
+int kind_of(const addk_conv_wgrad_args* a) { return st_ok(a) ? 8 : h3_ok(a) ? 5 : h1_ok(a) ? 9 : hk_ok(a) ? 7 : rs_ok(a) ? 6 : os_kind(a->Cout, a->src.C); }
 // Halo-patch scheduling.  A block runs `steps` row segments; blocks are dispatched in grid order as CU slots free up
 // (2 resident blocks per CU at NT=2, 3 at NT=1), so what matters is that the LAST round of blocks is nearly full:
 // pick the segment count per block that minimises  ceil(blocks / slots) * (steps + start-up)  over the whole launch.
@@ -1723,6 +1893,19 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
     k.chunkP = cdiv(nseg, k.splits);
     ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   }
+  if (!h3_ok(a) && h1_ok(a)) {      // wide 1x1 heads on the split-bf16 kernel: 128 output x 64 input channels per workgroup, 64-pixel row segments
+    cty = 8; ctz = 4;
+    k.nyt = a->Cout / 128; k.nzt = cdiv(a->src.C, 16 * H1_TP);
+    tiles = k.nyt * k.nzt;
+    const long nseg = (long)a->N * a->OH * cdiv(a->OW, H3_KP);
+    if (h3_steps <= 0) { H3Op o{tiles, nseg}; h3_steps = h3_pick_steps(&o, 1, 2); }
+    long cap = addk_conv_wgrad_ws(k.P, a->Cout, a->src.C, 1) / ((long)a->Cout * a->src.C);      // slices the workspace was sized for
+    if (cap < 1) cap = 1;
+    long sp = cdiv(nseg, h3_steps); if (sp > cap) sp = cap; if (sp < 1) sp = 1;
+    k.chunkP = cdiv(nseg, sp);
+    k.splits = cdiv(nseg, k.chunkP);
+    ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  }
   k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
   k.vecZ = src_vec_ok(a->src);
   if (st_ok(a)) {      // few input channels: one workgroup holds every (tap, channel) column; 1024-pixel slices, as many as the workspace bound allows
@@ -1831,6 +2014,16 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
   if (kind == 5 && cty == 4 && h3b_runs(cty)) { if (ctz == 2) { ADDK_H3B(1, 2) } else { ADDK_H3B(1, 1) } }
 #undef ADDK_H3B
 #undef ADDK_H3B_
+  if (kind == 9) {
+    if (!h3b_runs(8)) { addk_set_error("conv_wgrad: launch prepared for the split-bf16 kernel, but the precision mode / ADDK_WGRAD_SPLIT changed since"); return ADDK_ERR_INVALID; }
+#define ADDK_H1B_(B_, P_) { \
+      static bool attr = false; \
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h1b_kernel<B_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
+      hipLaunchKernelGGL((wgrad_h1b_kernel<B_, P_>), grid, dim3(256), wg_h1b_lds(P_), st, k, ops, work); done = true; }
+    if (ops) { if (wg_np == 3) ADDK_H1B_(true, 3) else ADDK_H1B_(true, 2) }
+    else { if (wg_np == 3) ADDK_H1B_(false, 3) else ADDK_H1B_(false, 2) }
+#undef ADDK_H1B_
+  }
 #define ADDK_H3(NT_) \
   if (!done && kind == 5 && cty == 4 * NT_) { \
     if (ops) hipLaunchKernelGGL((wgrad_h3_kernel<NT_, true>), grid, dim3(256), 0, st, k, ops, work); \
@@ -1892,6 +2085,12 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
     H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
     for (int i = 0; i < n; ++i) { ho[i].tiles = hk_tiles(a[i].Cout, a[i].src.C, a[i].KH); ho[i].nseg = (long)a[i].N * a[i].OH * cdiv(a[i].OW, H3_KP); }
     h3_steps = h3_pick_steps(ho, n, hk_ct(a[0].Cout, a[0].KH) == 3 ? 1 : 2);
+    free(ho);
+  }
+  if (!h3_ok(&a[0]) && h1_ok(&a[0])) {
+    H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
+    for (int i = 0; i < n; ++i) { ho[i].tiles = (a[i].Cout / 128) * cdiv(a[i].src.C, 16 * H1_TP); ho[i].nseg = (long)a[i].N * a[i].OH * cdiv(a[i].OW, H3_KP); }
+    h3_steps = h3_pick_steps(ho, n, 2);
     free(ho);
   }
   if (h3_ok(&a[0])) {
