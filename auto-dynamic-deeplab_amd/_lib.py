@@ -33,14 +33,10 @@ class ConvDgradArgs(C.Structure):
                 ('dab', vp), ('wpack', vp), ('wpack_floats', i64), ('wpack_ready', i32), ('_pad2', i32)]
 
 
-class BnFold(C.Structure):
-    _fields_ = [('y', vp), ('ldy', i32), ('_pad', i32), ('c1', vp), ('c2', vp), ('mean', vp)]
-
-
 class ConvWgradArgs(C.Structure):
     _fields_ = [('dy', vp), ('lddy', i32), ('Cout', i32), ('N', i32), ('H', i32), ('W', i32), ('OH', i32), ('OW', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('src', Src), ('dw', vp),
-                ('ldw', i32), ('cin_total', i32), ('w_choff', i32), ('accumulate', i32), ('ws', vp), ('ws_floats', i64), ('fold', BnFold)]
+                ('ldw', i32), ('cin_total', i32), ('w_choff', i32), ('accumulate', i32), ('ws', vp), ('ws_floats', i64)]
 
 
 class BnFinalizeArgs(C.Structure):
@@ -52,18 +48,12 @@ class BnFinalizeArgs(C.Structure):
 class SepArgs(C.Structure):
     _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('Cout', i32), ('ldw', i32), ('dw_w', vp), ('pw_w', vp),
                 ('y', vp), ('ldy', i32), ('ldt', i32), ('t', vp), ('stats', vp), ('stats_ld', i32), ('stats_rows', i32), ('nterm', i32), ('ea', vp), ('eb', vp),
-                ('term', Src * MAX_TERMS), ('fin', BnFinalizeArgs), ('fin_counter', vp), ('io16', i32), ('_pad', i32)]
-
-
-class SepConvArgs(C.Structure):
-    _fields_ = [('src', Src), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('ldw', i32), ('ldy', i32), ('dw1_w', vp), ('pw1_w', vp),
-                ('mid_a', vp), ('mid_b', vp), ('dw2_w', vp), ('pw2_w', vp), ('y', vp), ('ea', vp), ('eb', vp), ('nterm', i32), ('_pad', i32),
-                ('term', Src * MAX_TERMS)]
+                ('term', Src * MAX_TERMS), ('fin', BnFinalizeArgs), ('fin_counter', vp)]
 
 
 class SepBwdArgs(C.Structure):
     _fields_ = [('dy', vp), ('lddy', i32), ('N', i32), ('H', i32), ('W', i32), ('K', i32), ('src', Src), ('Cout', i32), ('ldw', i32),
-                ('dw_w', vp), ('pw_w', vp), ('g', vp), ('ldg', i32), ('accumulate', i32), ('dab', vp), ('ws', vp), ('fold', BnFold)]
+                ('dw_w', vp), ('pw_w', vp), ('g', vp), ('ldg', i32), ('accumulate', i32), ('dab', vp), ('ws', vp)]
 
 
 class CeUpsampleArgs(C.Structure):
@@ -175,8 +165,6 @@ _SIGS = {
     'addk_sep_fwd_supported': (i32, [C.POINTER(SepArgs)]),
     'addk_sep_rows': (i32, [C.POINTER(SepArgs)]),
     'addk_bn_fin_ws_bytes': (i64, [i32, i32]),
-    'addk_sepconv_fwd_supported': (i32, [C.POINTER(SepConvArgs)]),
-    'addk_sepconv_fwd': (i32, [C.POINTER(SepConvArgs), vp]),
     'addk_sep_bwd_rows': (i32, [C.POINTER(SepBwdArgs)]),
     'addk_sep_bwd': (i32, [C.POINTER(SepBwdArgs), vp]),
     'addk_sep_bwd_batch_key': (i32, [C.POINTER(SepBwdArgs)]),

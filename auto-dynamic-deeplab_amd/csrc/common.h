@@ -7,6 +7,8 @@
 
 void addk_set_error(const char* fmt, ...);
 int addk_check_launch(const char* what);
+int addk_env(const char* name, int dflt);      // util.cpp: the library's only getenv (integer switches, read once under a lock)
+int addk_env_math(int dflt);
 
 #define ADDK_REQUIRE(cond, ...)                    \
   do {                                             \

@@ -481,11 +481,7 @@ int pick_pt(long P) { return P >= 128L * 512 ? 2 : 1; }
 int g_prec = -1;
 int conv_precision() {
   if (g_prec < 0) {
-    const char* e = getenv("ADDK_MATH");
-    g_prec = ADDK_DEFAULT_PRECISION;
-    if (e && e[0] == 'f') g_prec = 0;
-    else if (e && e[0] == 'b') g_prec = strstr(e, "x3") ? 1 : 2;
-    else if (e && e[0] == 't') g_prec = 3;
+    g_prec = addk_env_math(ADDK_DEFAULT_PRECISION);
   }
   return g_prec;
 }
@@ -494,12 +490,11 @@ int g_fast = -1;
 int fast_paths() {
   if (g_fast < 0) {
     int m = ADDK_FAST_PW | ADDK_FAST_CONV3 | ADDK_FAST_WGRAD3 | ADDK_FAST_DWTILE | ADDK_FAST_WGRAD_RS;
-    const char* e;
-    if ((e = getenv("ADDK_PW")) && e[0] == '0') m &= ~ADDK_FAST_PW;
-    if ((e = getenv("ADDK_C3")) && e[0] == '0') m &= ~ADDK_FAST_CONV3;
-    if ((e = getenv("ADDK_WGRAD_H3")) && e[0] == '0') m &= ~ADDK_FAST_WGRAD3;
-    if ((e = getenv("ADDK_DWTILE")) && e[0] == '0') m &= ~ADDK_FAST_DWTILE;
-    if ((e = getenv("ADDK_WGRAD_RS")) && e[0] == '0') m &= ~ADDK_FAST_WGRAD_RS;
+    if (!addk_env("ADDK_PW", 1)) m &= ~ADDK_FAST_PW;
+    if (!addk_env("ADDK_C3", 1)) m &= ~ADDK_FAST_CONV3;
+    if (!addk_env("ADDK_WGRAD_H3", 1)) m &= ~ADDK_FAST_WGRAD3;
+    if (!addk_env("ADDK_DWTILE", 1)) m &= ~ADDK_FAST_DWTILE;
+    if (!addk_env("ADDK_WGRAD_RS", 1)) m &= ~ADDK_FAST_WGRAD_RS;
     g_fast = m;
   }
   return g_fast;
@@ -555,9 +550,8 @@ extern "C" int addk_conv_rows(int64_t P, int32_t Cout) {
   (void)Cout;
   int nt = cdiv(P, 64);           // one slab row per workgroup; every conv kernel launches exactly this many in x
   // [r3] small maps (the 63x127 and 32x64 levels: 251 / 64 rows) left most of the 256 CUs with one workgroup or none: one row per 32 pixels
-  // up to 512 rows (ADDK_CONV_ROWS_SMALL=0 restores one per 64)
-  static int small = -1; if (small < 0) { const char* e = getenv("ADDK_CONV_ROWS_SMALL"); small = (e && e[0] == '0') ? 0 : 1; }
-  if (small && nt < 512) { nt = cdiv(P, 32); if (nt > 512) nt = 512; }
+  // up to 512 rows
+  if (nt < 512) { nt = cdiv(P, 32); if (nt > 512) nt = 512; }
   return nt < 1024 ? nt : 1024;
 }
 

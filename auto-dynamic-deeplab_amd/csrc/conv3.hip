@@ -809,8 +809,7 @@ int c3b_wc(int Cn, long P) {
 }
 
 bool c3_enabled() { return (addk_get_fast_paths() & ADDK_FAST_CONV3) != 0; }
-inline bool c3b_pointwise_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_POINTWISE"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
-inline bool c3b_half_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_HALF"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
+inline bool c3b_pointwise_enabled() { return addk_env("ADDK_C3B_POINTWISE", 1) != 0; }
 // bf16 planes of a launch (3: six product terms, 2: three), or 0 = the exact fp32 MFMA kernel.  Every halo launch takes the
 // split kernel, the <= 64-channel ones (stem1, the cells' 40-channel dilated convs) on 4-wave blocks = 2 channel tiles x 2
 // pixel halves (PH = 2; the first 2-wave form staged 13-22 slots per thread, spilled and was slower than fp32: 125 vs 78 us
@@ -819,12 +818,12 @@ inline bool c3b_half_enabled() { static int v = -1; if (v < 0) { const char* e =
 // test_add_whole_net_frozen_bn_gradients that once suggested keeping the narrow launches on fp32 (4.9e-4 vs 2.5e-4 median) was
 // a sample of that spread: over four more draws at 2x512x1024 split-bf16 everywhere was CLOSER to fp64 than the fp32 kernels
 // in all four (median 0.40-0.89x the fp32 oracle's error against 0.84-1.22x; profiles/r02_split_threshold_study.txt).
-// ADDK_C3B_MINC / addk_set_split_min_channels(n) keep launches with fewer than n output channels on the fp32 kernel.
+// addk_set_split_min_channels(n) keeps launches with fewer than n output channels on the fp32 kernel.
 int g_c3b_minc = -1;
 inline int c3_planes(int Cn, int taps) {
   const int m = addk_get_conv_precision();
   (void)taps;
-  if (g_c3b_minc < 0) { const char* e = getenv("ADDK_C3B_MINC"); g_c3b_minc = e ? atoi(e) : 0; }
+  if (g_c3b_minc < 0) g_c3b_minc = 0;
   if (m == 0 || Cn < g_c3b_minc) return 0;
   if (m == 3) return Cn >= 192 ? 2 : 3;          // tail_x3: three product terms in the exit heads (ASPP, decoder: 256 / 304 / 400 channels), six elsewhere
   return m == 2 ? 3 : 2;
@@ -851,20 +850,16 @@ long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
   const int bct = c3_bct(Cn, P);
   return (long)cdiv(Cn, 16 * bct) * nchunks * taps * bct * 256;
 }
-inline int c3b_narrow_k() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_C3B_NARROW_K"); v = e ? atoi(e) : 0; } return v; }
 bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, int OH, int OW, long P, int Cn, int ktot = 0, bool fwd = false) {
   if (KH == 1 && KW == 1) {      // wide pointwise heads (ASPP 1x1, the 1280 -> 256 concat conv): the split kernel as a plain GEMM (KS = 1)
-    // [r3] and the FORWARD of the cells' glue convs with many input channels (dense-connection preprocess: K = 200..800 -> 40..160): ktot
-    // is the forward reduction length (0 for data gradients), ADDK_C3B_NARROW_K the smallest K that takes this path.  Measured and left OFF
-    // (default 0): 28.6 vs 29.4 us per launch at 40 output channels, 41.6 vs 25.7 us at 80 — the streaming-K fp32 kernel (pwk_kernel) is
-    // memory-bound on these shapes, the 6-term matrix work is not what they wait for
-    const bool wide = Cn >= 192, narrow = c3b_narrow_k() > 0 && ktot >= c3b_narrow_k() && Cn >= 32 && Cn <= 160;
-    return c3_enabled() && c3b_pointwise_enabled() && stride == 1 && dil == 1 && pad == 0 && OH == H && OW == W && (wide || narrow) && c3_planes(Cn, 1) != 0 &&
+    // (the FORWARD of the cells' many-input glue convs, K = 200..800 -> 40..160, was measured on this path in round 3 and is NOT taken: 28.6 vs 29.4 us
+    // per launch at 40 output channels, 41.6 vs 25.7 us at 80 — the streaming-K fp32 kernel (pwk_kernel) is memory-bound on those shapes)
+    (void)ktot;
+    return c3_enabled() && c3b_pointwise_enabled() && stride == 1 && dil == 1 && pad == 0 && OH == H && OW == W && Cn >= 192 && c3_planes(Cn, 1) != 0 &&
            W >= 48 && P >= 2048;
   }
   if (stride == 2) {             // [r3] stem2 (3x3, stride 2, pad 1) forward on the split kernel: 128-channel blocks of 4 waves, de-interleaved patch rows
-    static int s2 = -1; if (s2 < 0) { const char* e = getenv("ADDK_C3B_STRIDE2"); s2 = (e && e[0] == '0') ? 0 : 1; }
-    if (!(s2 && c3_enabled() && KH == 3 && KW == 3 && dil == 1 && pad == 1 && OH == (H - 1) / 2 + 1 && OW == (W - 1) / 2 + 1 && c3_planes(Cn, 9) != 0 && OW >= 96)) return false;
+    if (!(addk_env("ADDK_C3B_STRIDE2", 1) && c3_enabled() && KH == 3 && KW == 3 && dil == 1 && pad == 1 && OH == (H - 1) / 2 + 1 && OW == (W - 1) / 2 + 1 && c3_planes(Cn, 9) != 0 && OW >= 96)) return false;
     if (fwd) return Cn >= 96 && c3b_wc(Cn, (long)P) == 4 && P >= 8192;
     return Cn >= 32 && Cn <= 64 && P >= 32768;      // data gradient: the four parity classes as 2-tile blocks (c3b_s2_dgrad)
   }
@@ -888,13 +883,7 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
   C3K4 q;
   int row0 = 0;
   // share of the workgroups per class: a tile costs (staging + barriers) + taps * MFMA time, not taps alone
-  static int share[4] = {0, 0, 0, 0};
-  if (!share[3]) {
-    const char* e = getenv("ADDK_C3B_S2D_SPLIT");
-    if (!e || sscanf(e, "%d,%d,%d,%d", &share[0], &share[1], &share[2], &share[3]) != 4 || share[0] < 1 || share[1] < 1 || share[2] < 1 || share[3] < 1) {
-      share[0] = 3; share[1] = 4; share[2] = 4; share[3] = 6;      // measured at stem2's shape: 0.481 ms against 0.494 for 1:2:2:4
-    }
-  }
+  const int share[4] = {3, 4, 4, 6};      // measured at stem2's shape: 0.481 ms against 0.494 for 1:2:2:4
   const int shsum = share[0] + share[1] + share[2] + share[3];
   for (int cls = 0; cls < 4; ++cls) {
     const int pi = cls >> 1, pj = cls & 1, tc = (1 + pi) * (1 + pj), pre = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
@@ -935,16 +924,14 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const int ph = wc == 2 ? 2 : 1;                                  // <= 64 channels: 4 waves = 2 channel tiles x 2 pixel halves
   // half-width tiles where 128-pixel tiles leave the chip short of blocks (instantiated for 3- and 4-wave blocks)
   const long blocks128 = (long)k.N * k.H * cdiv(k.W, C3_BP) * cdiv(k.Cn, 32 * wc);
-  const bool half = k.st == 1 && ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && !(wc == 3 && ks == 1) && blocks128 < 384 && c3b_half_enabled();      // (rows of <= 64 pixels land here too)
-  static int s2bpx = -1; if (s2bpx < 0) { const char* e = getenv("ADDK_C3B_S2_BPX"); s2bpx = e ? atoi(e) : 64; }
+  const bool half = k.st == 1 && ph == 1 && (wc == 3 || wc == 4) && !(wc == 3 && bigd) && !(wc == 4 && ks == 5) && !(wc == 3 && ks == 1) && blocks128 < 384;      // (rows of <= 64 pixels land here too)
   // quarter-width (32-pixel) tiles where even 64-pixel tiles leave the chip short of workgroups: the cells' dilated convs on the 32x64 maps ran as
   // 128 workgroups of 3 waves — half the CUs idle, one wave per SIMD on the others, every LDS / weight round trip exposed
-  static int quarter_on = -1; if (quarter_on < 0) { const char* e = getenv("ADDK_C3B_QUARTER"); quarter_on = (e && e[0] == '0') ? 0 : 1; }
   const long blocks64 = (long)k.N * k.H * cdiv(k.W, 64) * cdiv(k.Cn, 32 * wc);
-  const bool quarter = half && quarter_on && wc == 3 && !bigd && (ks == 3 || ks == 5) && blocks64 < 192;      // measured: 160 ch @ 32x64 85 -> 63 us (5x5), 45 -> 34 (3x3); 80 ch @ 63x127 (252 blocks) is slower quartered (53 -> 66)
-  const int bpx = k.st == 2 ? (s2bpx == 128 ? 128 : 64) : quarter ? 32 : half ? 64 : C3_BP;
+  const bool quarter = half && wc == 3 && !bigd && (ks == 3 || ks == 5) && blocks64 < 192;      // measured: 160 ch @ 32x64 85 -> 63 us (5x5), 45 -> 34 (3x3); 80 ch @ 63x127 (252 blocks) is slower quartered (53 -> 66)
+  const int bpx = k.st == 2 ? 64 : quarter ? 32 : half ? 64 : C3_BP;
   // two-row tiles (2 rows, d apart, of half the one-row width) for the 3x3 / 5x5 launches at dilation <= 2: KS + 1 staged rows per two output rows
-  static int tworow_on = -1; if (tworow_on < 0) { const char* e = getenv("ADDK_C3B_TWOROW"); tworow_on = e ? atoi(e) : 2; }      // 1: dilation-1 3x3 only (decoder, stem1); 2: all
+  const int tworow_on = addk_env("ADDK_C3B_TWOROW", 2);      // 0: one-row tiles; 1: dilation-1 3x3 only (decoder, stem1); 2: all
   const bool tr_shape = k.st == 1 && (ks == 3 || ks == 5) && !bigd && k.om == 1 && (bpx == C3_BP || (bpx == 64 && wc == 3)) && k.H >= 2 * k.dil;
   const bool tworow = tr_shape && (tworow_on >= 2 || (tworow_on == 1 && ks == 3 && k.dil == 1 && (wc == 4 || wc == 2)));
   const int rpx = tworow ? bpx / 2 : bpx;                       // pixels per tile row

@@ -327,7 +327,7 @@ extern "C" int addk_affine_sum_bwd(const addk_affine_sum_bwd_args* a, void* stre
   k.nterm = a->nterm; k.P = a->P; k.C = a->C; k.dout = a->dout; k.lddo = a->lddo; k.fout = a->out; k.ldfo = a->ldo; k.relu_out = a->relu_out;
   EwMap m = ew_map(a->C); k.nq = m.nq; k.npl = m.npl;
   size_t sh = (size_t)m.npl * m.nq * 4 * 2 * sizeof(double);
-  static int vec2 = -1; if (vec2 < 0) { const char* e = getenv("ADDK_SUM_BWD_VEC"); vec2 = (e && e[0] == '0') ? 0 : 1; }
+  const int vec2 = 1;
   bool vec_ok = vec2 && k.vec && a->C % 4 == 0 && a->C == m.nq * 4;
   for (int i = 0; i < a->nterm && vec_ok; ++i) if (a->term[i].a && (!aligned16(a->term[i].a) || !aligned16(a->term[i].b))) vec_ok = false;
   const dim3 grid(ew_rows(a->P, a->C));

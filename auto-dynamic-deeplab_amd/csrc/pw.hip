@@ -508,7 +508,7 @@ static bool pw_config(PwK& k, int rows, PwCfg& c) {
   // [r4] two 16-pixel tiles per wave: a wave's fixed cost (the weight panel — 36 strided scalar loads per lane in the data gradient —, the
   // prologue coefficients, the statistics reduction) was paid for ONE tile; with two the level-batched launches (up to ~9000 workgroups
   // queueing on 256 CUs) do half of it: step 35.0 -> 34.5-34.7 ms, inference segment unchanged (ADDK_PW_TILES=1 restores one tile, 4 measured 34.65)
-  static int tpw = 0; if (!tpw) { const char* e = getenv("ADDK_PW_TILES"); tpw = e ? atoi(e) : 2; if (tpw < 1) tpw = 1; }
+  const int tpw = 2;
   if (c.gx > cdiv(k.ntiles16, 4 * tpw)) c.gx = cdiv(k.ntiles16, 4 * tpw);
   if (c.gx < 1) c.gx = 1;
   c.gy = cdiv(k.Cn, 16 * c.ct);
@@ -831,7 +831,7 @@ __global__ void __launch_bounds__(256) k1s_dgrad_kernel(const K1sK p) {
   }
 }
 static int k1s_try_dgrad(const addk_conv_dgrad_args* a, int rows, hipStream_t st) {
-  static int en = -1; if (en < 0) { const char* e = getenv("ADDK_K1S"); en = (e && e[0] == '0') ? 0 : 1; }
+  const int en = addk_env("ADDK_K1S", 1);
   if (!en || a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->H != a->OH || a->W != a->OW) return 1;
   if (a->Cout > 32 || a->dst.C < 128 || a->dst.C > 256 || a->dst.C % 4) return 1;
   if (!src_vec_ok(a->dst) || !aligned16(a->g) || a->ldg % 4 || !aligned16(a->w) || a->ldw % 4 || a->w_choff % 4) return 1;

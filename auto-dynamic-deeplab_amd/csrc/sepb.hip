@@ -27,7 +27,6 @@ struct SepbK {
   float* g; int ldg; int accumulate;
   double* dab; float* ws;
   int tiles_x, tiles_y, gx;
-  addk_bn_fold fold;             // fold.y: BatchNorm backward applied to dy on the fly (addk.h)
 };
 
 __device__ __forceinline__ float4 fma4b(float4 w, float4 v, float4 a) {
@@ -52,7 +51,7 @@ struct SepbGeo {
   static constexpr size_t LDS = (size_t)(PATCH + DWL + PWL + DWS + RED) * 4;
 };
 
-template <int KS, int KG, int KP, int R, bool FOLD>
+template <int KS, int KG, int KP, int R>
 __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   typedef SepbGeo<KS, KG, KP, R> G;
   constexpr int CT = G::CT, PW = G::PW, NPIX = G::NPIX, KQ = G::KQ, HK = KS / 2, NT = KS * KS;
@@ -69,17 +68,16 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   const int ih0 = ty * (4 * R), iw0 = tx * 16;
 
   // ---- [r4] the first stage-1 tile's dy quads are requested before anything else: they travel while the weights are staged ----
-  auto dy_geom = [&](int j, const float*& dp, const float*& yp, bool& ok) {
+  auto dy_geom = [&](int j, const float*& dp, bool& ok) {
     const int pix = 16 * j + li;
     const int pr = pix / PW, pc = pix - pr * PW;
     const int oh = ih0 - HK + pr, ow = iw0 - HK + pc;
     ok = j < G::NT16 && pix < NPIX && (unsigned)oh < (unsigned)p.H && (unsigned)ow < (unsigned)p.W;
     dp = p.dy + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.lddy : 0);
-    yp = (FOLD && p.fold.y) ? p.fold.y + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.fold.ldy : 0) : p.dy;
   };
   auto dy_load = [&](int j, float4 (&d)[KG]) {
-    const float* dp; const float* yp; bool ok;
-    dy_geom(j, dp, yp, ok);
+    const float* dp; bool ok;
+    dy_geom(j, dp, ok);
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const int k = 16 * g + 4 * kq;
@@ -118,20 +116,10 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   __syncthreads();
 
   // ---- stage 1: dt = W^T dy on the haloed patch, 16 pixels at a time ----
-  // folded BatchNorm backward: dy = G + (c1 + c2 (y - mean)), addk_bn_bwd_apply's own expression, on this lane's channel quads
-  // (a template variant: as a run-time branch the coefficient quads cost the DEFAULT path 30-80 VGPRs)
-  const bool fold = FOLD && p.fold.y != nullptr;
-  float4 f1[KG], f2[KG], fm[KG];
-#pragma unroll
-  for (int g = 0; g < KG; ++g) {
-    f1[g] = zero4(); f2[g] = zero4(); fm[g] = zero4();
-    const int k = 16 * g + 4 * kq;
-    if (fold && k < C) { f1[g] = ld4(p.fold.c1 + k); f2[g] = ld4(p.fold.c2 + k); if (p.fold.mean) fm[g] = ld4(p.fold.mean + k); }
-  }
   for (int j = wave; j < G::NT16; j += 4) {
     const int pix = 16 * j + li;
-    const float* dp; const float* yp; bool ok;
-    dy_geom(j, dp, yp, ok);
+    const float* dp; bool ok;
+    dy_geom(j, dp, ok);
     dy_load(j + 4, dnxt);                                  // the next tile of this wave: in flight under this tile's matrix work (masked beyond the patch)
     float4 d[KG];
 #pragma unroll
@@ -139,11 +127,6 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
       const int k = 16 * g + 4 * kq;
       const bool okk = ok && k < C;
       float4 v = dcur[g];
-      if (fold) {
-        const float4 y = ld4(yp + (okk ? k : 0));
-        v.x += fmaf(f2[g].x, y.x - fm[g].x, f1[g].x); v.y += fmaf(f2[g].y, y.y - fm[g].y, f1[g].y);
-        v.z += fmaf(f2[g].z, y.z - fm[g].z, f1[g].z); v.w += fmaf(f2[g].w, y.w - fm[g].w, f1[g].w);
-      }
       v.x = okk ? v.x : 0.f; v.y = okk ? v.y : 0.f; v.z = okk ? v.z : 0.f; v.w = okk ? v.w : 0.f;
       d[g] = v;
       dcur[g] = dnxt[g];
@@ -284,21 +267,21 @@ __device__ __forceinline__ void sepb_body(const SepbK& p, float* sm) {
   }
 }
 
-template <int KS, int KG, int KP, int R, bool FOLD>
+template <int KS, int KG, int KP, int R>
 __global__ void __launch_bounds__(256, 2) sepb_kernel(const SepbK p) {
   extern __shared__ __attribute__((aligned(16))) float sepb_sm[];
-  sepb_body<KS, KG, KP, R, FOLD>(p, sepb_sm);
+  sepb_body<KS, KG, KP, R>(p, sepb_sm);
 }
-template <int KS, int KG, int KP, int R, bool FOLD>
+template <int KS, int KG, int KP, int R>
 __global__ void __launch_bounds__(256, 2) sepb_batch_kernel(const SepbK* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) float sepb_sm[];
   const SepbK p = tab[blockIdx.z];
   if ((int)blockIdx.x >= p.gx) return;
-  sepb_body<KS, KG, KP, R, FOLD>(p, sepb_sm);
+  sepb_body<KS, KG, KP, R>(p, sepb_sm);
 }
 
-struct SepbCfg { int ks, kg, kp, r, fold; };
-inline int sepb_key(const SepbCfg& c) { return (c.fold << 20) | (c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r; }
+struct SepbCfg { int ks, kg, kp, r; };
+inline int sepb_key(const SepbCfg& c) { return (c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r; }
 
 bool sepb_fill(const addk_sep_bwd_args* a, SepbK& k, SepbCfg& c) {
   if (!a || !(a->K == 3 || a->K == 5) || a->N <= 0 || a->H <= 0 || a->W <= 0) return false;
@@ -314,39 +297,33 @@ bool sepb_fill(const addk_sep_bwd_args* a, SepbK& k, SepbCfg& c) {
   k.dy = a->dy; k.lddy = a->lddy; k.src = s; k.N = a->N; k.H = a->H; k.W = a->W; k.C = s.C;
   k.dww = a->dw_w; k.pww = a->pw_w; k.ldw = a->ldw; k.g = a->g; k.ldg = a->ldg; k.accumulate = a->accumulate;
   k.dab = (double*)a->dab; k.ws = a->ws;
-  if (a->fold.y) {                 // BatchNorm backward applied on the fly: 16-byte loads of y and of the coefficient vectors
-    const addk_bn_fold& f = a->fold;
-    if (!f.c1 || !f.c2 || !aligned16(f.y) || f.ldy % 4 || f.ldy < a->Cout || !aligned16(f.c1) || !aligned16(f.c2) || (f.mean && !aligned16(f.mean))) return false;
-    k.fold = f;
-  }
   const long blocks2 = (long)a->N * cdiv(a->H, 8) * cdiv(a->W, 16);
   // 80-channel tiles need 100-127 KB of LDS: one workgroup per CU.  That is fine while the launch has at most two rounds of them
   // (config 2: 256 workgroups at 64x128) and LOSES to the separate depthwise / pointwise launches beyond (F = 40, 80 channels at
   // 128x256 = 1024 workgroups: step 72.2 ms fused vs 66.5 ms unfused) — those shapes stay on the unfused kernels
   if (kg == 5 && (long)a->N * cdiv(a->H, 4) * cdiv(a->W, 16) > 512) return false;
-  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1; c.fold = a->fold.y ? 1 : 0;
-  { static int fr = -1; if (fr < 0) { const char* e = getenv("ADDK_SEP_R"); fr = e ? atoi(e) : 0; } if (fr == 1 || (fr == 2 && kg == 3)) c.r = fr; }   // tuning aid
+  c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1;
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
   return true;
 }
 
-template <int KS, int KG, int KP, int R, bool FOLD>
+template <int KS, int KG, int KP, int R>
 int sepb_go(bool batch, dim3 grid, hipStream_t st, const SepbK* one, const SepbK* tab) {
   typedef SepbGeo<KS, KG, KP, R> G;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_kernel<KS, KG, KP, R, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_batch_kernel<KS, KG, KP, R, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_kernel<KS, KG, KP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepb_batch_kernel<KS, KG, KP, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr = true;
   }
-  if (batch) hipLaunchKernelGGL((sepb_batch_kernel<KS, KG, KP, R, FOLD>), grid, dim3(256), G::LDS, st, tab);
-  else hipLaunchKernelGGL((sepb_kernel<KS, KG, KP, R, FOLD>), grid, dim3(256), G::LDS, st, *one);
+  if (batch) hipLaunchKernelGGL((sepb_batch_kernel<KS, KG, KP, R>), grid, dim3(256), G::LDS, st, tab);
+  else hipLaunchKernelGGL((sepb_kernel<KS, KG, KP, R>), grid, dim3(256), G::LDS, st, *one);
   return addk_check_launch("sep_bwd");
 }
 
 int sepb_dispatch(const SepbCfg& c, bool batch, dim3 grid, hipStream_t st, const SepbK* one, const SepbK* tab) {
 #define ADDK_SEPB(KS_, KG_, KP_, R_) if (c.ks == KS_ && c.kg == KG_ && c.kp == KP_ && c.r == R_) \
-    return c.fold ? sepb_go<KS_, KG_, KP_, R_, true>(batch, grid, st, one, tab) : sepb_go<KS_, KG_, KP_, R_, false>(batch, grid, st, one, tab);
+    return sepb_go<KS_, KG_, KP_, R_>(batch, grid, st, one, tab);
   ADDK_SEPB(3, 3, 40, 1) ADDK_SEPB(3, 3, 40, 2) ADDK_SEPB(5, 3, 40, 1) ADDK_SEPB(5, 3, 40, 2)
   ADDK_SEPB(3, 3, 56, 1) ADDK_SEPB(3, 3, 56, 2) ADDK_SEPB(5, 3, 56, 1) ADDK_SEPB(5, 3, 56, 2)
   ADDK_SEPB(3, 5, 72, 1) ADDK_SEPB(5, 5, 72, 1) ADDK_SEPB(3, 5, 88, 1) ADDK_SEPB(5, 5, 88, 1)
@@ -395,6 +372,6 @@ extern "C" int64_t addk_sep_bwd_batch_prepare(const addk_sep_bwd_args* a, int32_
 extern "C" int addk_sep_bwd_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
   ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "sep_bwd_batch_run: bad args");
   const int key = (int)meta[0];
-  SepbCfg c{(key >> 16) & 15, (key >> 12) & 15, (key >> 4) & 255, key & 15, (key >> 20) & 1};
+  SepbCfg c{(key >> 16) & 15, (key >> 12) & 15, (key >> 4) & 255, key & 15};
   return sepb_dispatch(c, true, dim3((unsigned)meta[2], 1, (unsigned)meta[1]), (hipStream_t)stream, nullptr, reinterpret_cast<const SepbK*>(dev_blob));
 }

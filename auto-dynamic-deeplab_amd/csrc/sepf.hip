@@ -39,26 +39,6 @@ __device__ __forceinline__ float4 fma4(float4 w, float4 v, float4 a) {
   return make_float4(fmaf(w.x, v.x, a.x), fmaf(w.y, v.y, a.y), fmaf(w.z, v.z, a.z), fmaf(w.w, v.w, a.w));
 }
 
-// Storage experiment: the activation tensors of the launch (input, output, depthwise output, sum terms) as
-// bf16 in HBM, fp32 arithmetic and statistics.  IO16 = false is the product path.
-template <bool IO16> __device__ __forceinline__ float4 ldx(const float* base, long off) {
-  if (!IO16) return ld4(base + off);
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 r = *(const __attribute__((address_space(1))) u32x2*)((const unsigned short*)base + off);
-  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
-}
-template <bool IO16> __device__ __forceinline__ void stx(float* base, long off, float4 v) {
-  if (!IO16) { st4(base + off, v); return; }
-  typedef float f32x2_ __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  const f32x2_ lo = {v.x, v.y}, hi = {v.z, v.w};
-  u32x2 r;
-  r.x = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2_));
-  r.y = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2_));
-  *(__attribute__((address_space(1))) u32x2*)((unsigned short*)base + off) = r;
-}
-
 template <int KS, int KG, int KP, int R>
 struct SepfGeo {
   static constexpr int CT = KG, PH = 4 * R + KS - 1, PW = 16 + KS - 1, NPIX = PH * PW, KQ = KP / 4;
@@ -86,7 +66,7 @@ __device__ unsigned long long g_sepf_span[2] = {~0ull, 0ull};
 #define SEPF_STAMP(i)
 #endif
 
-template <int KS, int KG, int KP, int R, bool IO16 = false>
+template <int KS, int KG, int KP, int R>
 __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   SEPF_STAMP(0);
   typedef SepfGeo<KS, KG, KP, R> G;
@@ -162,7 +142,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
           const int pix = pl + 64 * u, q = 4 * g + qq;
           const int oh = oh0 + (pix >> 4), ow = ow0 + (pix & 15);
           const bool ok = 4 * q < C && oh < p.H && ow < p.W;
-          tq[g][u] = ldx<IO16>(p.term[0].x, ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0);
+          tq[g][u] = ld4(p.term[0].x + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0));
         }
     }
     // (3) the input patch, group by group
@@ -175,7 +155,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
         const int pr = pix / PW, pc = pix - pr * PW;
         const int ih = ih0 + pr, iw = iw0 + pc;
         const bool ok = pix < NPIX && 4 * q < C && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        pv[g][u] = ldx<IO16>(p.src.x, ok ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + 4 * q : 0);
+        pv[g][u] = ld4(p.src.x + (ok ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld + 4 * q : 0));
         pokm[g] |= (ok ? 1u : 0u) << u;
       }
     }
@@ -230,7 +210,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
         const int pr = pix / PW, pc = pix - pr * PW;
         const int ih = ih0 + pr, iw = iw0 + pc;
         pok[u] = qact && pix < NPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        pv[u] = ldx<IO16>(p.src.x, xq + (pok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
+        pv[u] = ld4(p.src.x + xq + (pok[u] ? ((long)(n * p.H + ih) * p.W + iw) * p.src.ld : 0));
       }
     };
     patch_issue(pl);
@@ -245,7 +225,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
         const int pix = pl + u * NPL;
         const int oh = oh0 + (pix >> 4), ow = ow0 + (pix & 15);
         const bool ok = qact && pix < G::TPX && oh < p.H && ow < p.W;
-        tq[u] = ldx<IO16>(p.term[0].x, ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0);
+        tq[u] = ld4(p.term[0].x + (ok ? ((long)(n * p.H + oh) * p.W + ow) * p.term[0].ld + 4 * q : 0));
       }
     }
     __builtin_amdgcn_sched_barrier(0);             // the loads above stay above: hipcc otherwise sinks each one to its first use
@@ -353,7 +333,7 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
       }
     if (p.t && 4 * q < C) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) if (pin[r]) stx<IO16>(p.t, (long)pp[r] * p.ldt + 4 * q, acc[r]);
+      for (int r = 0; r < R; ++r) if (pin[r]) st4(p.t + (long)pp[r] * p.ldt + 4 * q, acc[r]);
     }
     float4 wf[CT];
 #pragma unroll
@@ -392,10 +372,10 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
       }
       for (int ti = 1; ti < p.nterm; ++ti) {
         const addk_src& T = p.term[ti];
-        const float4 u = prologue4(ldx<IO16>(T.x, (long)pp[r] * T.ld + c), T.a, T.b, c, 4, T.relu != 0, true);
+        const float4 u = prologue4(ld4(T.x + (long)pp[r] * T.ld + c), T.a, T.b, c, 4, T.relu != 0, true);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
-      if (!IO16 && p.wt) st4_wt(p.y + (long)pp[r] * p.ldy + c, v); else stx<IO16>(p.y, (long)pp[r] * p.ldy + c, v);
+      if (p.wt) st4_wt(p.y + (long)pp[r] * p.ldy + c, v); else st4(p.y + (long)pp[r] * p.ldy + c, v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float f = get4(v, e); s1[i][e] += f; s2[i][e] = fmaf(f, f, s2[i][e]); }
     }
@@ -439,10 +419,10 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
   }
 }
 
-template <int KS, int KG, int KP, int R, bool IO16 = false>
+template <int KS, int KG, int KP, int R>
 __global__ void __launch_bounds__(256, 2) sepf_kernel(const SepfK p) {
   extern __shared__ __attribute__((aligned(16))) float sepf_sm[];
-  sepf_body<KS, KG, KP, R, IO16>(p, sepf_sm);
+  sepf_body<KS, KG, KP, R>(p, sepf_sm);
 }
 template <int KS, int KG, int KP, int R>
 __global__ void __launch_bounds__(256, 2) sepf_batch_kernel(const SepfK* __restrict__ tab) {
@@ -452,8 +432,8 @@ __global__ void __launch_bounds__(256, 2) sepf_batch_kernel(const SepfK* __restr
   sepf_body<KS, KG, KP, R>(p, sepf_sm);
 }
 
-struct SepfCfg { int ks, kg, kp, r, io16; };
-inline int sepf_key(const SepfCfg& c) { return c.io16 ? -1 : ((c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r); }
+struct SepfCfg { int ks, kg, kp, r; };
+inline int sepf_key(const SepfCfg& c) { return (c.ks << 16) | (c.kg << 12) | (c.kp << 4) | c.r; }
 
 bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   if (!a || !(a->K == 3 || a->K == 5) || a->N <= 0 || a->H <= 0 || a->W <= 0) return false;
@@ -482,10 +462,8 @@ bool sepf_fill(const addk_sep_args* a, SepfK& k, SepfCfg& c) {
   // 128x256 = 1024 workgroups: step 72.2 ms fused vs 66.5 ms unfused) — those shapes stay on the unfused kernels
   if (kg == 5 && (long)a->N * cdiv(a->H, 4) * cdiv(a->W, 16) > 512) return false;
   c.ks = a->K; c.kg = kg; c.kp = kp; c.r = (kg == 3 && blocks2 >= 384) ? 2 : 1;
-  { static int fr = -1; if (fr < 0) { const char* e = getenv("ADDK_SEP_R"); fr = e ? atoi(e) : 0; } if (fr == 1 || (fr == 2 && kg == 3)) c.r = fr; }   // tuning aid
-  c.io16 = a->io16 ? 1 : 0;
   k.tiles_x = cdiv(a->W, 16); k.tiles_y = cdiv(a->H, 4 * c.r); k.gx = a->N * k.tiles_y * k.tiles_x;
-  { static int wt = -1; if (wt < 0) { const char* e = getenv("ADDK_SEPF_WT"); wt = (e && e[0] == '0') ? 0 : 1; } k.wt = wt; }
+  k.wt = addk_env("ADDK_SEPF_WT", 1);
   k.rows = a->stats_rows;
   if (k.slab && k.gx > k.rows) return false;             // the caller sizes the slab with addk_sep_rows
   if (a->fin.a) {
@@ -511,25 +489,7 @@ int sepf_go(bool batch, dim3 grid, hipStream_t st, const SepfK* one, const SepfK
   return addk_check_launch("sep_fwd");
 }
 
-template <int KS, int KG, int KP, int R>
-int sepf_go16(dim3 grid, hipStream_t st, const SepfK* one) {
-  typedef SepfGeo<KS, KG, KP, R> G;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepf_kernel<KS, KG, KP, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS); attr = true; }
-  hipLaunchKernelGGL((sepf_kernel<KS, KG, KP, R, true>), grid, dim3(256), G::LDS, st, *one);
-  return addk_check_launch("sep_fwd(bf16 storage)");
-}
-
 int sepf_dispatch(const SepfCfg& c, bool batch, dim3 grid, hipStream_t st, const SepfK* one, const SepfK* tab) {
-  if (c.io16) {          // storage experiment: the four cell shapes of config 2, single launches only
-    if (batch) { addk_set_error("sep_fwd: the bf16-storage experiment has no batched form"); return ADDK_ERR_UNSUPPORTED; }
-    if (c.ks == 3 && c.kg == 3 && c.kp == 40 && c.r == 2) return sepf_go16<3, 3, 40, 2>(grid, st, one);
-    if (c.ks == 5 && c.kg == 3 && c.kp == 40 && c.r == 2) return sepf_go16<5, 3, 40, 2>(grid, st, one);
-    if (c.ks == 3 && c.kg == 5 && c.kp == 88 && c.r == 1) return sepf_go16<3, 5, 88, 1>(grid, st, one);
-    if (c.ks == 5 && c.kg == 5 && c.kp == 88 && c.r == 1) return sepf_go16<5, 5, 88, 1>(grid, st, one);
-    addk_set_error("sep_fwd: the bf16-storage experiment covers C = 40 / 80 at config-2 map sizes only");
-    return ADDK_ERR_UNSUPPORTED;
-  }
 #define ADDK_SEPF(KS_, KG_, KP_, R_) if (c.ks == KS_ && c.kg == KG_ && c.kp == KP_ && c.r == R_) return sepf_go<KS_, KG_, KP_, R_>(batch, grid, st, one, tab);
   ADDK_SEPF(3, 3, 40, 1) ADDK_SEPF(3, 3, 40, 2) ADDK_SEPF(5, 3, 40, 1) ADDK_SEPF(5, 3, 40, 2)
   ADDK_SEPF(3, 3, 56, 1) ADDK_SEPF(3, 3, 56, 2) ADDK_SEPF(5, 3, 56, 1) ADDK_SEPF(5, 3, 56, 2)
@@ -598,6 +558,6 @@ extern "C" int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n,
 extern "C" int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream) {
   ADDK_REQUIRE(dev_blob && meta && meta[1] > 0 && meta[2] > 0, "sep_batch_run: bad args");
   const int key = (int)meta[0];
-  SepfCfg c{key >> 16, (key >> 12) & 15, (key >> 4) & 255, key & 15, 0};
+  SepfCfg c{key >> 16, (key >> 12) & 15, (key >> 4) & 255, key & 15};
   return sepf_dispatch(c, true, dim3((unsigned)meta[2], 1, (unsigned)meta[1]), (hipStream_t)stream, nullptr, reinterpret_cast<const SepfK*>(dev_blob));
 }

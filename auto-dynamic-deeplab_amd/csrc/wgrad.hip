@@ -21,7 +21,6 @@ struct WgK {
   int vecY, vecZ;
   // reduction target (used by the batched reduce)
   float* dw; int ldw, cin_total, w_choff, accumulate;
-  addk_bn_fold fold;       // fold.y: dy = G + (c1 + c2 (y - mean)) on the fly (register-streaming kernel only)
 };
 
 // Descriptor of this block's convolution, BY VALUE (scalar registers, loaded once): either the kernel argument or the
@@ -31,7 +30,6 @@ __device__ __forceinline__ WgK wg_desc(const WgK& pv, const WgK* __restrict__ op
   if (!BATCH) return pv;
   WgK k = ops[op];
   k.dy = gptr(k.dy); k.src.x = gptr(k.src.x); k.src.a = gptr(k.src.a); k.src.b = gptr(k.src.b); k.ws = gptr(k.ws); k.dw = gptr(k.dw);
-  k.fold.y = gptr(k.fold.y); k.fold.c1 = gptr(k.fold.c1); k.fold.c2 = gptr(k.fold.c2); k.fold.mean = gptr(k.fold.mean);
   return k;
 }
 
@@ -505,12 +503,6 @@ __device__ __forceinline__ unsigned wg_cvt2(float a, float b) {
 template <int NP>
 __device__ __forceinline__ void wg_split4(const float4 v, uint2 (&pl)[NP]) {
   float a = v.x, b = v.y, c = v.z, d = v.w;
-#ifdef ADDK_WG_FAKE_SPLIT      // upper-bound experiment (scripts/wgrad_split_bound.sh): WRONG numbers — the planes m, l are copies of h, i.e. the split costs one conversion
-  { const unsigned p0 = wg_cvt2(a, b), p1 = wg_cvt2(c, d);
-#pragma unroll
-    for (int k = 0; k < NP; ++k) pl[k] = make_uint2(p0, p1);
-    return; }
-#endif
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const unsigned p0 = wg_cvt2(a, b), p1 = wg_cvt2(c, d);
@@ -976,8 +968,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_h1b_kernel(const WgK pv, const W
 }
 constexpr size_t wg_h1b_lds(int np) { return (size_t)np * ((128 / 16) + H1_TP) * (H3_KP * 32 + 32); }
 
-inline bool wgrad_split_narrow() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT_NARROW"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
-inline bool wgrad_split_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ADDK_WGRAD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; } return v != 0; }
+inline bool wgrad_split_narrow() { return addk_env("ADDK_WGRAD_SPLIT_NARROW", 1) != 0; }
+inline bool wgrad_split_enabled() { return addk_env("ADDK_WGRAD_SPLIT", 1) != 0; }
 constexpr size_t wg_h3b_lds(int nt, int np, int ng) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + ng * (3 * 104 * 32 + (ng > 1 ? 64 : 0))); }
 
 // Halo-patch weight gradient of the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5: 40/80/160 channels,
@@ -1343,7 +1335,7 @@ __device__ __forceinline__ RsFrag<LAY> rs_load(const float* base, int li, bool o
 // channel (relative to the tile origin) held by component e, row/column index R of the MFMA tile
 template <int LAY> __device__ __forceinline__ int rs_chan(int e, int R) { return LAY == 4 ? 4 * R + e : (e < 2 ? 2 * R + e : 32 + R); }
 
-template <int LA, int LB, bool BATCH, bool FOLD>
+template <int LA, int LB, bool BATCH>
 __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
   int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
   if (BATCH) {
@@ -1377,25 +1369,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
   const float* ybase = p.dy + co0;
   const float* zbase = p.src.x + c0;
   const bool same = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;      // 1x1: the activation pixel is the dy pixel
-  // folded BatchNorm backward on the dy operand: dy = G + (c1 + c2 (y - mean)), addk_bn_bwd_apply's own expression
-  // (a template variant: as a run-time branch it cost the default path 12-16 VGPRs; a batch takes it when any of its convs folds)
-  const bool fold = FOLD && p.fold.y != nullptr;
-  const float* fbase = fold ? p.fold.y + co0 : p.dy;
-  RsFrag<LA> f1, f2, fm;
-#pragma unroll
-  for (int e = 0; e < LA; ++e) { f1.v[e] = 0.f; f2.v[e] = 0.f; fm.v[e] = 0.f; }
-  if (fold) {
-    f1 = rs_load<LA>(p.fold.c1 + co0, li, y4, y2, y1); f2 = rs_load<LA>(p.fold.c2 + co0, li, y4, y2, y1);
-    if (p.fold.mean) fm = rs_load<LA>(p.fold.mean + co0, li, y4, y2, y1);
-  }
-
   f32x4 acc[LA][LB];
 #pragma unroll
   for (int e = 0; e < LA; ++e)
 #pragma unroll
     for (int f = 0; f < LB; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (!FOLD) {
+  {
     // [r4] The loop used to spend 6-11 vector instructions per MFMA (r03 counters: 6892 VALU / 1148 MFMA per wave, 66-70 % issue stall; 52 of
     // the 84 VALU of the compute block were v_cndmask, the load blocks re-derived (n, oh, ow) by integer division for every k-step): with
     // 24 issue cycles free per 32-cycle fp32 MFMA the kernel was bound by VALU issue, not by HBM.  Now
@@ -1466,52 +1446,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
           for (int f = 0; f < LB; ++f)
             acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy4[u].v[e], v.v[f], acc[e][f], 0, 0, 0);
       }
-    }
-  } else
-  for (int s0 = s_beg; s0 < s_end; s0 += RS_U) {
-    RsFrag<LA> dy4[RS_U]; RsFrag<LB> z4v[RS_U];
-    bool zv[RS_U];
-#pragma unroll
-    for (int u = 0; u < RS_U; ++u) {
-      const int pp = pbeg + 4 * (s0 + u) + kq;
-      const bool pv_ = (s0 + u) < s_end && pp < pend;
-      dy4[u] = rs_load<LA>(ybase + (pv_ ? (long)pp * p.lddy : 0), li, pv_ && y4, pv_ && y2, pv_ && y1);
-      if (fold) {
-        const RsFrag<LA> yv = rs_load<LA>(fbase + (pv_ ? (long)pp * p.fold.ldy : 0), li, pv_ && y4, pv_ && y2, pv_ && y1);
-#pragma unroll
-        for (int e = 0; e < LA; ++e) {
-          const bool oke = pv_ && (LA == 4 ? y4 : (e < 2 ? y2 : y1));
-          const float v = dy4[u].v[e] + fmaf(f2.v[e], yv.v[e] - fm.v[e], f1.v[e]);
-          dy4[u].v[e] = oke ? v : 0.f;
-        }
-      }
-      long zoff = 0; bool okz = pv_;
-      if (same) zoff = (long)pp * p.src.ld;
-      else if (okz) {
-        const int n = pp / ohw, rem = pp - n * ohw, oh = rem / p.OW, ow = rem - oh * p.OW;
-        const int ih = oh * p.stride - p.pad + kh * p.dil, iw = ow * p.stride - p.pad + kw * p.dil;
-        okz = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        zoff = ((long)(n * p.H + ih) * p.W + iw) * p.src.ld;
-      }
-      z4v[u] = rs_load<LB>(zbase + (okz ? zoff : 0), li, okz && z4, okz && z2, okz && z1);
-      zv[u] = okz;
-    }
-#pragma unroll
-    for (int u = 0; u < RS_U; ++u) {
-      RsFrag<LB> v = z4v[u];
-      const bool ok = zv[u];
-#pragma unroll
-      for (int f = 0; f < LB; ++f) {
-        float x = fmaf(za.v[f], v.v[f], zb.v[f]);
-        if (zrelu) x = fmaxf(x, 0.f);
-        const bool okf = ok && (LB == 4 ? z4 : (f < 2 ? z2 : z1));
-        v.v[f] = okf ? x : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < LA; ++e)
-#pragma unroll
-        for (int f = 0; f < LB; ++f)
-          acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy4[u].v[e], v.v[f], acc[e][f], 0, 0, 0);
     }
   }
   // combine the four waves in a fixed order; acc[e][f][r] = dW[co0 + chanA(e, 4*kq + r)][c0 + chanB(f, li)]
@@ -1744,8 +1678,7 @@ bool h3_ok(const addk_conv_wgrad_args* a) {
 // 9: the split-bf16 halo-patch arithmetic for the wide 1x1 heads (wgrad_h1b_kernel), when the split kernels are in use
 inline bool h3b_runs(int cty);
 bool h1_ok(const addk_conv_wgrad_args* a) {
-  static int en = -1; if (en < 0) { const char* e = getenv("ADDK_WGRAD_H1"); en = (e && e[0] == '0') ? 0 : 1; }
-  return en && (addk_get_fast_paths() & ADDK_FAST_WGRAD3) && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->OH == a->H && a->OW == a->W &&
+  return (addk_get_fast_paths() & ADDK_FAST_WGRAD3) && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && a->OH == a->H && a->OW == a->W &&
          a->W >= 64 && a->Cout % 128 == 0 && a->src.C >= 64 && a->src.C % 4 == 0 && aligned16(a->dy) && a->lddy % 4 == 0 && src_vec_ok(a->src) &&
          (!a->src.a || (aligned16(a->src.a) && aligned16(a->src.b))) && (long)a->N * a->H * a->W >= 8192 && h3b_runs(8);
 }
@@ -1790,8 +1723,7 @@ inline bool h3b_runs(int cty) { return wg_np_of(cty) && wgrad_split_enabled() &&
 // input-channel tiles per workgroup of the 3x3 halo-patch kernel: 2 (512 threads sharing one staged dy tile) on the split-bf16 kernel when the channels fill
 // whole pairs of tiles (a half-empty pair costs what the shared dy saves: 304 and 400 channels measured equal, 256 -7 %, stem1's 64 -> 64 -14 %)
 inline int h3_ng(int Cout, int C) {
-  static int dis = -1; if (dis < 0) { const char* e = getenv("ADDK_WGRAD_NG"); dis = (e && e[0] == '1') ? 1 : 0; }
-  return (!dis && C % 32 == 0 && h3b_runs(Cout % 128 == 0 ? 8 : 4)) ? 2 : 1;
+  return (C % 32 == 0 && h3b_runs(Cout % 128 == 0 ? 8 : 4)) ? 2 : 1;
 }
 inline int h3_tiles(int Cout, int C) { const int nt = Cout % 128 == 0 ? 2 : 1; return (Cout / (64 * nt)) * cdiv(C, 16); }
 // at most 32 workspace slices, or as many as it takes for the op alone to offer one block per slot (few-tile convs: stem1)
@@ -1880,9 +1812,10 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   k.P = a->N * a->OH * a->OW;
   tiles = k.nyt * k.taps * k.nzt;
   k.splits = pick_splits(k.P, tiles, budget, min_steps);
-  ADDK_REQUIRE(!check_ws || h3_ok(a) || hk_ok(a) || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
+  ADDK_REQUIRE(!check_ws || kind_of(a) == 5 || kind_of(a) == 7 || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   k.chunkP = cdiv(cdiv(k.P, k.splits), KP) * KP;
-  if (h3_ok(a)) {      // halo-patch kernel: pixel range in 64-pixel row segments, never more slices than the workspace bound
+  const int kd = kind_of(a);      // ONE decision for geometry and launch: a shape several kernels accept (1x1, Cout = 128: h1 and rs) must not get the geometry of one and the launch of another
+  if (kd == 5) {      // halo-patch kernel: pixel range in 64-pixel row segments, never more slices than the workspace bound
     const int nt = a->Cout % 128 == 0 ? 2 : 1, ng = h3_ng(a->Cout, a->src.C);
     cty = 4 * nt; ctz = ng;
     k.nyt = a->Cout / (64 * nt); k.nzt = cdiv(a->src.C, 16 * ng);
@@ -1893,7 +1826,7 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
     k.chunkP = cdiv(nseg, k.splits);
     ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   }
-  if (!h3_ok(a) && h1_ok(a)) {      // wide 1x1 heads on the split-bf16 kernel: 128 output x 64 input channels per workgroup, 64-pixel row segments
+  if (kd == 9) {      // wide 1x1 heads on the split-bf16 kernel: 128 output x 64 input channels per workgroup, 64-pixel row segments
     cty = 8; ctz = 4;
     k.nyt = a->Cout / 128; k.nzt = cdiv(a->src.C, 16 * H1_TP);
     tiles = k.nyt * k.nzt;
@@ -1908,7 +1841,7 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
   }
   k.vecY = aligned16(a->dy) && a->lddy % 4 == 0 && a->Cout % 4 == 0;
   k.vecZ = src_vec_ok(a->src);
-  if (st_ok(a)) {      // few input channels: one workgroup holds every (tap, channel) column; 1024-pixel slices, as many as the workspace bound allows
+  if (kd == 8) {      // few input channels: one workgroup holds every (tap, channel) column; 1024-pixel slices, as many as the workspace bound allows
     cty = 4; ctz = 2;
     k.nyt = 1; k.nzt = 1; tiles = 1;
     int sp = cdiv(k.P, 1024);
@@ -1917,7 +1850,7 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
     k.splits = cdiv(k.P, k.chunkP);
     ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   } else
-  if (!h3_ok(a) && hk_ok(a)) {      // halo-patch kernel, taps split across waves: 64-pixel row segments like wgrad_h3
+  if (kd == 7) {      // halo-patch kernel, taps split across waves: 64-pixel row segments like wgrad_h3
     const int ct = hk_ct(a->Cout, a->KH);
     cty = ct; ctz = a->KH;
     k.nyt = cdiv(a->Cout, 16 * ct); k.nzt = cdiv(a->src.C, 16);
@@ -1928,13 +1861,13 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
     k.chunkP = cdiv(nseg, k.splits);
     ADDK_REQUIRE(!check_ws || a->ws_floats >= (int64_t)k.splits * a->Cout * k.taps * a->src.C, "conv_wgrad: workspace too small");
   } else
-  if (!h3_ok(a) && rs_ok(a)) {      // register-streaming kernel: <= 64-channel tiles, 2048-pixel chunks (128 k-steps per wave), vecY/vecZ carry the tile strides
+  if (kd == 6) {      // register-streaming kernel: <= 64-channel tiles, 2048-pixel chunks (128 k-steps per wave), vecY/vecZ carry the tile strides
     const int cap = pick_splits(k.P, tiles);
     k.vecY = rs_tile(a->Cout); k.vecZ = rs_tile(a->src.C);
     cty = rs_lay(k.vecY); ctz = rs_lay(k.vecZ);
     k.nyt = cdiv(a->Cout, k.vecY); k.nzt = cdiv(a->src.C, k.vecZ);
     tiles = k.nyt * k.taps * k.nzt;
-    static int rs_chunk = 0; if (!rs_chunk) { const char* e = getenv("ADDK_RS_CHUNK"); rs_chunk = e ? atoi(e) : 2048; if (rs_chunk < 256) rs_chunk = 2048; }      // tuning aid
+    const int rs_chunk = 2048;
     int sp = cdiv(k.P, rs_chunk);
     if (sp > cap) sp = cap;
     if (sp < 1) sp = 1;
@@ -1942,20 +1875,10 @@ static int wg_fill(const addk_conv_wgrad_args* a, WgK& k, int& cty, int& ctz, in
     k.splits = cdiv(k.P, k.chunkP);
   }
   k.dw = a->dw; k.ldw = a->ldw; k.cin_total = a->cin_total; k.w_choff = a->w_choff; k.accumulate = a->accumulate;
-  k.fold = addk_bn_fold{nullptr, 0, 0, nullptr, nullptr, nullptr};
-  if (a->fold.y) {
-    const bool rs = !h3_ok(a) && !hk_ok(a) && rs_ok(a);
-    ADDK_REQUIRE(rs, "conv_wgrad: a folded BatchNorm backward needs the register-streaming kernel (kind 6) for this shape");
-    ADDK_REQUIRE(a->fold.c1 && a->fold.c2 && a->fold.ldy >= a->Cout && a->fold.ldy % 4 == 0 && aligned16(a->fold.y) && aligned16(a->fold.c1) &&
-                 aligned16(a->fold.c2) && (!a->fold.mean || aligned16(a->fold.mean)), "conv_wgrad: bad fold operands");
-    k.fold = a->fold;
-  }
   return 0;
 }
 
 static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, const WgK& k, const WgK* ops, const int4* work) {
-  const bool fold = (kind >> 8) & 1;         // bit 8: some conv of the launch carries a folded BatchNorm backward (kind 6 only)
-  kind &= 255;
   bool done = false;
 #define ADDK_OS(K_, TY_, TZ_) \
   if (kind == K_) { \
@@ -1990,10 +1913,8 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
   }
 #define ADDK_RS(A_, B_) \
   if (kind == 6 && cty == A_ && ctz == B_) { \
-    if (ops) { if (fold) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true, true>), grid, dim3(256), 0, st, k, ops, work); \
-               else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true, false>), grid, dim3(256), 0, st, k, ops, work); } \
-    else { if (fold) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false, true>), grid, dim3(256), 0, st, k, ops, work); \
-           else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false, false>), grid, dim3(256), 0, st, k, ops, work); } \
+    if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true>), grid, dim3(256), 0, st, k, ops, work); \
+    else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false>), grid, dim3(256), 0, st, k, ops, work); \
     done = true; }
   ADDK_RS(3, 3) ADDK_RS(3, 4) ADDK_RS(4, 3) ADDK_RS(4, 4)
 #undef ADDK_RS
@@ -2003,9 +1924,7 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
   if (kind == 5 && ctz == 2 && !h3b_runs(cty)) { addk_set_error("conv_wgrad: launch prepared for the split-bf16 kernel, but the precision mode / ADDK_WGRAD_SPLIT changed since"); return ADDK_ERR_INVALID; }
 #define ADDK_H3B_(N_, B_, P_, G_) { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; \
-      if (getenv("ADDK_WG_OCC")) { int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_, G_>), 256 * G_, wg_h3b_lds(N_, P_, G_)); \
-        fprintf(stderr, "addk: wgrad_h3b<%d,%d,%d,%d> lds %zu B, grid %u x %u: %d workgroups per CU\n", N_, (int)B_, P_, G_, wg_h3b_lds(N_, P_, G_), grid.x, grid.y, nb); } } \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h3b_kernel<N_, B_, P_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
     hipLaunchKernelGGL((wgrad_h3b_kernel<N_, B_, P_, G_>), grid, dim3(256 * G_), wg_h3b_lds(N_, P_, G_), st, k, ops, work); done = true; }
 #define ADDK_H3B(N_, G_) \
     if (ops) { if (wg_np == 3) ADDK_H3B_(N_, true, 3, G_) else ADDK_H3B_(N_, true, 2, G_) } \
@@ -2051,7 +1970,7 @@ extern "C" int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream) {
   int rc = wg_fill(a, k, cty, ctz, tiles, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = wg_launch(kind_of(a) | (k.fold.y ? 256 : 0), cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
+  rc = wg_launch(kind_of(a), cty, ctz, dim3(tiles, k.splits), st, k, nullptr, nullptr);
   if (rc) return rc;
   long n = (long)a->Cout * k.taps * a->src.C;
   if (k.splits > 16 && n <= 65536) {
@@ -2077,23 +1996,24 @@ extern "C" int addk_conv_wgrad_config(const addk_conv_wgrad_args* a, int32_t* cf
 extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta) {
   if (!a || n <= 0 || !meta) { addk_set_error("wgrad_batch_prepare: bad args"); return ADDK_ERR_INVALID; }
   long nblocks = 0, nrblocks = 0;
-  int kind0 = -1, cty0 = 0, ctz0 = 0, anyfold = 0;
+  int kind0 = -1, cty0 = 0, ctz0 = 0;
   int budget = 8192 / n; if (budget < 32) budget = 32; if (budget > 1536) budget = 1536;
   const int min_steps = n >= 4 ? 8 : 1;
   int h3_steps = 0;
-  if (!h3_ok(&a[0]) && hk_ok(&a[0])) {
+  const int kd0 = kind_of(&a[0]);
+  if (kd0 == 7) {
     H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
     for (int i = 0; i < n; ++i) { ho[i].tiles = hk_tiles(a[i].Cout, a[i].src.C, a[i].KH); ho[i].nseg = (long)a[i].N * a[i].OH * cdiv(a[i].OW, H3_KP); }
     h3_steps = h3_pick_steps(ho, n, hk_ct(a[0].Cout, a[0].KH) == 3 ? 1 : 2);
     free(ho);
   }
-  if (!h3_ok(&a[0]) && h1_ok(&a[0])) {
+  if (kd0 == 9) {
     H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
     for (int i = 0; i < n; ++i) { ho[i].tiles = (a[i].Cout / 128) * cdiv(a[i].src.C, 16 * H1_TP); ho[i].nseg = (long)a[i].N * a[i].OH * cdiv(a[i].OW, H3_KP); }
     h3_steps = h3_pick_steps(ho, n, 2);
     free(ho);
   }
-  if (h3_ok(&a[0])) {
+  if (kd0 == 5) {
     H3Op* ho = (H3Op*)malloc(sizeof(H3Op) * n);
     const int nt = a[0].Cout % 128 == 0 ? 2 : 1, ng = h3_ng(a[0].Cout, a[0].src.C);
     for (int i = 0; i < n; ++i) {
@@ -2109,7 +2029,6 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
     int rc = wg_fill(&a[i], k, cty, ctz, tiles, host_blob != nullptr, budget, min_steps, h3_steps);
     if (rc) return rc;
     int kind = kind_of(&a[i]);
-    if (k.fold.y) anyfold = 256;
     if (i == 0) { kind0 = kind; cty0 = cty; ctz0 = ctz; }
     if (kind != kind0 || cty != cty0 || ctz != ctz0) { addk_set_error("wgrad_batch_prepare: mixed tile configurations"); return ADDK_ERR_INVALID; }
     nblocks += (long)tiles * k.splits;
@@ -2119,7 +2038,7 @@ extern "C" int64_t addk_conv_wgrad_batch_prepare(const addk_conv_wgrad_args* a, 
   const int64_t off_work = ((int64_t)n * sizeof(WgK) + 15) / 16 * 16;
   const int64_t off_rwork = off_work + nblocks * (int64_t)sizeof(int4);
   const int64_t total = off_rwork + nrblocks * (int64_t)sizeof(int4);
-  meta[0] = kind0 | anyfold; meta[1] = cty0; meta[2] = ctz0; meta[3] = n; meta[4] = off_work; meta[5] = nblocks; meta[6] = off_rwork; meta[7] = nrblocks;
+  meta[0] = kind0; meta[1] = cty0; meta[2] = ctz0; meta[3] = n; meta[4] = off_work; meta[5] = nblocks; meta[6] = off_rwork; meta[7] = nrblocks;
   if (!host_blob) return total;
   if (blob_bytes < total) { addk_set_error("wgrad_batch_prepare: blob too small"); return ADDK_ERR_INVALID; }
   WgK* ops = reinterpret_cast<WgK*>(host_blob);

@@ -67,9 +67,6 @@ class SepConv(AddkModule):
     def emit(self, g, x, sum_terms=None, out=None):
         """Each half is one fused launch (plan.Graph.sep_half).  `sum_terms` / `out` (inference): this op closes a cell block —
         its second half adds the other branches and writes the block sum (ADD.py:108) itself."""
-        whole = g.sepconv_whole(x, self.op[1], self.op[2], self.op[3], self.op[5], self.op[6], self.op[7], sum_terms=sum_terms, out=out)
-        if whole is not None:                   # inference: both halves in ONE launch (csrc/sepw.hip), the intermediate tensor never exists
-            return whole
         y = g.sep_half(x, self.op[1], self.op[2], self.op[3])
         return g.sep_half(y, self.op[5], self.op[6], self.op[7], sum_terms=sum_terms, out=out)
 

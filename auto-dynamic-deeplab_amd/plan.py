@@ -138,12 +138,13 @@ class Resample:
 class Cmd:
     """One kernel launch of a plan: fn(*args, stream).  `rd`/`wr` are the memory regions it reads / writes
     (keys from `_region`), used to schedule independent launches on parallel HIP streams."""
-    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag', 'payload', 'bkey', 'arena', 'members')
+    __slots__ = ('name', 'fn', 'args', 'rd', 'wr', 'stream', 'waits', 'event', 'pin', 'tag', 'tags', 'payload', 'bkey', 'arena', 'members')
 
     def __init__(self, name, fn, args, rd=(), wr=(), pin=False):
         self.name, self.fn, self.args = name, fn, list(args)
         self.rd, self.wr = [k for k in (_region(x) for x in rd) if k], [k for k in (_region(x) for x in wr) if k]
         self.stream, self.waits, self.event, self.pin, self.tag = 0, (), None, pin, ''
+        self.tags = None
         self.payload = None            # argument struct of a launch that has a table-driven batched form (level_batch)
         self.bkey = 0                  # kernel-variant key: only launches with equal keys share a batch
         self.arena, self.members = None, 1
@@ -181,11 +182,25 @@ def _overlap(a, b):
     return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
 
 
-def schedule(cmds, nstreams):
+LEAF_STREAM = 1          # `schedule(..., leaf=)`: the stream that takes the leaf work (weight gradients and their reductions)
+
+
+def is_leaf(c):
+    """Work nothing on the step's dependency chain waits for: weight-gradient batches, their reductions, bias gradients — read by the
+    optimizer only (profiles/r04_critical_path.txt: 41 chip-filling launches, 14 ms, none of them on the 19-ms chain)."""
+    return c.name.startswith(('conv_wgrad', 'dw_wreduce', 'bias_grad', 'bias_n_grad', 'sep_wreduce'))
+
+
+def schedule(cmds, nstreams, leaf=None):
     """Assign every command a stream and the cross-stream waits it needs.  A command follows the stream of its most
     recent dependency when that dependency is still the tail of its stream (a chain stays on one stream, no event);
     otherwise it opens on the least recently used stream and waits on events.  Program order inside a stream plus the
-    recorded waits preserve every RAW/WAW/WAR relation of the sequential list."""
+    recorded waits preserve every RAW/WAW/WAR relation of the sequential list.
+    `leaf` (a predicate, nstreams >= 3): commands it accepts are pinned to stream LEAF_STREAM and no other command is placed there —
+    the stream the caller creates at LOW priority, so that the dependency chain on the other streams gets the CUs first."""
+    if leaf is not None and nstreams < 3:
+        leaf = None
+    free = [t for t in range(nstreams) if leaf is None or t != LEAF_STREAM]
     writers, readers = {}, {}            # buffer id -> [(region, idx)]
     tail = [-1] * nstreams               # index of the last command on each stream
     # vector clocks: clock[i][t] = latest command of stream t known to have completed before command i starts.  A wait
@@ -200,12 +215,14 @@ def schedule(cmds, nstreams):
             deps.update(j for r, j in readers.get(k[0], ()) if _overlap(r, k))
         if c.pin or nstreams == 1:
             st = 0
+        elif leaf is not None and leaf(c):
+            st = LEAF_STREAM
         elif deps:
             last = max(deps)
             ls = cmds[last].stream
-            st = ls if tail[ls] == last else min(range(nstreams), key=lambda t: tail[t])
+            st = ls if (tail[ls] == last and ls in free) else min(free, key=lambda t: tail[t])
         else:
-            st = min(range(nstreams), key=lambda t: tail[t])
+            st = min(free, key=lambda t: tail[t])
         # hipStreamEndCapture (ROCm 7.2) crashes when two SIDE streams wait on each other (measured with
         # scripts/capture_probe.py: 'mutual12' dumps core, 'ordered' does not).  Side stream s therefore only ever waits
         # on side streams t > s (and on the main stream 0, which may wait on anybody); a command that would need the
@@ -368,10 +385,25 @@ class Graph:
             for i, c in enumerate(lst):
                 if not isinstance(c, Cmd):           # commands appended as plain triples (e.g. collectives): pinned to the main stream
                     lst[i] = Cmd(c[0], c[1], c[2], pin=True)
-            schedule(lst, self.nstreams)
+            schedule(lst, self.nstreams, is_leaf if self.stream_mode() in ('w3', 'w3n') else None)
             for c in lst:
                 if c.event:
                     c.event = torch.cuda.Event()
+
+    @staticmethod
+    def stream_mode():
+        """ADDK_STREAM_PRIO: '0' plain streams (structural two-stream schedule); 'p2': the main stream at high priority, side streams low;
+        'w3' (three streams): leaf work (plan.is_leaf) pinned to a LOW-priority stream, the dependency chain on two HIGH-priority ones;
+        'w3n': the same placement without priorities (the control of the A/B)."""
+        return os.environ.get('ADDK_STREAM_PRIO', '0')
+
+    def main_stream(self):
+        """The stream a whole step is issued / captured on when the stream mode asks for priorities (else None: the caller's current stream)."""
+        if self.device.type != 'cuda' or self.stream_mode() not in ('p2', 'w3'):
+            return None
+        if getattr(self, '_main', None) is None:
+            self._main = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._main
 
     _BATCHED = {'bn_finalize': ('addk_bn_finalize_batch', lambda p: p.C), 'bn_bwd': ('addk_bn_bwd_batch', lambda p: p.C),
                 'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P),
@@ -447,10 +479,12 @@ class Graph:
             groups = collections.defaultdict(list)
             for c in buckets[lv]:
                 if c.name in self._BATCHED and c.payload is not None and c.name not in single:
-                    groups[(c.name, c.bkey)].append(c)
+                    # the segment tag is part of the key: a merged launch never mixes network segments (stem / cell / low / aspp / decoder), so the
+                    # per-segment figures bench.segment_roofline reports time exactly that segment's work; all-reduces stay per level
+                    groups[(c.name, c.bkey, '' if c.name == 'allreduce' else c.tag)].append(c)
                 else:
                     out.append(c)
-            for (name, _), cs in groups.items():
+            for (name, _, _), cs in groups.items():
                 if len(cs) == 1 and name != 'allreduce':
                     out.append(cs[0])
                     continue
@@ -464,6 +498,7 @@ class Graph:
                     m.rd = [r for c in cs for r in c.rd]
                     m.wr = [r for c in cs for r in c.wr]
                     m.tag = cs[0].tag
+                    m.tags = {c.tag for c in cs}
                     m.members = len(cs)
                     out.append(m)
                     continue
@@ -490,6 +525,7 @@ class Graph:
                 m.rd = [r for c in cs for r in c.rd]
                 m.wr = [r for c in cs for r in c.wr]
                 m.tag = cs[0].tag
+                m.tags = {c.tag for c in cs}           # a merged launch may hold members of several network segments (bench.segment_roofline checks)
                 out.append(m)
         lst[:] = out
 
@@ -651,7 +687,10 @@ class Graph:
 
     def _side_streams(self):
         if getattr(self, '_streams', None) is None:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.nstreams - 1)]
+            mode = self.stream_mode()
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
+            prio = {'p2': lambda i: lo, 'w3': lambda i: lo if i == LEAF_STREAM else hi}.get(mode, lambda i: 0)
+            self._streams = [torch.cuda.Stream(device=self.device, priority=prio(i)) for i in range(1, self.nstreams)]
         return self._streams
 
     def _pending(self, act):
@@ -963,11 +1002,6 @@ class Graph:
                 else:
                     ba.c1, ba.c2 = c1.ptr, c2.ptr
                     self._add(self.bwd, 'bn_bwd', lib.addk_bn_bwd, C.byref(ba), rd=rd_bn, wr=pg + [c1, c2]).payload = ba
-                if id(raw) in self.__dict__.get('_fold_ok', ()):
-                    # the two consumers of this gradient (fused SepConv-half backward, its pointwise weight gradient) apply
-                    # dy = G + c1 + c2 (x - mean) in their own loaders (addk_bn_fold): no bn_bwd_apply launch, G stays as it is
-                    self.__dict__.setdefault('_fold', {})[id(raw)] = (c1, c2, mu)
-                    return
                 # dy_raw = G + c1 + c2*x, in place on the accumulated gradient
                 cap = self._add(self.bwd, 'bn_bwd_apply', lib.addk_bn_bwd_apply, g.ptr, g.ld, raw.ptr, raw.ld, mu.ptr if mu else None,
                                 c1.ptr, c2.ptr, raw.P, Cc, g.ptr, g.ld, rd=[g, raw, c1, c2, mu], wr=[g])
@@ -1077,15 +1111,6 @@ class Graph:
             ba = L.SepBwdArgs()
             fill(ba, raw.ptr, raw.ld)
             ok = int(lib.addk_sep_bwd_rows(C.byref(ba))) > 0
-            if ok and os.environ.get('ADDK_FOLD_BN_APPLY', '0') == '1':      # measured SLOWER (step 37.7 vs 36.5 ms): opt-in, see DESIGN §10
-                # may the BatchNorm backward behind this half be folded into its two consumers (sepb's dy loader and the pointwise weight
-                # gradient's)?  Only when that weight gradient runs on the register-streaming kernel (kind 6), the one that honours `fold`
-                wa = L.ConvWgradArgs()
-                ts = L.Src(); ts.x, ts.ld, ts.C = raw.ptr, Cc, Cc
-                fill_w(wa, raw.ptr, raw.ld, ts, raw.ptr, 0)
-                cfg = (C.c_int32 * 4)()
-                if lib.addk_conv_wgrad_config(C.byref(wa), cfg) == 0 and cfg[0] == 6:
-                    self.__dict__.setdefault('_fold_ok', set()).add(id(raw))
             return ok
 
         def emit_bwd():
@@ -1097,20 +1122,10 @@ class Graph:
             gp, acc = self.param_grad(pw_mod.weight, (0, Cc))
             fill_w(wa, dy.ptr, dy.ld, self.src(t), gp, acc)
             wa.ws_floats = lib.addk_conv_wgrad_ws(N * H * W, Cout, Cc, 1)
-            # BatchNorm backward folded into both consumers (Graph.bn left dy un-applied and recorded its coefficient vectors)
-            fold = self.__dict__.get('_fold', {}).get(id(raw))
-            frd = []
-            if fold is not None:
-                c1, c2, mu = fold
-                frd = [raw, c1, c2] + ([mu] if mu is not None else [])
-            self._wgrads.append((wa, [dy] + self.lz(t) + frd, self.pgrad[pw_mod.weight], (id(pw_mod.weight), 0, Cc)))
+            self._wgrads.append((wa, [dy] + self.lz(t), self.pgrad[pw_mod.weight], (id(pw_mod.weight), 0, Cc)))
             # fused data gradient + depthwise backward
             ba = L.SepBwdArgs()
             fill(ba, dy.ptr, dy.ld)
-            if fold is not None:
-                for a_ in (wa, ba):
-                    a_.fold.y, a_.fold.ldy, a_.fold.c1, a_.fold.c2 = raw.ptr, raw.ld, c1.ptr, c2.ptr
-                    a_.fold.mean = mu.ptr if mu is not None else None
             rows = int(lib.addk_sep_bwd_rows(C.byref(ba)))
             gs = slab = None
             if src.needs_grad:
@@ -1127,7 +1142,7 @@ class Graph:
             it.ws, it.dw, it.rows, it.n, it.accumulate = ws.ptr, gpw, rows, Cc * k * k, accw
             self._dwreds.append((it, ws, self.pgrad[dw_mod.weight]))
             self.keep.append(ba)
-            cb = self._add(self.bwd, 'sep_bwd', lib.addk_sep_bwd, C.byref(ba), rd=[dy, dw_mod.weight, pw_mod.weight] + self.lz(src) + frd,
+            cb = self._add(self.bwd, 'sep_bwd', lib.addk_sep_bwd, C.byref(ba), rd=[dy, dw_mod.weight, pw_mod.weight] + self.lz(src),
                            wr=[gs, slab, ws])
             bk = int(lib.addk_sep_bwd_batch_key(C.byref(ba)))
             if bk >= 0:
@@ -1200,54 +1215,6 @@ class Graph:
         if bk >= 0:
             c.payload, c.bkey = ar, bk
         return act
-
-    def sepconv_whole(self, src, dw1, pw1, bn1, dw2, pw2, bn2, sum_terms=None, out=None):
-        """A WHOLE SepConv (operations.py:46-62) as ONE inference launch (addk_sepconv_fwd, csrc/sepw.hip): both halves, the frozen BatchNorm
-        + ReLU between them, and — when this op closes a cell block — its own frozen BatchNorm plus the other branches of the block
-        (ADD.py:108).  The intermediate tensor never exists.  Returns the Act, or None where the kernel does not cover the op (training,
-        gradients, other shapes): the caller then emits the two halves (sep_half)."""
-        lib = self.lib
-        # BUILT, MEASURED, OFF BY DEFAULT (profiles/r04_sepconv_whole_vs_halves.txt): one launch takes 26.8 / 31.2 us against 2 x 14.5 / 2 x 18 us
-        # for the 3x3 SepConvs at 80 / 40 channels and 52.6 / 57.2 us against 2 x 17 / 2 x 20 us for the 5x5 ones (x2.5 recomputed mid pixels in three
-        # rounds per wave, pointwise weights streamed from L2 because the 101 KB patch fills the LDS); the inference segment: 7.90 ms with every
-        # SepConv in one launch, 7.08-7.12 ms with the 3x3 ones only, 6.85-6.90 ms with the two fused halves.  '3': 3x3 only, '1': all, '0' (default): never
-        mode = os.environ.get('ADDK_FUSE_SEPCONV', '0')
-        if self.training or self.want_grad or mode == '0':
-            return None
-        k = dw1.kernel_size[0]
-        if k != 3 and mode != '1':
-            return None
-        same = all(m.stride[0] == 1 and m.dilation[0] == 1 and m.padding[0] == k // 2 and m.kernel_size[0] == k for m in (dw1, dw2))
-        if not same or pw1.kernel_size[0] != 1 or pw2.kernel_size[0] != 1 or pw1.out_channels != src.C or pw2.out_channels != src.C:
-            return None
-        N, H, W, Cc = src.N, src.H, src.W, src.C
-        raw = out if (out is not None and sum_terms is not None) else self.tensor(N, H, W, Cc)
-        ar = L.SepConvArgs()
-        ar.src = self.src(src, True)
-        ar.N, ar.H, ar.W, ar.K, ar.ldw, ar.ldy = N, H, W, k, Cc, raw.ld
-        ar.dw1_w, ar.pw1_w, ar.dw2_w, ar.pw2_w = self.param(dw1.weight), self.param(pw1.weight), self.param(dw2.weight), self.param(pw2.weight)
-        ar.y = raw.ptr
-        ar.nterm = 0
-        if int(lib.addk_sepconv_fwd_supported(C.byref(ar))) != 1:
-            return None
-        st1 = self.bn(TRef(None, 0, N, H, W, Cc, Cc), bn1, None, 0).bn          # frozen BatchNorm of half 1: (a, b) only, the tensor never exists
-        ar.mid_a, ar.mid_b = st1.a.ptr, st1.b.ptr
-        rd = self.lz(src) + [dw1.weight, pw1.weight, dw2.weight, pw2.weight, st1.a, st1.b]
-        res = None
-        if sum_terms is not None:
-            st2 = self.bn(raw, bn2, None, 0).bn
-            terms = [tm for tm in sum_terms if not tm.zero]
-            assert len(terms) <= L.MAX_TERMS and out is not None
-            ar.ea, ar.eb, ar.nterm = st2.a.ptr, st2.b.ptr, len(terms)
-            for i, tm in enumerate(terms):
-                assert (tm.N, tm.H, tm.W, tm.C) == (N, H, W, Cc), 'branch shapes differ'
-                ar.term[i] = self.src(tm)
-                rd += self.lz(tm)
-            rd += [st2.a, st2.b]
-            res = Act(raw, None, False, False)
-        self.keep.append(ar)
-        self._add(self.fwd, 'sepconv_fwd', lib.addk_sepconv_fwd, C.byref(ar), rd=rd, wr=[raw])
-        return res if res is not None else self.bn(raw, bn2, None, 0)
 
     def affine_sum(self, terms, out=None, relu_out=False):
         """Materialise sum_i relu_i?(a_i*x_i+b_i) (optionally ReLU'd) into `out`."""

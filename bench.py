@@ -209,7 +209,13 @@ def segment_roofline(model, x, mode, reps=8):
     whole2 = _events_ms(lambda: g2.run_parallel(g2.fwd, None), reps)
     # the SAME segment on the list the model really runs (level-ordered, batched, two streams): the cell + ASPP commands of that list,
     # re-scheduled on their own (their inputs — stem outputs, frozen-BN coefficients, packed weights — are resident from the runs above)
-    segc = [c for c in g2.fwd if c.tag in ('cell', 'aspp')]
+    seg_tags = {'cell', 'aspp'}
+    tags_of = lambda c: getattr(c, 'tags', None) or {c.tag}
+    segc = [c for c in g2.fwd if tags_of(c) & seg_tags]
+    # a level-merged launch carries the tags of ALL its members: the segment figure is only the segment's if no selected launch holds work of
+    # another segment (stem / low-level / decoder) and no cell / ASPP member hides in a launch that was dropped
+    mixed = [(c.name, sorted(t for t in tags_of(c) if t)) for c in segc if not tags_of(c) <= seg_tags]
+    assert not mixed, 'segment_roofline: merged launches mix segments: %r' % mixed[:4]
     for c in segc:
         c.event = None
     P.schedule(segc, g2.nstreams)
@@ -662,15 +668,17 @@ def main():
             assert rel <= 1e-3, 'first-step loss %.7f differs from the CPU oracle %.7f on the same inputs (rel %.2e)' % (losses[0], ref, rel)
             if len(losses) > 1 and cb.get('second_step_loss') is not None:
                 # the second step's loss has been through one whole backward pass + SGD update of every parameter: the full-size
-                # backward / optimizer check of the headline shape.  The bound is 5e-3, not 1e-3: with random-init weights the
-                # train-mode network amplifies a 3e-8 forward perturbation (another summation order of one BatchNorm's statistics)
-                # to 2e-4 at the decoder and 3e-2 in the gradients (scripts/ab_sep_fwd.py, scripts/ab_sep.py), which moves this
-                # loss by 1e-4 .. 1.3e-3 between builds that are each correct to rounding (measured 6.8e-5, 1.1e-4, 1.24e-3); a
-                # missing or wrong update is 1.8e-2 away (the loss does not move without the step)
+                # backward / optimizer check of the headline shape.  Bound from the reference's OWN arithmetic at this shape
+                # (tests/golden/grads64.npz `full_train_sentinels`, the real reference in fp32 and in double at 2x1024x2048, train mode): its
+                # fp32 gradients sit 4.4e-2..6.5e-2 (max-abs) / 4.8e-2..5.0e-2 (rms) from its fp64 ones on the stems and early cells —
+                # train-mode BatchNorm amplifies rounding by 10^4..10^5 — so two fp32 realisations of the step, each correct to rounding,
+                # disagree by ~7 % of what the update does to the loss: 0.07 x 0.053 (the loss moves 3.30 -> 3.25) / 3.25 = 1.2e-3 relative
+                # (measured over builds 6.8e-5 .. 1.27e-3).  Asserted at 2.5e-3 = twice that spread; a missing or wrong update is 1.6e-2
+                # away (the loss does not move without the step).  tests/test_gpu_round5.py holds the gradients themselves to that fixture
                 ref2 = cb['second_step_loss']
                 rel2 = abs(losses[1] - ref2) / abs(ref2)
                 out['first_step_loss_vs_cpu_oracle']['second_step'] = {'gpu': losses[1], 'cpu_oracle': ref2, 'rel_diff': rel2}
-                assert rel2 <= 5e-3, 'second-step loss %.7f differs from the CPU oracle %.7f (rel %.2e): backward / SGD parity' % (losses[1], ref2, rel2)
+                assert rel2 <= 2.5e-3, 'second-step loss %.7f differs from the CPU oracle %.7f (rel %.2e): backward / SGD parity' % (losses[1], ref2, rel2)
     json_out.write(json.dumps(out) + '\n')
     json_out.flush()
     if comm is not None:

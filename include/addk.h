@@ -189,13 +189,6 @@ int addk_conv_pack_batch(const void* dev_descs, int32_t n, void* stream);
 /* Weight gradient for ONE source: dw[co][tap][w_choff+ci] = sum_p dy[p,co] * z[p@tap,ci],
  * z = relu?(a*x+b).  Deterministic split-P: partial tiles go to `ws`, then are reduced into
  * dw (accumulate: the shared ASPP/decoder head is used once per exit — SURVEY Q4). */
-/* BatchNorm backward FOLDED into a consumer of dy: the consumer computes, element by element and in addk_bn_bwd_apply's own order,
- *   dy_used = dy + (c1 + c2 * (y - mean))        y: the BatchNorm's raw input at the same pixel / channel; mean NULL = 0
- * instead of reading a gradient that addk_bn_bwd_apply rewrote in place (one launch and one read-modify-write of the tensor per
- * BatchNorm saved; reference batchnorm.py:51-53).  y == NULL: dy is used as it is.  Honoured by addk_sep_bwd and by the
- * register-streaming weight gradient (addk_conv_wgrad_config: kind 6); every other kernel refuses a non-NULL y. */
-typedef struct addk_bn_fold { const float* y; int32_t ldy; int32_t _pad; const float* c1; const float* c2; const float* mean; } addk_bn_fold;
-
 typedef struct addk_conv_wgrad_args {
   const float* dy; int32_t lddy; int32_t Cout;
   int32_t N, H, W, OH, OW, KH, KW, stride, pad, dil;
@@ -203,7 +196,6 @@ typedef struct addk_conv_wgrad_args {
   float* dw; int32_t ldw, cin_total, w_choff;
   int32_t accumulate;
   float* ws; int64_t ws_floats;  /* workspace, >= addk_conv_wgrad_ws() floats */
-  addk_bn_fold fold;             /* dy = gradient wrt a BatchNorm's OUTPUT, the BatchNorm backward applied on the fly (kind 6 only) */
 } addk_conv_wgrad_args;
 int addk_conv_wgrad(const addk_conv_wgrad_args* a, void* stream);
 int64_t addk_conv_wgrad_ws(int64_t P, int32_t Cout, int32_t C, int32_t taps);
@@ -246,7 +238,6 @@ typedef struct addk_sep_args {
   addk_src term[ADDK_MAX_TERMS];
   addk_bn_finalize_args fin;        /* fused finalize of the statistics (fin.a == NULL: none) */
   void* fin_counter;
-  int32_t io16; int32_t _pad;       /* 1: storage experiment — src.x, y, t and the terms are bf16 arrays (same element strides), single launches of the config-2 cell shapes only */
 } addk_sep_args;
 int64_t addk_bn_fin_ws_bytes(int32_t nblocks, int32_t ld);
 int addk_sep_rows(const addk_sep_args* a);               /* slab rows (= workgroups) of the fused launch; 0: not covered */
@@ -257,30 +248,9 @@ int addk_sep_fwd_batch_key(const addk_sep_args* a);
 int64_t addk_sep_fwd_batch_prepare(const addk_sep_args* a, int32_t n, void* host_blob, int64_t blob_bytes, int64_t* meta);
 int addk_sep_batch_run(const void* dev_blob, const int64_t* meta, void* stream);
 
-/* A WHOLE SepConv in one launch, inference form (csrc/sepw.hip; operations.py:46-62 with both BatchNorms frozen):
- *   relu?(a*x+b) -> depthwise K x K -> pointwise -> mid_a*(.)+mid_b -> ReLU -> depthwise K x K -> pointwise
- *   -> y = ea*acc + eb + sum_i relu_i?(a_i*term_i + b_i)      (ea == NULL: plain y = acc: the caller's lazy BatchNorm follows)
- * The intermediate tensor never exists: the first half is computed on the second half's halo inside the workgroup.  Same covered
- * shapes as addk_sep_fwd (K in {3,5}, channels in (32,48] or (64,80]); addk_sepconv_fwd_supported says so; results agree with two
- * addk_sep_fwd launches to fp32 rounding (same products, same summation order per output element). */
-typedef struct addk_sepconv_args {
-  addk_src src;                       /* lazy input (x, a, b, relu) */
-  int32_t N, H, W, K;                 /* output size == input size; depthwise kernel size of both halves */
-  int32_t ldw, ldy;                   /* pointwise weight row stride (both halves); output pixel stride */
-  const float* dw1_w; const float* pw1_w;     /* half 1: depthwise [C][K*K], pointwise [C][ldw] */
-  const float* mid_a; const float* mid_b;     /* frozen BatchNorm of half 1 (both NULL = identity); ReLU follows */
-  const float* dw2_w; const float* pw2_w;     /* half 2 */
-  float* y;
-  const float* ea; const float* eb;           /* own frozen BatchNorm of half 2 (both NULL = none) */
-  int32_t nterm; int32_t _pad;
-  addk_src term[ADDK_MAX_TERMS];
-} addk_sepconv_args;
-int addk_sepconv_fwd_supported(const addk_sepconv_args* a);
-int addk_sepconv_fwd(const addk_sepconv_args* a, void* stream);
-
 /* Fused BACKWARD of a SepConv half (csrc/sepb.hip): pointwise data gradient (dt = W^T dy, matrix cores) and depthwise backward
  * (dx, depthwise weight-gradient partials, (dA, dB) of the input's lazy BatchNorm) in one launch; dt stays on chip.  dy is the
- * gradient wrt the pointwise output with the BatchNorm backward already applied (addk_bn_bwd_apply) or, with `fold`, applied here.  The pointwise WEIGHT
+ * gradient wrt the pointwise output with the BatchNorm backward already applied (addk_bn_bwd_apply).  The pointwise WEIGHT
  * gradient is not part of it (addk_conv_wgrad on dy and the stored depthwise output).  `ws` ([rows][C][K*K] floats) and `dab`
  * ([rows][C][2] fp64) get one row per workgroup, rows = addk_sep_bwd_rows(a); ws is reduced by addk_dw_wreduce_batch. */
 typedef struct addk_sep_bwd_args {
@@ -292,7 +262,6 @@ typedef struct addk_sep_bwd_args {
   float* g; int32_t ldg; int32_t accumulate;   /* gradient wrt src.x (NULL: skip) */
   double* dab;                      /* or NULL */
   float* ws;
-  addk_bn_fold fold;                /* fold.y != NULL: dy is the gradient BEFORE addk_bn_bwd_apply, which is applied on the fly */
 } addk_sep_bwd_args;
 int addk_sep_bwd_rows(const addk_sep_bwd_args* a);
 int addk_sep_bwd(const addk_sep_bwd_args* a, void* stream);

@@ -38,7 +38,7 @@ torch.set_num_threads(8)
 SA = os.path.join(HERE, '..', '..', 'searched_arch', '40_5e_38_lr')
 
 
-def run_case(out, case, Fv, geno, hw, wseed, xseed, xname, tseed, train, only=None, ignore=True, conv_only=False, arch=ARCH_C2, logits=False):
+def run_case(out, case, Fv, geno, hw, wseed, xseed, xname, tseed, train, only=None, ignore=True, conv_only=False, arch=ARCH_C2, logits=False, lstride=97):
     """One forward + CE (mean over exits) + backward of the reference in fp32 and in fp64 on the same weights / batch."""
     t0 = time.time()
     args = (arch['network_arch'], arch['C_index'], geno, 19, make_args(Fv), arch['low_level_layer'])
@@ -61,7 +61,7 @@ def run_case(out, case, Fv, geno, hw, wseed, xseed, xname, tseed, train, only=No
         losses[prec] = float(loss)
         if logits:            # per-exit train-mode logits: every 97th element (as tests/golden/make_golden.py store_big) + the L2 norm
             for i, y in enumerate(ys):
-                out['%s/logits%s_%d@sub97' % (case, prec, i)] = y.detach().double().reshape(-1)[::97].float().numpy().copy()
+                out['%s/logits%s_%d@sub%d' % (case, prec, i, lstride)] = y.detach().double().reshape(-1)[::lstride].float().numpy().copy()
                 out['%s/logits%s_%d@maxabs' % (case, prec, i)] = np.float64(float(y.detach().abs().max()))
         grads[prec] = {n: p.grad.detach().double() for n, p in m.named_parameters() if p.grad is not None}
         del m, ys, loss
@@ -111,6 +111,10 @@ def cases():
         c['f40_%s' % g] = dict(Fv=40, geno=np.load(os.path.join(SA, g + '.npy')), hw=(256, 512), wseed=900, xseed=61, xname='f40_frozen_x', tseed=62, train=False, conv_only=True)
     # tests/test_gpu_round3.py::test_full_size_frozen_bn_gradients_on_sentinel_convs: config 2 at 2x1024x2048, 14 sentinel convs
     c['full_sentinels'] = dict(Fv=20, geno=GENOTYPE_AUTODEEPLAB, hw=(1024, 2048), wseed=1003, xseed=203, xname='full_frozen_x', tseed=66, train=False, only=SENTINELS)
+    # tests/test_gpu_round5.py::test_full_size_train_mode_gradients_on_sentinel_convs: the same shape and sentinels in TRAIN mode (batch statistics
+    # in every BatchNorm, `train.py:227-240`): the headline step's backward held against the reference in double
+    c['full_train_sentinels'] = dict(Fv=20, geno=GENOTYPE_AUTODEEPLAB, hw=(1024, 2048), wseed=1003, xseed=203, xname='full_frozen_x', tseed=66, train=True, only=SENTINELS,
+                                     logits=True, lstride=9973)
     return c
 
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     structs = {'addk_src': L.Src, 'addk_conv_args': L.ConvArgs, 'addk_conv_dgrad_args': L.ConvDgradArgs,
-               'addk_conv_wgrad_args': L.ConvWgradArgs, 'addk_dw_args': L.DwArgs, 'addk_sep_args': L.SepArgs, 'addk_sepconv_args': L.SepConvArgs, 'addk_sep_bwd_args': L.SepBwdArgs, 'addk_ce_upsample_args': L.CeUpsampleArgs, 'addk_dw_bwd_args': L.DwBwdArgs,
+               'addk_conv_wgrad_args': L.ConvWgradArgs, 'addk_dw_args': L.DwArgs, 'addk_sep_args': L.SepArgs, 'addk_sep_bwd_args': L.SepBwdArgs, 'addk_ce_upsample_args': L.CeUpsampleArgs, 'addk_dw_bwd_args': L.DwBwdArgs,
                'addk_bn_finalize_args': L.BnFinalizeArgs, 'addk_bn_bwd_args': L.BnBwdArgs,
                'addk_affine_sum_args': L.AffineSumArgs, 'addk_affine_sum_bwd_args': L.AffineSumBwdArgs,
                'addk_resize_args': L.ResizeArgs, 'addk_edm_args': L.EdmArgs, 'addk_resize_bwd_args': L.ResizeBwdArgs,

@@ -576,74 +576,3 @@ def test_stride2_conv_on_split_kernel_matches_fp64_reference(lib, shape, prec):
             errs['dab%d' % i] = _rel(dabs[i], dabref[i])
         bad = ['%s %.2e' % kv for kv in errs.items() if not kv[1] <= (tol if tag == 'split' else TOL)]
         assert not bad, '%s[%s] %s: %s' % (name, prec, tag, ', '.join(bad))
-
-
-@pytest.mark.parametrize('centered', [True, False], ids=['centred', 'folded_mean'])
-@pytest.mark.parametrize('shape', [SEP_SHAPES[0], SEP_SHAPES[3], ('sep3_c48_odd', 1, 67, 91, 48, 3)], ids=lambda s: s[0])
-def test_bn_backward_folded_into_sep_backward_and_pointwise_wgrad_is_bitwise_the_two_pass_form(lib, shape, centered):
-    """addk_bn_fold: dy = G + (c1 + c2 (y - mean)) computed inside the dy loaders of addk_sep_bwd and of the register-streaming
-    weight gradient (reference batchnorm.py:51-53 applied on the fly) must give, bit for bit, what the two-pass form gives —
-    addk_bn_bwd_apply writing dy, then the same two kernels reading it (each of those is held against fp64 elsewhere in this file)."""
-    L = lib
-    lb = L.load()
-    lb.addk_set_fast_paths(FAST_ALL)
-    name, N, H, W, Cc, k = shape
-    dev = torch.device('cuda:0')
-    gen = torch.Generator(device='cpu').manual_seed(11 + sum(map(ord, name)))
-    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
-    P = N * H * W
-    x, a, b = rnd(P, Cc), rnd(Cc), 0.3 * rnd(Cc)
-    wdw, wpw = 0.3 * rnd(Cc, k * k), 0.2 * rnd(Cc, Cc)
-    G, y, t = rnd(P, Cc), rnd(P, Cc), rnd(P, Cc)
-    c1, c2, mean = 0.1 * rnd(Cc), 0.2 * rnd(Cc), (0.5 * rnd(Cc) if centered else None)
-    st = torch.cuda.current_stream().cuda_stream
-    dy = torch.empty_like(G)
-    L.check(lb.addk_bn_bwd_apply(G.data_ptr(), Cc, y.data_ptr(), Cc, mean.data_ptr() if centered else None, c1.data_ptr(), c2.data_ptr(),
-                                 P, Cc, dy.data_ptr(), Cc, st), 'bn_bwd_apply')
-
-    def set_fold(f):
-        f.y, f.ldy, f.c1, f.c2, f.mean = y.data_ptr(), Cc, c1.data_ptr(), c2.data_ptr(), (mean.data_ptr() if centered else None)
-
-    res = {}
-    for tag in ('two_pass', 'folded'):
-        ba = L.SepBwdArgs()
-        ba.dy, ba.lddy, ba.N, ba.H, ba.W, ba.K = (dy if tag == 'two_pass' else G).data_ptr(), Cc, N, H, W, k
-        ba.src.x, ba.src.a, ba.src.b, ba.src.ld, ba.src.C, ba.src.relu = x.data_ptr(), a.data_ptr(), b.data_ptr(), Cc, Cc, 1
-        ba.Cout, ba.ldw, ba.dw_w, ba.pw_w = Cc, Cc, wdw.data_ptr(), wpw.data_ptr()
-        if tag == 'folded':
-            set_fold(ba.fold)
-        rows = lb.addk_sep_bwd_rows(C.byref(ba))
-        assert rows > 0
-        g = torch.full((P, Cc), float('nan'), device=dev)
-        dab = torch.full((rows, Cc, 2), float('nan'), device=dev, dtype=torch.float64)
-        ws = torch.full((rows, Cc, k * k), float('nan'), device=dev)
-        ba.g, ba.ldg, ba.accumulate, ba.dab, ba.ws = g.data_ptr(), Cc, 0, dab.data_ptr(), ws.data_ptr()
-        L.check(lb.addk_sep_bwd(C.byref(ba), st), 'sep_bwd')
-        wa = L.ConvWgradArgs()
-        wa.dy, wa.lddy, wa.Cout = (dy if tag == 'two_pass' else G).data_ptr(), Cc, Cc
-        wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = N, H, W, H, W, 1, 1, 1, 0, 1
-        wa.src.x, wa.src.ld, wa.src.C = t.data_ptr(), Cc, Cc
-        dw = torch.full((Cc, Cc), float('nan'), device=dev)
-        wa.dw, wa.ldw, wa.cin_total, wa.w_choff, wa.accumulate = dw.data_ptr(), Cc, Cc, 0, 0
-        wa.ws_floats = lb.addk_conv_wgrad_ws(P, Cc, Cc, 1)
-        wsw = torch.empty(int(wa.ws_floats), device=dev)
-        wa.ws = wsw.data_ptr()
-        if tag == 'folded':
-            set_fold(wa.fold)
-        cfg = (C.c_int32 * 4)()
-        L.check(lb.addk_conv_wgrad_config(C.byref(wa), cfg), 'wgrad_config')
-        assert cfg[0] == 6, 'the pointwise weight gradient of a SepConv half runs on the register-streaming kernel'
-        L.check(lb.addk_conv_wgrad(C.byref(wa), st), 'conv_wgrad')
-        torch.cuda.synchronize()
-        res[tag] = (g, dab, ws, dw)
-    for u, v, what in zip(res['two_pass'], res['folded'], ('dx', 'dab', 'dw workspace', 'pointwise dW')):
-        assert torch.equal(u, v), '%s %s: folded form differs from addk_bn_bwd_apply + kernel (max |diff| %.3e)' % (name, what, float((u - v).abs().max()))
-    # and a kernel that cannot fold must say so instead of ignoring the request
-    wa = L.ConvWgradArgs()
-    wa.dy, wa.lddy, wa.Cout = G.data_ptr(), Cc, Cc
-    wa.N, wa.H, wa.W, wa.OH, wa.OW, wa.KH, wa.KW, wa.stride, wa.pad, wa.dil = 1, 8, 8, 8, 8, 1, 1, 1, 0, 1          # 64 pixels: below the streaming kernel's floor
-    wa.src.x, wa.src.ld, wa.src.C = t.data_ptr(), Cc, Cc
-    wa.dw, wa.ldw, wa.cin_total, wa.w_choff = dw.data_ptr(), Cc, Cc, 0
-    wa.ws, wa.ws_floats = wsw.data_ptr(), wsw.numel()
-    set_fold(wa.fold)
-    assert lb.addk_conv_wgrad(C.byref(wa), st) != 0

@@ -394,11 +394,12 @@ def test_tail_x3_mode_holds_the_frozen_bn_gradient_gate(dev):
     fp32 oracle's own distance to the reference's fp64 per draw, every gradient elementwise to 1e-2).  The heads sit at the end of the
     network, where nothing amplifies their rounding; the reference's own GPU path is 16-bit throughout (apex O1, train.py:145-165)."""
     import addk
+    prev = addk.get_precision()
     try:
         addk.set_precision('tail_x3')
         test_add_whole_net_frozen_bn_gradients(dev, 20, (512, 1024))
     finally:
-        addk.set_precision('bf16x6')
+        addk.set_precision(prev)
 
 
 @pytest.mark.parametrize('gname', ['genotype_1', 'genotype_2'])

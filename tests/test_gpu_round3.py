@@ -80,56 +80,83 @@ def test_stem0_kernel_matches_fp64_reference(dev, shape):
     assert e_y <= 2e-6 and e_s <= 2e-6
 
 
-def test_full_size_frozen_bn_gradients_on_sentinel_convs(dev):
-    """BASELINE config 2 at 2x1024x2048, BatchNorm frozen (eval mode), CE loss over both exits, backward: the conv-weight
-    gradients of a sentinel set spread over the network against an fp64 evaluation of the oracle, relative to the fp32 oracle's
-    own error (frozen BatchNorm removes the train-mode amplification, so this is a meaningful elementwise check)."""
+SENTINELS = ['stem1.0.weight', 'stem2.1.weight', 'cells.0._ops.1.op.2.weight', 'cells.0._ops.0.op.1.weight',
+             'cells.3._ops.6.op.1.weight', 'cells.4.preprocess.conv_1.weight', 'cells.7.pre_preprocess_1x1.op.1.weight',
+             'cells.11._ops.9.op.6.weight', 'low_level_conv.1.weight', 'aspp.aspp3.weight', 'aspp.conv1.weight',
+             'decoder._conv.1.weight', 'decoder._conv.4.weight', 'decoder._conv.7.weight']
+
+
+def sentinel_gate(dev, case, train, ratio, floor, full_rel, full_rms, log=None):
+    """Config 2 at 2x1024x2048, CE loss over both exits, backward; the conv-weight gradients of 14 sentinel convs spread over the network
+    (a) at the fixture's sample positions against the REFERENCE's own fp64 gradients (tests/golden/grads64.npz `case`), relative to the live
+    fp32 oracle's error on the same samples: e_addk <= max(ratio * e_oracle, floor) in both metrics — the log says which branch passed;
+    (b) over EVERY element against the live fp32 oracle (full_rel max-abs / full_rms): a fault confined to a channel tail or a tap that the
+    128-sample stride misses cannot pass.  Returns {name: (e_addk, e_oracle, e_ref32)}."""
+    log = log or _log
     hw = (1024, 2048)
     ma, mo = _bench_model(dev, seed=3)
-    sentinels = ['stem1.0.weight', 'stem2.1.weight', 'cells.0._ops.1.op.2.weight', 'cells.0._ops.0.op.1.weight',
-                 'cells.3._ops.6.op.1.weight', 'cells.4.preprocess.conv_1.weight', 'cells.7.pre_preprocess_1x1.op.1.weight',
-                 'cells.11._ops.9.op.6.weight', 'low_level_conv.1.weight', 'aspp.aspp3.weight', 'aspp.conv1.weight',
-                 'decoder._conv.1.weight', 'decoder._conv.4.weight', 'decoder._conv.7.weight']
     x = rand_tensor(203, 'full_frozen_x', (2, 3) + hw)
     tgt = _target(hw, seed=66)
     crit = nn.CrossEntropyLoss(ignore_index=255)
-    ma.eval(); mo.eval()
-    (sum(crit(y, tgt.to(dev)) for y in ma(x.to(dev))) / 2).backward()
+    ma.train(train); mo.train(train)
+    la = sum(crit(y, tgt.to(dev)) for y in ma(x.to(dev))) / 2
+    la.backward()
     torch.cuda.synchronize()
-    ga = {k: p.grad.detach().double().cpu() for k, p in ma.named_parameters() if k in sentinels}
+    ga = {k: p.grad.detach().double().cpu() for k, p in ma.named_parameters() if k in SENTINELS}
+    la = float(la)
     del ma
     torch.cuda.empty_cache()
     for p in mo.parameters():
         p.requires_grad_(False)
     po = dict(mo.named_parameters())
-    for k in sentinels:
+    for k in SENTINELS:
         po[k].requires_grad_(True)
-    (sum(crit(y, tgt) for y in mo(x)) / 2).backward()
-    # [r4] fp64 truth: the real reference in double precision at this very shape, held sub-sampled by tests/golden/grads64.npz — the
-    # full-size fp64 pass on the host (the longest single item of the round-3 suite) is gone
+    lo = sum(crit(y, tgt) for y in mo(x)) / 2
+    lo.backward()
+    # fp64 truth: the real reference in double precision at this very shape, held sub-sampled by tests/golden/grads64.npz
     from grads64_util import Grads64
-    fx = Grads64('full_sentinels')
-    assert set(fx.names()) == set(sentinels)
-    worst = 0.0
-    for k in sentinels:
+    fx = Grads64(case)
+    assert set(fx.names()) == set(SENTINELS)
+    mode = 'train-mode' if train else 'frozen-BN'
+    log('config2 2x1024x2048 %s loss: addk %.7f  fp32 oracle %.7f  reference fp64 %.7f (fp32 %.7f)', mode, la, float(lo), fx.loss64, fx.loss32)
+    assert abs(la - fx.loss64) <= 1e-3 * abs(fx.loss64), (la, fx.loss64)
+    worst, out = 0.0, {}
+    for k in SENTINELS:
         ea, eo = fx.rel_err(k, ga[k]), fx.rel_err(k, po[k].grad)
         ra, ro = fx.rms_err(k, ga[k]), fx.rms_err(k, po[k].grad)
+        g32 = po[k].grad.detach().double()
+        fr = float((ga[k] - g32).abs().max() / g32.abs().max())
+        fm = float(((ga[k] - g32) ** 2).mean().sqrt() / (g32 ** 2).mean().sqrt())
         worst = max(worst, ea / max(eo, 1e-30))
-        _log('config2 2x1024x2048 frozen-BN gradient %-44s addk %.2e  fp32 oracle %.2e  ratio %.2f | rms addk %.2e  fp32 oracle %.2e', k, ea, eo, ea / max(eo, 1e-30), ra, ro)
-        assert ea <= max(4 * eo, 1e-3), (k, ea, eo)
-        assert ra <= max(4 * ro, 1e-3), (k, ra, ro)
-    _log('config2 2x1024x2048 frozen-BN sentinel gradients: worst ratio to the fp32 oracle %.2f', worst)
+        branch = 'ratio' if ea <= ratio * eo else 'floor'
+        log('config2 2x1024x2048 %s gradient %-40s addk %.2e  fp32 oracle %.2e (reference fp32 %.2e)  ratio %.2f [passes by %s] | rms addk %.2e  oracle %.2e | '
+            'every element vs fp32 oracle: max %.2e  rms %.2e', mode, k, ea, eo, fx.ref32_rel_err(k), ea / max(eo, 1e-30), branch, ra, ro, fr, fm)
+        assert ea <= max(ratio * eo, floor), (k, ea, eo)
+        assert ra <= max(ratio * ro, floor), (k, ra, ro)
+        assert fr <= full_rel and fm <= full_rms, (k, fr, fm)
+        out[k] = (ea, eo, fx.ref32_rel_err(k))
+    log('config2 2x1024x2048 %s sentinel gradients: worst ratio to the fp32 oracle %.2f', mode, worst)
+    return out
+
+
+def test_full_size_frozen_bn_gradients_on_sentinel_convs(dev):
+    """BASELINE config 2 at 2x1024x2048, BatchNorm frozen (eval mode): see sentinel_gate.  Asserted: error against the reference's fp64 within
+    max(4x the fp32 oracle's own, 1e-3) per sentinel in max-abs and rms metrics (measured worst ratios 8-13x on the split-bf16 weight gradients
+    of the exit heads, at absolute errors <= 1e-5: they pass by the 1e-3 floor, which is north_star's tolerance), and every element within
+    1e-2 / 1e-3 of the live fp32 oracle."""
+    sentinel_gate(dev, 'full_sentinels', False, 4.0, 1e-3, 1e-2, 2e-3)
 
 
 def test_tail_x3_mode_holds_the_full_size_sentinel_gate(dev):
     """`tail_x3` at the headline shape: the 14 sentinel conv-weight gradients of config 2 at 2x1024x2048 within 4x the fp32 oracle's own error
     against the reference's fp64 — the bf16x6 gate, unchanged."""
     import addk
+    prev = addk.get_precision()
     try:
         addk.set_precision('tail_x3')
         test_full_size_frozen_bn_gradients_on_sentinel_convs(dev)
     finally:
-        addk.set_precision('bf16x6')
+        addk.set_precision(prev)
 
 
 def _structured_images(n, hw, seed):
@@ -206,6 +233,7 @@ def test_bf16x3_whole_network_parity(dev):
     1e-3 of the oracle, frozen-BN conv-weight gradients at 2x256x512 median within 10x the fp32 oracle's own error against fp64 (p90 <= 1e-2, max <= 5e-2), one
     train-mode step's loss within 1e-4 of the oracle's."""
     import addk
+    prev = addk.get_precision()
     try:
         addk.set_precision('bf16x3')
         hw = (256, 512)
@@ -249,7 +277,7 @@ def test_bf16x3_whole_network_parity(dev):
         _log('bf16x3 F40_g1 256x512 train-mode loss: addk %.7f  oracle %.7f', float(la), float(lo))
         assert abs(float(la) - float(lo)) <= 1e-4 * abs(float(lo))
     finally:
-        addk.set_precision('bf16x6')
+        addk.set_precision(prev)
 
 
 def test_config5_architecture_full_size_logits_and_first_step_loss(dev):

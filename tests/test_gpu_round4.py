@@ -247,108 +247,6 @@ def test_dynamic_inference_gate_reads_the_pinned_word_the_fused_head_writes(dev)
         assert m.dynamic_inference(x, threshold=c + 1.0, confidence='edm', edm=e)[1] == 1
 
 
-SEPW_SHAPES = [
-    # N, H, W, C, K, number of sum terms (None = raw output, the caller's lazy BatchNorm follows)
-    (2, 63, 127, 80, 3, 1), (2, 63, 127, 80, 5, 1), (1, 125, 253, 40, 3, 1), (1, 125, 253, 40, 5, 2),
-    (1, 20, 33, 48, 3, None), (1, 9, 17, 72, 5, 0), (2, 3, 5, 40, 3, 1), (1, 64, 128, 80, 3, None), (1, 7, 16, 44, 5, 3),
-]
-
-
-@pytest.mark.parametrize('shape', SEPW_SHAPES, ids=['%dx%dx%dx%d_k%d_t%s' % s for s in SEPW_SHAPES])
-def test_whole_sepconv_launch_matches_fp64_reference_and_two_halves(L, dev, shape):
-    """addk_sepconv_fwd (csrc/sepw.hip): a whole inference SepConv (operations.py:46-62, BatchNorms frozen) in one launch against an fp64
-    PyTorch evaluation (relu -> depthwise -> pointwise -> affine -> relu -> depthwise -> pointwise -> affine + terms) and against the two
-    addk_sep_fwd launches it replaces; NaN-prefilled output (every pixel written), map edges and sizes that are not tile multiples,
-    channel counts with padded pixel strides (44, 48, 72), bit-identical run to run."""
-    lib = L.load()
-    N, H, W, Cc, K, nterm = shape
-    st = torch.cuda.current_stream().cuda_stream
-    g = torch.Generator().manual_seed(N * 7 + H + Cc + K)
-    P = N * H * W
-    x = torch.randn(P, Cc, generator=g).to(dev)
-    a0, b0 = (torch.rand(Cc, generator=g) + 0.5).to(dev), (torch.randn(Cc, generator=g) * 0.3).to(dev)
-    a1, b1 = (torch.rand(Cc, generator=g) + 0.5).to(dev), (torch.randn(Cc, generator=g) * 0.3).to(dev)
-    ea, eb = (torch.rand(Cc, generator=g) + 0.5).to(dev), (torch.randn(Cc, generator=g) * 0.3).to(dev)
-    dw1, dw2 = (torch.randn(Cc, K * K, generator=g) * 0.3).to(dev), (torch.randn(Cc, K * K, generator=g) * 0.3).to(dev)
-    pw1, pw2 = (torch.randn(Cc, Cc, generator=g) / Cc ** 0.5).to(dev), (torch.randn(Cc, Cc, generator=g) / Cc ** 0.5).to(dev)
-    terms = [torch.randn(P, Cc, generator=g).to(dev) for _ in range(nterm or 0)]
-    ta, tb = (torch.rand(Cc, generator=g) + 0.5).to(dev), (torch.randn(Cc, generator=g) * 0.3).to(dev)
-
-    def whole():
-        y = torch.full((P, Cc), float('nan'), device=dev)
-        ar = L.SepConvArgs()
-        ar.src = _mk_src(L, x, a0, b0, Cc, Cc, True)
-        ar.N, ar.H, ar.W, ar.K, ar.ldw, ar.ldy = N, H, W, K, Cc, Cc
-        ar.dw1_w, ar.pw1_w, ar.mid_a, ar.mid_b = dw1.data_ptr(), pw1.data_ptr(), a1.data_ptr(), b1.data_ptr()
-        ar.dw2_w, ar.pw2_w, ar.y = dw2.data_ptr(), pw2.data_ptr(), y.data_ptr()
-        if nterm is not None:
-            ar.ea, ar.eb, ar.nterm = ea.data_ptr(), eb.data_ptr(), nterm
-            for i, tm in enumerate(terms):
-                ar.term[i] = _mk_src(L, tm, ta if i == 0 else None, tb if i == 0 else None, Cc, Cc, i == 0)
-        assert lib.addk_sepconv_fwd_supported(C.byref(ar)) == 1
-        L.check(lib.addk_sepconv_fwd(C.byref(ar), st), 'sepconv_fwd')
-        return y
-
-    def halves():
-        mid = torch.full((P, Cc), float('nan'), device=dev)
-        y = torch.full((P, Cc), float('nan'), device=dev)
-        for k, (src, dw, pw, dst) in enumerate(((_mk_src(L, x, a0, b0, Cc, Cc, True), dw1, pw1, mid), (_mk_src(L, mid, a1, b1, Cc, Cc, True), dw2, pw2, y))):
-            ar = L.SepArgs()
-            ar.src = src
-            ar.N, ar.H, ar.W, ar.K, ar.Cout, ar.ldw = N, H, W, K, Cc, Cc
-            ar.dw_w, ar.pw_w, ar.y, ar.ldy = dw.data_ptr(), pw.data_ptr(), dst.data_ptr(), Cc
-            if k == 1 and nterm is not None:
-                ar.ea, ar.eb, ar.nterm = ea.data_ptr(), eb.data_ptr(), nterm
-                for i, tm in enumerate(terms):
-                    ar.term[i] = _mk_src(L, tm, ta if i == 0 else None, tb if i == 0 else None, Cc, Cc, i == 0)
-            assert lib.addk_sep_fwd_supported(C.byref(ar)) == 1
-            L.check(lib.addk_sep_fwd(C.byref(ar), st), 'sep_fwd')
-        return y
-    y1, y2, yh = whole(), whole(), halves()
-    torch.cuda.synchronize()
-    assert not torch.isnan(y1).any(), 'pixels left unwritten'
-    assert torch.equal(y1, y2)
-    # fp64 reference
-    xd = (x.double().cpu() * a0.double().cpu() + b0.double().cpu()).relu().view(N, H, W, Cc).permute(0, 3, 1, 2)
-    t = F.conv2d(xd, dw1.double().cpu().view(Cc, 1, K, K), padding=K // 2, groups=Cc)
-    t = F.conv2d(t, pw1.double().cpu().view(Cc, Cc, 1, 1))
-    t = (t * a1.double().cpu().view(1, Cc, 1, 1) + b1.double().cpu().view(1, Cc, 1, 1)).relu()
-    t = F.conv2d(t, dw2.double().cpu().view(Cc, 1, K, K), padding=K // 2, groups=Cc)
-    t = F.conv2d(t, pw2.double().cpu().view(Cc, Cc, 1, 1)).permute(0, 2, 3, 1).reshape(P, Cc)
-    if nterm is not None:
-        t = t * ea.double().cpu() + eb.double().cpu()
-        for i, tm in enumerate(terms):
-            t = t + ((tm.double().cpu() * ta.double().cpu() + tb.double().cpu()).relu() if i == 0 else tm.double().cpu())
-    scale = float(t.abs().max())
-    e_ref = float((y1.double().cpu() - t).abs().max()) / scale
-    e_hal = float((y1.double().cpu() - yh.double().cpu()).abs().max()) / scale
-    assert e_ref < 2e-5 and e_hal < 2e-5, (e_ref, e_hal)
-
-
-def test_inference_plan_uses_one_launch_per_sepconv_and_equals_the_two_half_plan(dev, monkeypatch):
-    """ADD F=20 inference at 256x512 with the opt-in whole-SepConv launch (ADDK_FUSE_SEPCONV=1; off by default: measured slower than the two
-    fused halves, plan.Graph.sepconv_whole): the plan holds no `sep_fwd` command for the covered cells, and the logits agree with the
-    two-launch form to 2e-5 of their range (the same arithmetic, the intermediate tensor kept in registers / LDS)."""
-    from _util import rand_tensor
-    x = rand_tensor(5, 'sepw_x', (1, 3, 256, 512)).to(dev)
-    outs, counts = {}, {}
-    for mode in ('1', '0'):
-        monkeypatch.setenv('ADDK_FUSE_SEPCONV', mode)
-        m = _cell_net(dev)
-        m.eval()
-        with torch.no_grad():
-            outs[mode] = [y.clone() for y in m(x)]
-        plan = next(iter(m._plans().values()))
-        counts[mode] = {n: sum(1 for c in plan.g.fwd if c.name.startswith(n)) for n in ('sepconv_fwd', 'sep_fwd')}
-        del m
-        torch.cuda.empty_cache()
-    assert counts['1']['sepconv_fwd'] >= 60 and counts['0']['sepconv_fwd'] == 0, counts
-    assert counts['1']['sep_fwd'] < counts['0']['sep_fwd'] // 4, counts
-    for a, b in zip(outs['1'], outs['0']):
-        e = float((a.double() - b.double()).abs().max() / b.double().abs().max())
-        assert e < 2e-5, e
-
-
 # ---- data gradient of the classifier (1x1, 256 -> 19): the register-weights / readlane kernel (pw.hip k1s_dgrad_kernel) -------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 33, 65, 256, 19, True, False), (1, 40, 50, 128, 19, False, True), (2, 17, 31, 256, 32, True, True),
