@@ -182,25 +182,11 @@ def _overlap(a, b):
     return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
 
 
-LEAF_STREAM = 1          # `schedule(..., leaf=)`: the stream that takes the leaf work (weight gradients and their reductions)
-
-
-def is_leaf(c):
-    """Work nothing on the step's dependency chain waits for: weight-gradient batches, their reductions, bias gradients — read by the
-    optimizer only (profiles/r04_critical_path.txt: 41 chip-filling launches, 14 ms, none of them on the 19-ms chain)."""
-    return c.name.startswith(('conv_wgrad', 'dw_wreduce', 'bias_grad', 'bias_n_grad', 'sep_wreduce'))
-
-
-def schedule(cmds, nstreams, leaf=None):
+def schedule(cmds, nstreams):
     """Assign every command a stream and the cross-stream waits it needs.  A command follows the stream of its most
     recent dependency when that dependency is still the tail of its stream (a chain stays on one stream, no event);
     otherwise it opens on the least recently used stream and waits on events.  Program order inside a stream plus the
-    recorded waits preserve every RAW/WAW/WAR relation of the sequential list.
-    `leaf` (a predicate, nstreams >= 3): commands it accepts are pinned to stream LEAF_STREAM and no other command is placed there —
-    the stream the caller creates at LOW priority, so that the dependency chain on the other streams gets the CUs first."""
-    if leaf is not None and nstreams < 3:
-        leaf = None
-    free = [t for t in range(nstreams) if leaf is None or t != LEAF_STREAM]
+    recorded waits preserve every RAW/WAW/WAR relation of the sequential list."""
     writers, readers = {}, {}            # buffer id -> [(region, idx)]
     tail = [-1] * nstreams               # index of the last command on each stream
     # vector clocks: clock[i][t] = latest command of stream t known to have completed before command i starts.  A wait
@@ -215,14 +201,12 @@ def schedule(cmds, nstreams, leaf=None):
             deps.update(j for r, j in readers.get(k[0], ()) if _overlap(r, k))
         if c.pin or nstreams == 1:
             st = 0
-        elif leaf is not None and leaf(c):
-            st = LEAF_STREAM
         elif deps:
             last = max(deps)
             ls = cmds[last].stream
-            st = ls if (tail[ls] == last and ls in free) else min(free, key=lambda t: tail[t])
+            st = ls if tail[ls] == last else min(range(nstreams), key=lambda t: tail[t])
         else:
-            st = min(free, key=lambda t: tail[t])
+            st = min(range(nstreams), key=lambda t: tail[t])
         # hipStreamEndCapture (ROCm 7.2) crashes when two SIDE streams wait on each other (measured with
         # scripts/capture_probe.py: 'mutual12' dumps core, 'ordered' does not).  Side stream s therefore only ever waits
         # on side streams t > s (and on the main stream 0, which may wait on anybody); a command that would need the
@@ -385,25 +369,10 @@ class Graph:
             for i, c in enumerate(lst):
                 if not isinstance(c, Cmd):           # commands appended as plain triples (e.g. collectives): pinned to the main stream
                     lst[i] = Cmd(c[0], c[1], c[2], pin=True)
-            schedule(lst, self.nstreams, is_leaf if self.stream_mode() in ('w3', 'w3n') else None)
+            schedule(lst, self.nstreams)
             for c in lst:
                 if c.event:
                     c.event = torch.cuda.Event()
-
-    @staticmethod
-    def stream_mode():
-        """ADDK_STREAM_PRIO: '0' plain streams (structural two-stream schedule); 'p2': the main stream at high priority, side streams low;
-        'w3' (three streams): leaf work (plan.is_leaf) pinned to a LOW-priority stream, the dependency chain on two HIGH-priority ones;
-        'w3n': the same placement without priorities (the control of the A/B)."""
-        return os.environ.get('ADDK_STREAM_PRIO', '0')
-
-    def main_stream(self):
-        """The stream a whole step is issued / captured on when the stream mode asks for priorities (else None: the caller's current stream)."""
-        if self.device.type != 'cuda' or self.stream_mode() not in ('p2', 'w3'):
-            return None
-        if getattr(self, '_main', None) is None:
-            self._main = torch.cuda.Stream(device=self.device, priority=-1)
-        return self._main
 
     _BATCHED = {'bn_finalize': ('addk_bn_finalize_batch', lambda p: p.C), 'bn_bwd': ('addk_bn_bwd_batch', lambda p: p.C),
                 'bn_bwd_apply': ('addk_bn_bwd_apply_batch', lambda p: p.P),
@@ -687,10 +656,7 @@ class Graph:
 
     def _side_streams(self):
         if getattr(self, '_streams', None) is None:
-            mode = self.stream_mode()
-            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
-            prio = {'p2': lambda i: lo, 'w3': lambda i: lo if i == LEAF_STREAM else hi}.get(mode, lambda i: 0)
-            self._streams = [torch.cuda.Stream(device=self.device, priority=prio(i)) for i in range(1, self.nstreams)]
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.nstreams - 1)]
         return self._streams
 
     def _pending(self, act):

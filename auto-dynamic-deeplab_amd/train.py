@@ -121,16 +121,8 @@ class TrainStep:
         self.use_graph = use_graph
         self.steps = 0
 
-    # one eager pass of the whole step on the current stream (or, with ADDK_STREAM_PRIO, on the plan's high-priority main stream)
+    # one eager pass of the whole step on the current stream
     def _run(self):
-        hp = self.g.main_stream()
-        if hp is not None and torch.cuda.current_stream() != hp and not torch.cuda.is_current_stream_capturing():
-            cur = torch.cuda.current_stream()
-            hp.wait_stream(cur)
-            with torch.cuda.stream(hp):
-                self._run()
-            cur.wait_stream(hp)
-            return
         main = torch.cuda.current_stream()
         st = main.cuda_stream
         g = self.g
@@ -163,7 +155,7 @@ class TrainStep:
             # A step with RCCL exchanges is captured in THREAD-LOCAL error mode: ProcessGroupNCCL's watchdog thread keeps
             # querying the events of the eager step's collectives, and in the default global mode such a query from another
             # thread while this one captures is an illegal call.
-            with torch.cuda.graph(graph, stream=self.g.main_stream(), capture_error_mode='thread_local' if self.has_coll else 'global'):
+            with torch.cuda.graph(graph, capture_error_mode='thread_local' if self.has_coll else 'global'):
                 self._run()
         except Exception as e:
             if not self.has_coll:

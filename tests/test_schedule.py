@@ -74,24 +74,6 @@ def test_side_streams_never_wait_on_each_other_both_ways(nstreams):
                 assert c.stream == 0 or t == 0 or t > c.stream, (c.stream, t)
 
 
-@pytest.mark.parametrize('nstreams', [3, 4])
-@pytest.mark.parametrize('seed', [7, 8, 9])
-def test_leaf_commands_are_pinned_to_their_own_stream_and_dependencies_survive(nstreams, seed):
-    """schedule(..., leaf=): every accepted command sits on plan.LEAF_STREAM, no other command does, every dependency still holds and the
-    side-stream wait rule of the capture constraint is kept (ADDK_STREAM_PRIO=w3: that stream is created at low priority)."""
-    cmds = _cmds(400, 12, seed, pinned_every=23)
-    leaf = lambda c: int(c.name[1:]) % 5 == 3 and not c.pin
-    P.schedule(cmds, nstreams, leaf)
-    deps, hb = _deps(cmds), _happens_before(cmds)
-    assert any(leaf(c) for c in cmds)
-    for i, c in enumerate(cmds):
-        assert (c.stream == P.LEAF_STREAM) == leaf(c), (i, c.stream)
-        assert deps[i] <= hb[i], 'command %d may start before %s' % (i, sorted(deps[i] - hb[i])[:3])
-        for j in c.waits:
-            t = cmds[j].stream
-            assert c.stream == 0 or t == 0 or t > c.stream, (c.stream, t)
-
-
 def test_implied_waits_are_pruned():
     # A(s0) -> B(s1) -> C(s?) with C also reading A's output: the wait on A is implied by the wait on B
     a = P.Cmd('a', None, (), rd=[], wr=[(1, 0, 16)])
