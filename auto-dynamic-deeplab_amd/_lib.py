@@ -150,6 +150,13 @@ _SIGS = {
     'addk_conv_dgrad_pack_desc': (i32, [C.POINTER(ConvDgradArgs), vp]),
     'addk_conv_pack_batch': (i32, [vp, i32, vp]),
     'addk_conv_fwd_resample_ok': (i32, [C.POINTER(ConvArgs)]),
+    'addk_debug_trace_fatal_signals': (i32, []),
+    'addk_comm_mailbox_bytes': (i64, [i32, i64]),
+    'addk_comm_alloc': (i32, [i32, i64, C.POINTER(vp), vp]),
+    'addk_comm_open': (i32, [i32, i32, i64, vp, vp, C.POINTER(vp)]),
+    'addk_comm_allreduce': (i32, [vp, vp, i64, i32, vp]),
+    'addk_comm_status': (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
+    'addk_comm_close': (i32, [vp, vp]),
     'addk_edm_head_ws_bytes': (i64, [i32, i32, i32]),
     'addk_edm_head_supported': (i32, [C.POINTER(EdmArgs)]),
     'addk_edm_head': (i32, [C.POINTER(EdmArgs), vp]),

@@ -14,41 +14,16 @@
 //
 // Reference call sites: decoder.py:17-27 (3x3 conv+BN+ReLU x2), aspp_train.py:20-41 (dilated 3x3 branches),
 // ADD.py:220-232 (stem1); autograd of nn.Conv2d for the data gradient.
-#include <stdlib.h>
-#include <string.h>
-#include <stdio.h>
-#include "common.h"
+#include "conv3b.h"
 
 namespace {
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-constexpr int C3_BP = 128;                 // pixels per tile (one row segment)
-constexpr int C3_BK = 16;                  // channels per chunk
 constexpr int C3_RS = 20;                  // floats per patch pixel in LDS (16 + 4: ds_read_b64 fragment reads hit 64 distinct banks per half-wave)
 constexpr int C3_MAXCH = 64;               // chunks per launch (K <= 1024 channels)
 // widest patch row: 3x3 up to dilation 18 (ASPP), 5x5 up to dilation 2 (the cells' dil_conv_5x5)
 constexpr int c3_pwmax(int ks) { return ks == 3 ? C3_BP + 2 * 18 : C3_BP + 4 * 2; }
 constexpr int c3_maxdil(int ks) { return ks == 3 ? 18 : 2; }
 
-struct C3K {
-  addk_src src[ADDK_MAX_SRC];
-  int nsrc;
-  int N, H, W, dil;       // H, W: the OUTPUT map (tiles, epilogue)
-  int HT;                   // tile rows in the walk: H, or ceil(H / 2) for two-row tiles
-  int IH, IW;               // the input map (= H, W for the stride-1 launches)
-  int Cn, ldy;
-  float* y;
-  const float* wp;          // packed weights of this launch
-  long wp_blk;              // floats per column block in wp
-  int nT;                   // chunks * taps
-  const float* bias; const float* bias_n;
-  double* slab; int slab_ld;
-  addk_src dst; int accumulate;
-  int vecY, red32;
-  long P; int ntiles, spr;
-  int st;                   // stride (host-side dispatch; 2 = the de-interleaved 3x3 forward of conv3b_kernel)
-  int om, oro, oco, OHo, OWo;   // output pixel of tile-grid position (oh, ow): (om oh + oro, om ow + oco) in an OHo x OWo map (om = 1: the grid itself)
-};
 
 struct PackK {
   const float* w; int ldw, cin_total;
@@ -333,47 +308,6 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
 }
 
 
-// ======================================================================================================================
-// Split-bf16 form of the same halo-patch convolution: every fp32 operand is written as x = h + m + l with h, m, l in bf16
-// (3 x 8 significand bits = the 24 of fp32, exactly) and a product is evaluated on the bf16 matrix pipe
-// (v_mfma_f32_32x32x16_bf16, fp32 accumulation) as the sum of its six largest bf16 x bf16 terms
-//     x*w  ~=  l*wh + h*wl + m*wm + m*wh + h*wm + h*wh          (dropped: m*wl, l*wm, l*wl  ~ 2^-26 relative)
-// Measured (scripts/bf16_split_probe.hip, K = 2048, random magnitudes over 6 octaves): max |err| / sum|a*b| = 3.0e-7, rms 5.6e-8 —
-// the same as the exact-fp32 v_mfma_f32_16x16x4_f32 chain (3.2e-7 / 6.8e-8) — at 6 x 16 = 96 matrix-pipe cycles per
-// 16x16x32 block of fp32 work instead of 256: 2.5x the fp32 MFMA rate (374 vs 149 TFLOP/s from registers).  The 3-term form
-// (h*wh + m*wh + h*wm, planes = 2) is the opt-in fast mode: 656 TFLOP/s, rms error 4.7e-7.
-//
-// Structure.  A block owns 128 pixels of one output row x (32 * WC) output channels; WAVE w owns channels [32w, 32w+32) of ALL
-// 128 pixels (four 32x32 accumulator tiles): the pixel fragments are shared through LDS (which has the bandwidth: 128 B/clk
-// per CU at 8 waves), the weight fragments are private to a wave and stream from L1/L2 (32 B/clk).  K is walked in
-// 16-channel chunks = one MFMA k-step; per chunk the KS input rows are staged ONCE: fp32 loads, lazy BatchNorm/ReLU prologue,
-// zero padding, then the split into planes — so the ~6 VALU operations per element of the split are paid once per staged
-// element, not per use (each element feeds KS*KS * 6 * WC MFMA operands).  LDS image per plane: [row][pixel][16 ch] bf16 =
-// 32 B per pixel, the two 16-byte halves of a pixel swapped when bit 3 of the pixel index is set: the ds_read_b128 of a
-// 32-pixel fragment then touches all 64 banks once per 16-lane group for every tap shift (no padding needed).
-// ======================================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int CB_PT = 4;                   // 32-pixel tiles per wave (128 pixels)
-constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP, int st = 1) { return st == 2 ? 2 * bpx + 16 : ks > 10 ? bpx + 4 : ks == 1 ? bpx : ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
-
-__device__ __forceinline__ unsigned bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
-__device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b << 16); }
-// 4 floats -> 4 bf16 per plane (8 bytes each)
-template <int NP>
-__device__ __forceinline__ void split4(const float4 v, uint2 (&pl)[NP]) {
-  float r[4] = {v.x, v.y, v.z, v.w};
-  unsigned b[NP][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float x = r[e];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) { b[k][e] = bf16_hi(x); x = x - bf16_f(b[k][e]); }
-  }
-#pragma unroll
-  for (int k = 0; k < NP; ++k) pl[k] = make_uint2(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16));
-}
-
 // packed weights: out (16-byte units) [colblk][T = chunk*taps + tap][tile (wave) i][plane][lane] = 8 bf16:
 //   W(row = colblk*32*bct + i*32 + (lane & 31), tap, k = 8*(lane >> 5) + j), j = 0..7       (bct = 32-row tiles per block)
 // Stride-2 data gradient (3x3, pad 1): input pixel (2a + pi, 2b + pj) collects dy(a + th, b + tw) W[kh][kw] over th <= pi, tw <= pj with
@@ -447,348 +381,6 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
     for (int k = 0; k < NP; ++k)
       o[k * 64] = make_uint4(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16), b[k][4] | (b[k][5] << 16), b[k][6] | (b[k][7] << 16));
   }
-}
-
-// PH = 2 (the <= 64-channel launches): the block's waves are also split over the two 64-pixel halves of the tile — wave w owns
-// channels [32 (w % WC), +32) of pixels [64 (w / WC), +64), two accumulator tiles — so that 4 waves share the staging work of
-// a 64-channel block (2-wave blocks staged 13-22 slots per thread and spilled).
-// BPX = 64: half-width pixel tiles (two accumulator tiles per wave) for launches that would otherwise put fewer than ~1.5
-// blocks on a CU (ASPP at 64x128, the 80-channel cell convs at 63x127: 126-256 blocks of 128 pixels = one wave per SIMD or less).
-// ST = 2 (stem2: 3x3, stride 2, pad 1, forward): output pixel ow reads input columns 2 ow - 1 + kw.  The patch row is staged
-// DE-INTERLEAVED — even patch columns pj = 2 e at LDS position e (0..BPX), odd ones pj = 2 o + 1 at position OB + o — so that
-// the fragment of tap kw is again 32 CONSECUTIVE positions (kw = 0: e = lp, kw = 1: o = lp, kw = 2: e = lp + 1) and the
-// swizzle / bank picture of the stride-1 kernel holds unchanged.  Checkerboard: position idx carries the sign (-1)^(oh+ow0+idx),
-// which is the output pixel's for kw = 0, 1 and its negative for kw = 2 — that tap's weights are packed negated.
-#ifdef ADDK_C3B_DIAG
-// diagnostic build (make CXXFLAGS+=-DADDK_C3B_DIAG, scripts/c3b_clock.sh): every workgroup adds its lifetime in shader-clock ticks (s_memtime)
-// and in 100 MHz reference ticks (s_memrealtime): their ratio is the clock the CUs ran at INSIDE this kernel
-__device__ unsigned long long g_c3b_diag[64][4];        // 64 slots: the workgroups' atomics do not queue on one L2 line
-#endif
-// TR = 2 (3x3 / 5x5, dilation d <= 2): the tile is TWO output rows of BPX pixels, d rows apart — oh0 and oh0 + d, whose input rows oh0 + (r - HK) d,
-// r = 0..KS, overlap in KS - 1 of KS + 1 — with the accumulator count of one row of 2 BPX pixels: the patch holds KS + 1 input rows instead
-// of 2 KS for the same outputs, 33 % (3x3) / 40 % (5x5) less staging (global loads, prologue, split, LDS writes) and HBM-side traffic.  The
-// tile walk counts row PAIRS (p.HT; pair q -> oh0 = (q / d) 2d + q % d) and the epilogue masks second rows beyond the map.
-template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1, int TR = 1>
-__device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const int gx) {      // workgroup bx of gx along x (tiles, slab row)
-#ifdef ADDK_C3B_DIAG
-  const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  static_assert(ST == 1 || (ST == 2 && KS == 3 && !BIGD && MODE == MODE_FWD), "stride 2: 3x3 forward only");
-  // KS = 12 / 21 / 22: a 1x2 / 2x1 / 2x2 tap set anchored at its first tap (no centring) — the parity classes of the stride-2 data
-  // gradient (c3b_s2_dgrad below); 1, 3, 5: the centred square kernels
-  constexpr int KH_ = KS > 10 ? KS / 10 : KS, KW_ = KS > 10 ? KS % 10 : KS;
-  static_assert(KS < 10 || (MODE == MODE_DGRAD && !BIGD && ST == 1), "anchored tap sets: data gradient only");
-  constexpr int OB = BPX + 16;                                      // ST = 2: LDS position of the first odd patch column
-  static_assert(TR == 1 || (TR == 2 && (KS == 3 || KS == 5) && !BIGD && ST == 1), "two-row tiles: centred kernels at dilation 1");
-  constexpr int BC = 32 * WC, NTHR = 64 * WC * PH, PT = TR * BPX / 32 / PH, TPR = BPX / 32;      // TPR: 32-pixel tiles per tile row
-  constexpr int PR_ = (KS > 10 ? KS / 10 : KS) + TR - 1;                                          // patch rows
-  constexpr int TAPS = KH_ * KW_, HK = KS > 10 ? 0 : KS / 2;
-  constexpr int PWP = cb_pwmax(KS, BIGD, BPX, ST);                         // LDS row pitch in pixels (compile time: tap offsets are immediates)
-  constexpr int NS = (PR_ * PWP * 4 + NTHR - 1) / NTHR;           // 16-byte (4-channel) patch slots per thread, enumerated over the pitch grid
-  static_assert(NS <= 32, "slot mask is 32 bits");
-  constexpr int PLANE = PR_ * PWP * 2;                             // uint4 units per plane
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* red = reinterpret_cast<double*>(smem);                  // [PH][BC][2] running statistics of this block (per pixel half)
-  uint4* Pl = reinterpret_cast<uint4*>(smem + ((PH * BC * 16 + 15) & ~15));   // [NP][KS][PWP][2] 16-byte halves
-  uint2* Pl2 = reinterpret_cast<uint2*>(Pl);
-
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wave = wv % WC, wpx = wv / WC, lp32 = lane & 31, hh = lane >> 5;
-  const int n0 = blockIdx.y * BC;
-  const int d = p.dil;
-  for (int i = t; i < PH * BC * 2; i += NTHR) red[i] = 0.0;
-
-  const int q = t & 3;
-  // patch slot -> (patch row r, LDS position sp in the row, patch column pj = input column - first input column of the tile)
-  auto slot_geo = [&](int k, int& r, int& sp, int& pj, bool& live) {
-    const int pix = (t + NTHR * k) >> 2;
-    r = pix / PWP; sp = pix - r * PWP;
-    if (ST == 1) { pj = sp; live = r < PR_ && pj < BPX + (KW_ - 1) * p.dil; }
-    else { const bool odd = sp >= OB; const int idx = odd ? sp - OB : sp; pj = 2 * idx + (odd ? 1 : 0); live = r < KH_ && (odd ? idx < BPX : idx <= BPX); }
-  };
-  // fragment read base per kernel column: pixel lane%32 + kw*d of patch row 0, the 16-byte half swizzled by bit 3 of the pixel
-  // (tile j adds 32 pixels: bit 3 unchanged); patch row kh and tile j are immediate offsets
-  int xb[KW_];
-  // 32-pixel tile j of this wave: tile row wrow + jrow(j), column tile wcol + jcol(j) (4-wave blocks of <= 64 channels split the tiles over two wave pairs:
-  // by rows when the tile has two, else by columns)
-  const int wrow = (PH == 2 && TR == 2) ? wpx : 0, wcol = (PH == 2 && TR == 1) ? wpx * PT : 0;
-  auto jrow = [](int j) { return PH == 1 ? j / TPR : 0; };
-  auto jcol = [](int j) { return PH == 1 ? j % TPR : j; };
-#pragma unroll
-  for (int kw = 0; kw < KW_; ++kw) {
-    const int pj = ST == 2 ? (kw == 1 ? OB + lp32 : lp32 + (kw >> 1)) : lp32 + kw * d;
-    xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)) + (wrow * PWP + wcol * 32) * 2;
-  }
-  const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)blockIdx.y * p.wp_blk + (long)wave * NP * 64 + lane);
-  const int nT = p.nT;
-  unsigned pmask = 0;                         // bit k: parity of (r*d + pj) of this thread's patch slot k (checkerboard sign, below)
-#pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    int r, sp, pj; bool live;
-    slot_geo(k, r, sp, pj, live);
-    pmask |= (unsigned)((ST == 2 ? sp : r * d + pj) & 1) << k;
-  }
-
-  const int tpx = p.ntiles >> 3;
-  const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
-  for (int tlin = bx; tlin < p.ntiles; tlin += gx) {
-    const int tile = swz ? (tlin & 7) * tpx + (tlin >> 3) : tlin;
-    const int rowid = tile / p.spr, sx = tile - rowid * p.spr;
-    const int n = rowid / p.HT, prq = rowid - n * p.HT;
-    const int oh = TR == 1 ? prq : (prq / d) * (2 * d) + prq % d;
-    const int ow0 = sx * BPX;
-    unsigned vmask = 0;
-    const int pbase = (n * p.IH + oh * ST - HK * d) * p.IW + ow0 * ST - HK * d;
-    const unsigned par0 = (unsigned)(oh + ow0);                 // parity of (ih + iw) of patch element (r, pj) = par0 + r*d + pj (the -2 HK d is even)
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      int r, sp, pj; bool live;
-      slot_geo(k, r, sp, pj, live);
-      const int ih = oh * ST + (r - HK) * d, iw = ow0 * ST - HK * d + pj;
-      const bool ok = live && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-      vmask |= (ok ? 1u : 0u) << k;
-    }
-
-    f32x16 acc[PT];
-#pragma unroll
-    for (int j = 0; j < PT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    // Blocked accumulation (the <= 64-channel launches: stem1, the cells' 40-channel dilated convs — the layers every later layer
-    // inherits its error from): the running sums are flushed into a second accumulator set after every 16-channel chunk, so a
-    // rounding error grows with sqrt(MFMAs per chunk) + sqrt(chunks) instead of sqrt(all MFMAs) (stem1: 54 + 4 instead of 216) —
-    // what a CPU library's blocked partial sums do (the even-size gradient deficit starts at stem1's K = 576 chain).
-    constexpr bool BLK = PH == 2 && (KS == 3 || KS > 10) && !BIGD;          // (the 5x5 and wide-dilation variants have no registers left: 256 + scratch with a second set)
-    f32x16 acc2[BLK ? PT : 1];
-    if (BLK) {
-#pragma unroll
-      for (int j = 0; j < PT; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
-    }
-
-    float4 ra[NS];
-    float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4();
-    bool prelu = false, pch = false;
-    auto load_patch = [&](int s_, int c0_) {      // branch-free: masked slots read the source base and are zeroed at store time
-      const addk_src S = p.src[s_];
-      const int c = c0_ + 4 * q;
-      pch = c < S.C;
-      prelu = S.relu != 0;
-      pa = make_float4(1.f, 1.f, 1.f, 1.f); pb = zero4();
-      if (S.a && pch) { pa = ld4(S.a + c); pb = ld4(S.b + c); }
-      const float* sb = S.x + (pch ? c : 0);
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        int r, sp, pj; bool live;
-        slot_geo(k, r, sp, pj, live);
-        const int po = ((vmask >> k) & 1u) ? pbase + r * d * p.IW + pj : 0;
-        ra[k] = ld4(sb + (long)po * S.ld);
-      }
-    };
-    auto store_patch = [&]() {                    // prologue, zero padding, split into planes
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        float4 v = ra[k];
-        v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
-        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        // zero padding and the checkerboard sign in one factor: 0 outside the image, -1 for input pixels of odd (ih + iw), else +1
-        const bool ok = pch && ((vmask >> k) & 1u);
-        const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
-        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
-        int r, sp, pj; bool live;
-        slot_geo(k, r, sp, pj, live);
-        if (r < PR_) {
-          uint2 pl[NP];
-          split4<NP>(v, pl);
-          const int slot = (r * PWP + sp) * 2 + ((q >> 1) ^ ((sp >> 3) & 1));
-#pragma unroll
-          for (int m = 0; m < NP; ++m) Pl2[(m * PLANE + slot) * 2 + (q & 1)] = pl[m];
-        }
-      }
-    };
-    // weight fragments of one tap: NP planes x 16 bytes per lane, the next tap's set is fetched while this tap's MFMAs issue
-    auto load_w = [&](int T, uint4* dst) {
-      const int Tc = T < nT ? T : nT - 1;
-      const uint4* src = wpl + (long)Tc * (WC * NP * 64);
-#pragma unroll
-      for (int m = 0; m < NP; ++m) dst[m] = src[m * 64];
-    };
-    // pixel fragment of (tap, tile j): lane reads 16 bytes of pixel (32 j + lane%32 + kw*d) in patch row kh, k half lane/32
-    auto read_x = [&](int tap, int j, uint4* x) {
-      const int kh = tap / KW_, kw = tap - kh * KW_;
-      const uint4* b = Pl + xb[kw];
-#pragma unroll
-      for (int m = 0; m < NP; ++m) x[m] = b[m * PLANE + ((kh + jrow(j)) * PWP + jcol(j) * 32) * 2];        // the wave's own tile row / first column tile sit in xb[]
-    };
-    // The accumulation inside the bf16 MFMA is not symmetric: what falls below its internal guard bits is floored, not rounded, so
-    // a result sits, on average, 0.17 rms errors BELOW the exact sum whatever the sign of the data (scripts/bf16_bias_probe.hip:
-    // mean error -2e-7 at |sum| ~ 1 for K = 2304; same for 32x32x16 and 16x16x32 and any term order; the fp32 MFMA shows
-    // none).  Per element that is below the rounding noise, but it is COHERENT: neighbouring pixels all err the same way, and
-    // the layers behind (3x3 windows, sums over 10^5-10^6 pixels) respond to such a DC shift far more than to white noise
-    // (whole-network frozen-BN gradients at 2x512x1024: 2.5x the error of the exact-fp32 kernels).  The kernel therefore
-    // computes a CHECKERBOARD of signs: output pixel (oh, ow) is accumulated as (-1)^(oh+ow) * y.  Input pixels of odd
-    // (ih + iw) are negated when they are staged (sign bits of the bf16 planes: exact), which puts (-1)^(oh+ow) * (-1)^((kh+kw) d)
-    // on the operand of tap (kh, kw); the second factor is uniform per tap and is baked into the packed weights; the epilogue undoes the
-    // pixel's sign.  The floor bias then alternates from pixel to pixel and averages out in every window and every sum.
-    auto mma = [&](f32x16& c, const uint4* w, const uint4* x) {
-      auto W = [&](int m) { return __builtin_bit_cast(bf16x8, w[m]); };
-      auto X = [&](int m) { return __builtin_bit_cast(bf16x8, x[m]); };
-      if (NP == 3) {          // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(2), X(0), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(2), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(1), c, 0, 0, 0);
-      }
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(0), c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(1), c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(0), c, 0, 0, 0);
-    };
-
-    // Software pipeline, pinned with sched_barrier (left alone, the compiler sinks every prefetch down to its first use and the
-    // wave then waits out a full L2 round trip per tap): weight fragments are fetched TWO taps ahead into a ring of three
-    // register sets, pixel fragments one 32-pixel tile ahead, and the next chunk's patch is loaded to registers during tap 0.
-    int s = 0, c0 = 0, T0 = 0;
-    uint4 wr[3][NP], xr[2][NP];
-    load_w(0, wr[0]);
-    load_w(1, wr[1]);
-    load_patch(0, 0);
-    __syncthreads();                 // every wave is done with the previous tile's patch (and red[] is initialised)
-    store_patch();
-    __syncthreads();
-    while (true) {
-      int s2 = s, c2 = c0 + C3_BK;
-      if (c2 >= p.src[s].C) { c2 = 0; ++s2; }
-      const bool more = s2 < p.nsrc;
-      read_x(0, 0, xr[0]);
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        load_w(T0 + tap + 2, wr[(tap + 2) % 3]);
-        if (tap == 0 && more) load_patch(s2, c2);
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-          const int nj = (j + 1) % PT, ntap = tap + (j + 1) / PT;
-          const int cur = (tap * PT + j) & 1;                       // the two fragment buffers alternate over the (tap, tile) sequence (PT may be odd: 32-pixel tiles)
-          if (ntap < TAPS) read_x(ntap, nj, xr[cur ^ 1]);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(acc[j], wr[tap % 3], xr[cur]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      T0 += TAPS;
-      if (TAPS % 3) {                // the two sets fetched ahead sit in ring slots TAPS%3 and (TAPS+1)%3: rotate them to 0 and 1
-        uint4 t0[NP], t1[NP];
-#pragma unroll
-        for (int m = 0; m < NP; ++m) { t0[m] = wr[TAPS % 3][m]; t1[m] = wr[(TAPS + 1) % 3][m]; }
-#pragma unroll
-        for (int m = 0; m < NP; ++m) { wr[0][m] = t0[m]; wr[1][m] = t1[m]; }
-      }
-      if (BLK) {
-#pragma unroll
-        for (int j = 0; j < PT; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { acc2[j][e] += acc[j][e]; acc[j][e] = 0.f; }
-      }
-      __syncthreads();
-      if (!more) break;
-      s = s2; c0 = c2;
-      store_patch();
-      __syncthreads();
-    }
-    if (BLK) {
-#pragma unroll
-      for (int j = 0; j < PT; ++j) acc[j] = acc2[j];
-    }
-
-    // ---- epilogue: lane holds pixel (32 j + lane%32), channels n0 + 32 wave + 8 g + 4 (lane/32) + {0..3}, g = 0..3 ----
-    const bool want_red = p.slab != nullptr;
-    float s1[4][4], s2v[4][4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[g][e] = 0.f; s2v[g][e] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-      const int jr = wrow + jrow(j);
-      const int lp = (wcol + jcol(j)) * 32 + lp32;
-      // output pixel: the tile grid's (oh, ow) itself, or (stride-2 data gradient) pixel (om oh + oro, om ow + oco) of the OHo x OWo map
-      const long pp = p.om == 1 ? ((long)n * p.H + oh + jr * d) * p.W + ow0 + lp : ((long)n * p.OHo + oh * p.om + p.oro) * p.OWo + (long)(ow0 + lp) * p.om + p.oco;
-      const bool pin = ow0 + lp < p.W && oh + jr * d < p.H;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = n0 + wave * 32 + 8 * g + 4 * hh;
-        const int nrem = p.Cn - c;
-        if (!pin || nrem <= 0) continue;
-        float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-        if ((par0 + (unsigned)(jr * d + lp32)) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
-        if (MODE == MODE_FWD) {
-          if (p.bias) { float4 b = ld4g(p.bias + c, nrem, false); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-          if (p.bias_n) {
-            float4 b = ld4g(p.bias_n + (long)n * p.Cn + c, nrem, false);
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-          }
-          st4g(p.y + pp * p.ldy + c, v, nrem, p.vecY);
-          if (want_red) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float f = (e < nrem) ? get4(v, e) : 0.f; s1[g][e] += f; s2v[g][e] += f * f; }
-          }
-        } else {
-          float4 x = ld4g(p.dst.x + pp * p.dst.ld + c, nrem, p.vecY);
-          float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = zero4();
-          if (p.dst.a) { av = ld4g(p.dst.a + c, nrem, p.vecY); bv = ld4g(p.dst.b + c, nrem, p.vecY); }
-          float4 gq;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float xe = get4(x, e), ae = get4(av, e), be = get4(bv, e), dz = get4(v, e);
-            const bool m = (e < nrem) && (!p.dst.relu || fmaf(ae, xe, be) > 0.f);
-            set4(gq, e, m ? dz * ae : 0.f);
-            if (want_red && m) { s1[g][e] += dz * xe; s2v[g][e] += dz; }
-          }
-          float* gp = p.y + pp * p.ldy + c;
-          if (p.accumulate) { float4 o = ld4g(gp, nrem, p.vecY); gq.x += o.x; gq.y += o.y; gq.z += o.z; gq.w += o.w; }
-          st4g(gp, gq, nrem, p.vecY);
-        }
-      }
-    }
-    if (want_red) {          // a wave owns its 32 channels alone: butterfly over the 32 pixel lanes, one lane per half adds into red[]
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a = s1[g][e], b = s2v[g][e];
-#pragma unroll
-          for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-          if (lp32 == 0) { double* r = red + ((wpx * BC) + wave * 32 + 8 * g + 4 * hh + e) * 2; r[0] += (double)a; r[1] += (double)b; }
-        }
-    }
-  }
-#ifdef ADDK_C3B_DIAG
-  if (t == 0) {
-    unsigned long long* dslot = g_c3b_diag[(bx + 7 * blockIdx.y) & 63];
-    atomicAdd(&dslot[0], __builtin_amdgcn_s_memtime() - diag_c0); atomicAdd(&dslot[1], __builtin_amdgcn_s_memrealtime() - diag_r0);
-    atomicAdd(&dslot[2], 1ull);
-  }
-#endif
-  if (p.slab) {
-    __syncthreads();
-    if (t < BC && n0 + t < p.Cn) {
-      double* o = p.slab + ((long)bx * p.slab_ld + n0 + t) * 2;
-      o[0] = red[2 * t] + (PH > 1 ? red[2 * (BC + t)] : 0.0); o[1] = red[2 * t + 1] + (PH > 1 ? red[2 * (BC + t) + 1] : 0.0);
-    }
-  }
-}
-
-template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1, int TR = 1>
-__global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
-  conv3b_body<WC, KS, MODE, NP, BIGD, PH, BPX, ST, TR>(p, blockIdx.x, gridDim.x);
-}
-// the four parity classes of the stride-2 data gradient in ONE launch: workgroups [row0[c], row0[c + 1]) run class c
-struct C3K4 { C3K c[4]; int row0[5]; };
-template <int NP>
-__global__ void __launch_bounds__(256, 2) conv3b_s2d_kernel(const C3K4 q) {
-  const int bx = blockIdx.x;
-  if (bx < q.row0[1])      conv3b_body<2, 1,  MODE_DGRAD, NP, false, 2>(q.c[0], bx, q.row0[1]);
-  else if (bx < q.row0[2]) conv3b_body<2, 12, MODE_DGRAD, NP, false, 2>(q.c[1], bx - q.row0[1], q.row0[2] - q.row0[1]);
-  else if (bx < q.row0[3]) conv3b_body<2, 21, MODE_DGRAD, NP, false, 2>(q.c[2], bx - q.row0[2], q.row0[3] - q.row0[2]);
-  else                     conv3b_body<2, 22, MODE_DGRAD, NP, false, 2>(q.c[3], bx - q.row0[3], q.row0[4] - q.row0[3]);
 }
 
 // 32-row tiles (= waves) per block of the split-bf16 kernel: the count in 3..5 that pads the channel count least (ties: the wider)
@@ -865,6 +457,7 @@ bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, 
   }
   if (!c3_enabled() || KH != KW || !(KH == 3 || KH == 5) || stride != 1 || dil < 1 || dil > c3_maxdil(KH)) return false;
   if (!(pad == dil * (KH / 2) && OH == H && OW == W && Cn >= 32)) return false;
+  if (dil <= 2 && H < 2 * dil) return false;      // two-row tiles (the one-row forms of these shapes are not instantiated)
   // the split kernel has half-width (64-pixel) tiles and also takes the 32x64 maps of level 3 (dil_conv at 160 channels: 152 us on
   // the generic kernel); the fp32 halo kernel keeps its 128-pixel tiles and the larger maps
   if (c3_planes(Cn, KH * KW)) return W >= 48 && P >= 2048;
@@ -906,8 +499,7 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
   q.row0[4] = rows;
   const size_t lds = (size_t)((2 * 32 * wc * 16 + 15) & ~15) + (size_t)np * 2 * cb_pwmax(22, false, C3_BP) * 32;
   dim3 grid(rows, cdiv(k.Cn, 32 * wc));
-  if (np == 3) hipLaunchKernelGGL(conv3b_s2d_kernel<3>, grid, dim3(256), lds, st, q);
-  else hipLaunchKernelGGL(conv3b_s2d_kernel<2>, grid, dim3(256), lds, st, q);
+  if (!c3b_run_s2d(&q, np, grid, lds, st)) { addk_set_error("conv3b stride-2 data gradient: no instantiation"); return ADDK_ERR_UNSUPPORTED; }
   return addk_check_launch("conv3b stride-2 data gradient");
 }
 
@@ -931,9 +523,8 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   const bool quarter = half && wc == 3 && !bigd && (ks == 3 || ks == 5) && blocks64 < 192;      // measured: 160 ch @ 32x64 85 -> 63 us (5x5), 45 -> 34 (3x3); 80 ch @ 63x127 (252 blocks) is slower quartered (53 -> 66)
   const int bpx = k.st == 2 ? 64 : quarter ? 32 : half ? 64 : C3_BP;
   // two-row tiles (2 rows, d apart, of half the one-row width) for the 3x3 / 5x5 launches at dilation <= 2: KS + 1 staged rows per two output rows
-  const int tworow_on = addk_env("ADDK_C3B_TWOROW", 2);      // 0: one-row tiles; 1: dilation-1 3x3 only (decoder, stem1); 2: all
-  const bool tr_shape = k.st == 1 && (ks == 3 || ks == 5) && !bigd && k.om == 1 && (bpx == C3_BP || (bpx == 64 && wc == 3)) && k.H >= 2 * k.dil;
-  const bool tworow = tr_shape && (tworow_on >= 2 || (tworow_on == 1 && ks == 3 && k.dil == 1 && (wc == 4 || wc == 2)));
+  // (every 3x3 / 5x5 launch at dilation <= 2 of full width, or of half width on 3-wave blocks, takes them; c3_geometry_ok requires H >= 2 dil)
+  const bool tworow = k.st == 1 && (ks == 3 || ks == 5) && !bigd && k.om == 1 && (bpx == C3_BP || (bpx == 64 && wc == 3)) && k.H >= 2 * k.dil;
   const int rpx = tworow ? bpx / 2 : bpx;                       // pixels per tile row
   k.HT = tworow ? cdiv(k.H, 2 * k.dil) * k.dil : k.H;
   k.spr = cdiv(k.W, rpx);
@@ -945,53 +536,10 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
   const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * (tworow ? ks + 1 : ks) * cb_pwmax(ks, bigd, rpx, k.st) * 32;
   dim3 grid(rows, cdiv(k.Cn, 32 * wc));
-  bool done = false;
-#define ADDK_C3B_(W_, K_, M_, P_, D_, X_) { \
-    constexpr int H_ = W_ == 2 ? 2 : 1; \
-    static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, D_, H_, X_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
-    hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, D_, H_, X_>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
-#define ADDK_C3BX(W_, K_, D_, X_) \
-  if (!done && wc == W_ && ks == K_ && bigd == D_ && bpx == X_) { \
-    if (mode == MODE_FWD) { if (np == 3) ADDK_C3B_(W_, K_, MODE_FWD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_FWD, 2, D_, X_) } \
-    else { if (np == 3) ADDK_C3B_(W_, K_, MODE_DGRAD, 3, D_, X_) else ADDK_C3B_(W_, K_, MODE_DGRAD, 2, D_, X_) } }
-#define ADDK_C3B(W_, K_, D_) ADDK_C3BX(W_, K_, D_, C3_BP)
-  if (tworow) {
-#define ADDK_C3TR(W_, K_, X_, M_, P_) { \
-      constexpr int H_ = W_ == 2 ? 2 : 1; \
-      static bool attr = false; \
-      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3b_kernel<W_, K_, M_, P_, false, H_, X_, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
-      hipLaunchKernelGGL((conv3b_kernel<W_, K_, M_, P_, false, H_, X_, 1, 2>), grid, dim3(64 * W_ * H_), lds, st, k); done = true; }
-#define ADDK_C3TRW(W_, K_, X_) if (!done && wc == W_ && ks == K_ && rpx == X_) { \
-      if (mode == MODE_FWD) { if (np == 3) ADDK_C3TR(W_, K_, X_, MODE_FWD, 3) else ADDK_C3TR(W_, K_, X_, MODE_FWD, 2) } \
-      else { if (np == 3) ADDK_C3TR(W_, K_, X_, MODE_DGRAD, 3) else ADDK_C3TR(W_, K_, X_, MODE_DGRAD, 2) } }
-    ADDK_C3TRW(4, 3, 64) ADDK_C3TRW(2, 3, 64) ADDK_C3TRW(3, 3, 64) ADDK_C3TRW(5, 3, 64)
-    ADDK_C3TRW(2, 5, 64) ADDK_C3TRW(3, 5, 64) ADDK_C3TRW(4, 5, 64) ADDK_C3TRW(5, 5, 64)
-    ADDK_C3TRW(3, 3, 32) ADDK_C3TRW(3, 5, 32)
-#undef ADDK_C3TRW
-#undef ADDK_C3TR
-  } else if (k.st == 2) {               // stem2 forward
-    if (wc == 4 && ks == 3 && mode == MODE_FWD) {
-#define ADDK_C3S2(P_, X_) { \
-      static bool attr = false; \
-      auto fn = &conv3b_kernel<4, 3, MODE_FWD, P_, false, 1, X_, 2>; \
-      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr = true; } \
-      hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k); done = true; }
-      if (bpx == 64) { if (np == 3) ADDK_C3S2(3, 64) else ADDK_C3S2(2, 64) }
-      else { if (np == 3) ADDK_C3S2(3, C3_BP) else ADDK_C3S2(2, C3_BP) }
-#undef ADDK_C3S2
-    }
-  } else {
-  ADDK_C3B(2, 3, false) ADDK_C3B(3, 3, false) ADDK_C3B(4, 3, false) ADDK_C3B(5, 3, false)
-  ADDK_C3B(3, 3, true) ADDK_C3B(4, 3, true) ADDK_C3B(5, 3, true) ADDK_C3B(2, 3, true)
-  ADDK_C3B(2, 5, false) ADDK_C3B(3, 5, false) ADDK_C3B(4, 5, false) ADDK_C3B(5, 5, false)
-  ADDK_C3BX(3, 3, false, 64) ADDK_C3BX(3, 5, false, 64) ADDK_C3BX(4, 3, false, 64) ADDK_C3BX(4, 3, true, 64)
-  ADDK_C3BX(3, 3, false, 32) ADDK_C3BX(3, 5, false, 32)
-  ADDK_C3B(4, 1, false) ADDK_C3B(3, 1, false) ADDK_C3B(5, 1, false) ADDK_C3BX(4, 1, false, 64) ADDK_C3B(2, 1, false)
-  }
-#undef ADDK_C3B
-#undef ADDK_C3BX
-#undef ADDK_C3B_
+  // the instantiations live in conv3b_tr3 / conv3b_tr5 / conv3b_row / conv3b_s2.hip (compiled in parallel)
+  const bool done = tworow ? (ks == 3 ? c3b_run_tr3(&k, wc, rpx, mode, np, grid, lds, st) : c3b_run_tr5(&k, wc, rpx, mode, np, grid, lds, st)) != 0
+                  : k.st == 2 ? (ks == 3 && mode == MODE_FWD && c3b_run_s2f(&k, wc, bpx, np, grid, lds, st) != 0)
+                  : c3b_run_row(&k, wc, ks, bigd, bpx, mode, np, grid, lds, st) != 0;
   if (!done) { addk_set_error("conv3b: no instantiation for %d waves, %d taps", wc, pk.taps); return ADDK_ERR_UNSUPPORTED; }
   return addk_check_launch("conv3b");
 }
@@ -1101,12 +649,10 @@ static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK
 
 #ifdef ADDK_C3B_DIAG
 // (shader ticks, reference ticks, workgroups, 0) summed since the last call; resets the counters
-extern "C" int addk_c3b_diag(unsigned long long* out4) {
-  unsigned long long h[64][4];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c3b_diag), sizeof h) != hipSuccess) return ADDK_ERR_INVALID;
-  for (int k = 0; k < 4; ++k) { out4[k] = 0; for (int i = 0; i < 64; ++i) out4[k] += h[i][k]; }
-  memset(h, 0, sizeof h);
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_c3b_diag), h, sizeof h) == hipSuccess ? ADDK_OK : ADDK_ERR_INVALID;
+extern "C" int addk_c3b_diag(unsigned long long* out12) {
+  for (int k = 0; k < 12; ++k) out12[k] = 0;
+  c3b_diag_tr3(out12); c3b_diag_tr5(out12); c3b_diag_row(out12); c3b_diag_s2(out12);      // every instantiating unit has its own counters
+  return ADDK_OK;
 }
 #endif
 extern "C" int addk_set_split_min_channels(int c) { g_c3b_minc = c < 0 ? 0 : c; return ADDK_OK; }

@@ -5,6 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "addk.h"
 
 static thread_local char g_err[512] = "";
@@ -54,4 +57,31 @@ int addk_env_math(int dflt) {
     else if (!strcmp(e, "tail_x3") || !strcmp(e, "3")) v = 3;
   });
   return v;
+}
+
+// Diagnostic: native stack of a SIGABRT / SIGSEGV on stderr (backtrace_symbols_fd is async-signal-safe enough for a dying process), then the
+// default action.  Python's faulthandler shows the Python frames only; two aborts of earlier rounds left no native frame behind.
+static struct sigaction g_old_abrt, g_old_segv;
+static void addk_abort_handler(int sig) {
+  static const char msg[] = "\n[addk] fatal signal, native stack:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  // hand over to whoever was installed before (Python's faulthandler prints the Python frames and re-raises), else die with the default action
+  const struct sigaction& old = sig == SIGABRT ? g_old_abrt : g_old_segv;
+  sigaction(sig, &old, nullptr);
+  raise(sig);
+}
+extern "C" int addk_debug_trace_fatal_signals(void) {
+  static bool done = false;
+  if (done) return ADDK_OK;
+  struct sigaction sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_handler = addk_abort_handler;
+  sa.sa_flags = SA_NODEFER;
+  sigaction(SIGABRT, &sa, &g_old_abrt);
+  sigaction(SIGSEGV, &sa, &g_old_segv);
+  done = true;
+  return ADDK_OK;
 }

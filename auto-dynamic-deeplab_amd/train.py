@@ -200,6 +200,13 @@ class TrainStep:
                 # this call's step runs eagerly (it also warms RCCL); the capture that follows executes nothing
                 self._run()
                 torch.cuda.synchronize()
+                if self.has_coll:
+                    # ProcessGroupNCCL's watchdog thread polls the events of the eager step's collectives (every 100 ms) until it has seen them
+                    # complete; a query from that thread while this one captures is the one cross-thread HIP call left in the process.  Give
+                    # it time to retire them first.  Inference, not a shown cause: an abort inside the capture of a step with collectives was
+                    # seen in rounds 2 and 5 (once each, not reproducible) — tests/conftest.py now leaves the native stack
+                    import time
+                    time.sleep(0.3)
                 self.graph = self._capture()
                 if self.graph is None:
                     self.use_graph = False

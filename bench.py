@@ -307,31 +307,47 @@ def ddp_path_world1(genotype, a, x, t, dev, steps=10):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
     os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
     dist.init_process_group(backend='nccl', init_method='env://')
-    ts = None
+    ts, out = None, {}
     try:
-        comm = parallel.init_sync_bn(force=True)
-        m = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=True), 0)
-        init_weights(m)
-        m.to(dev)
-        ts = TrainStep(m, tuple(x.shape), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm)
-        ts.load_batch(x, t)
-        for _ in range(3):
-            ts.step()
-        calls0 = comm.calls
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            ts.step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        nall = sum(getattr(c, 'members', 1) for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed'))
-        ncmd = sum(1 for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed', 'grad_allreduce'))
-        return {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'hip_graph': ts.graph is not None,
-                'collectives_per_step': ncmd, 'exchanged_statistics_vectors': nall,
-                'what': 'world_size 1, exchanges forced: SyncBN statistics all-reduces (one per dependency level) + bucketed gradient all-reduce'}
+        # twice on one process group: the statistics exchanges through the small-message mailboxes (csrc/comm.hip, the default when its
+        # start-up self-test against the stock collective passes) and through stock RCCL all_reduce (ADDK_COMM_SMALL=0)
+        for key, small in (('mailbox', '1'), ('rccl', '0')):
+            os.environ['ADDK_COMM_SMALL'] = small
+            comm = parallel.init_sync_bn(force=True)
+            m = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F, sync_bn=True), 0)
+            init_weights(m)
+            m.to(dev)
+            ts = TrainStep(m, tuple(x.shape), lr=0.05, momentum=0.9, weight_decay=4e-5, nesterov=True, sync_comm=comm)
+            ts.load_batch(x, t)
+            for _ in range(3):
+                ts.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ts.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            comm.check()
+            nall = sum(getattr(c, 'members', 1) for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed'))
+            ncmd = sum(1 for c in ts.g.fwd + ts.g.bwd if getattr(c, 'name', '') in ('allreduce', 'allreduce_packed', 'grad_allreduce'))
+            res = {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'hip_graph': ts.graph is not None,
+                   'collectives_per_step': ncmd, 'exchanged_statistics_vectors': nall, 'loss': float(ts.loss.item()),
+                   'statistics_exchange': 'addk_comm_allreduce (mailboxes, %d launches so far)' % comm.small.calls if comm.small is not None else 'torch.distributed all_reduce (RCCL)'}
+            if key == 'mailbox':
+                out = dict(res, what='world_size 1, exchanges forced: SyncBN statistics all-reduces (one per dependency level) + bucketed gradient all-reduce')
+            else:
+                out['stock_all_reduce'] = res
+            ts.close()
+            ts = None
+            del m
+            torch.cuda.synchronize()
+            parallel.disable_sync_bn()
+            torch.cuda.empty_cache()
+        return out
     finally:
         # teardown in dependency order: the captured graph holds RCCL kernel nodes of this communicator and the
         # gradient buckets hold Work handles on it — release those, drain the device, THEN destroy the group
+        os.environ.pop('ADDK_COMM_SMALL', None)
         if ts is not None:
             ts.close()
         ts = None
@@ -545,6 +561,7 @@ def main():
                 'data': 'synthetic',
                 'config': {'workload': 'ADD F=%d searched_arch/%s C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, a.genotype, h, w, n),
                            'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': comm is not None,
+                           'sync_bn_exchange': None if comm is None else ('addk mailboxes (csrc/comm.hip)' if comm.small is not None else 'torch.distributed all_reduce (RCCL)'),
                            'hip_graph': bool(graph), 'math': math}}
         if note:
             line['note'] = note
@@ -552,9 +569,12 @@ def main():
 
     dt, modes, losses = timed_region(ts, a.steps, a.warmup, world, rank, barrier, max_over_ranks, contract_line, json_out, no_graph=a.no_graph)
     loss = float(ts.loss.item())
+    if comm is not None:
+        comm.check()              # a timed-out mailbox exchange raises here (bounded polls: csrc/comm.hip), on every rank
     if rank != 0:
         ts.close()
         torch.cuda.synchronize()
+        parallel.disable_sync_bn()
         torch.distributed.destroy_process_group()
         return
     ms = dt / a.steps * 1e3
@@ -685,6 +705,7 @@ def main():
         if 'ts' in locals():
             ts.close()
         torch.cuda.synchronize()
+        parallel.disable_sync_bn()
         torch.distributed.destroy_process_group()
 
 

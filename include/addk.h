@@ -532,6 +532,27 @@ int addk_nearest_u8(const uint8_t* in, int32_t IH, int32_t IW, uint8_t* out, int
 int addk_finish_sample(const uint8_t* img, const uint8_t* lbl, int32_t IH, int32_t IW, int32_t i0, int32_t j0, int32_t CH, int32_t CW,
                        const float* mean3, const float* std3, float* out_img, int64_t* out_lbl, void* stream);
 
+/* ---- small-message all-reduce of the SyncBN statistics inside one node (csrc/comm.hip) -------------------------------------------------
+ * Replaces, for the (sum, sumsq) / (dmean, dvar) vectors of the BatchNorms of one dependency level, what the reference moves through its
+ * master / slave pipes per BatchNorm call (modeling/sync_batchnorm/batchnorm.py:95-108, comm.py:56-129) and what rounds 2-4 sent through a
+ * stock RCCL all_reduce.  Every rank owns a mailbox in its own HBM (fine-grained allocation, exported as a hipIpc handle, mapped by every
+ * peer); an exchange is ONE single-workgroup launch: push the vector into every mailbox, flag it, poll the own mailbox (bounded: a missing
+ * flag sets an error word and the kernel returns), add the ranks' vectors in rank order (bit-identical on every rank).  Capturable in a
+ * hipGraph (the sequence number lives in device memory).  Every rank issues the same sequence of addk_comm_allreduce calls.
+ *   host flow: addk_comm_alloc -> exchange the 64-byte handles (any out-of-band channel, e.g. the process group) -> addk_comm_open
+ *              -> addk_comm_allreduce ... -> addk_comm_status (error word) -> addk_comm_close.
+ * Error behaviour: negative status + addk_last_error() for invalid arguments / HIP failures; a timed-out exchange is reported by
+ * addk_comm_status (err != 0: bit 63 | sequence number << 8 | rank whose flag never arrived), never by a hang. */
+int64_t addk_comm_mailbox_bytes(int32_t world, int64_t max_bytes);
+int addk_comm_alloc(int32_t world, int64_t max_bytes, void** mailbox, void* handle64);
+int addk_comm_open(int32_t rank, int32_t world, int64_t max_bytes, void* my_mailbox, const void* handles, void** comm_out);
+int addk_comm_allreduce(void* comm, void* buf, int64_t count, int32_t dtype /* 0 fp32, 1 fp64 */, void* stream);
+int addk_comm_status(void* comm, int64_t* seq, int64_t* err);
+int addk_comm_close(void* comm, void* my_mailbox);
+
+/* diagnostic: print the NATIVE stack on SIGABRT / SIGSEGV (stderr), then die as before.  tests/conftest.py and bench.py's child processes call it. */
+int addk_debug_trace_fatal_signals(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ int main(int argc, char** argv) {
     {"dil 5x5 d2 160->160 @32x64", 2, 32, 64, 160, 160, 5, 2},
     {"dil 3x3 d2 160->160 @32x64", 2, 32, 64, 160, 160, 3, 2},
     {"dil 5x5 d2 40->40 @125x253", 2, 125, 253, 40, 40, 5, 2},
+    {"dil 3x3 d2 40->40 @125x253", 2, 125, 253, 40, 40, 3, 2},
     {"glue 1x1 400->80 @63x127", 2, 63, 127, 400, 80, 1, 1},
     {"glue 1x1 800->160 @32x64", 2, 32, 64, 800, 160, 1, 1},
     {"stem2 3x3s2 64->128 @512x1024", 2, 512, 1024, 64, 128, 3, 1, 2},
@@ -103,10 +104,15 @@ int main(int argc, char** argv) {
     ar.wpack_floats = addk_conv_fwd_pack_floats(&ar); if (ar.wpack_floats) hipMalloc(&ar.wpack, ar.wpack_floats * 4);
     dg.wpack_floats = addk_conv_dgrad_pack_floats(&dg); if (dg.wpack_floats) hipMalloc(&dg.wpack, dg.wpack_floats * 4);
     double gf = 2.0 * PO * s.Cout * taps * s.Cin * 1e-9;
+    typedef int (*diag_fn)(unsigned long long*);
+    static diag_fn diag = (diag_fn)dlsym(RTLD_DEFAULT, "addk_c3b_diag");
     for (int mode = 0; mode < 3; ++mode) {
+      if (getenv("NOWGRAD") && mode == 2) break;
       auto run = [&] { return mode == 0 ? addk_conv_fwd(&ar, st) : mode == 1 ? addk_conv_dgrad(&dg, st) : addk_conv_wgrad(&wg, st); };
       if (run() != 0) { printf("%s: error %s\n", s.name, addk_last_error()); return 1; }
       hipStreamSynchronize(st);
+      if (getenv("PACKED")) { ar.wpack_ready = 1; dg.wpack_ready = 1; }      // the weight pack ran in the call above: time the convolution launch alone, as a plan does (hoisted packs)
+      if (diag && mode < 2) { unsigned long long z[12]; diag(z); }             // reset the diagnostic counters after the untimed call
       float ms;
       if (getenv("COLD")) {      // every timed run behind a 1 GiB fill: operands come from HBM, not from L2 / the infinity cache
         static char* junk = nullptr; if (!junk) hipMalloc(&junk, 1L << 30);
@@ -124,12 +130,14 @@ int main(int argc, char** argv) {
       double mb = 4.0 * (P * s.Cin + PO * s.Cout) * 1e-6;
       printf("%-34s %-5s %8.1f us  %6.1f TFLOP/s (%.1f GF)  %6.0f GB/s of min traffic\n", s.name, mode == 0 ? "fwd" : mode == 1 ? "dgrad" : "wgrad", ms * 1e3, gf / ms, gf, mb / ms);
       // diagnostic library (built with -DADDK_C3B_DIAG): the clock inside the split kernel's workgroups
-      typedef int (*diag_fn)(unsigned long long*);
-      static diag_fn diag = (diag_fn)dlsym(RTLD_DEFAULT, "addk_c3b_diag");
-      unsigned long long dv[4];
-      if (diag && mode < 2 && diag(dv) == 0 && dv[1])
-        printf("      in-kernel clock: %.0f MHz (s_memtime / s_memrealtime over %llu workgroups, mean workgroup life %.1f us)\n",
-               100.0 * (double)dv[0] / (double)dv[1], dv[2], (double)dv[1] / (double)dv[2] / 100.0);
+      unsigned long long dv[12];
+      if (diag && mode < 2 && diag(dv) == 0 && dv[1]) {
+        const double life = (double)dv[0];
+        printf("      in-kernel clock: %.0f MHz (s_memtime / s_memrealtime over %llu workgroups, mean workgroup life %.1f us); wave 0's life: first patch %.1f %%, matrix phase %.1f %%, "
+               "barrier behind it %.1f %%, prologue + split + LDS stores %.1f %%, barrier behind them %.1f %%, epilogue %.1f %%\n",
+               100.0 * life / (double)dv[1], dv[2], (double)dv[1] / (double)dv[2] / 100.0, 100.0 * dv[4] / life, 100.0 * dv[5] / life, 100.0 * dv[6] / life, 100.0 * dv[7] / life,
+               100.0 * dv[8] / life, 100.0 * dv[9] / life);
+      }
       // (-DADDK_WG_DIAG): clock and phase split inside wgrad_h3b_kernel
       static diag_fn wdiag = (diag_fn)dlsym(RTLD_DEFAULT, "addk_wg_diag");
       unsigned long long wv[8];

@@ -22,6 +22,20 @@ def pytest_configure(config):
         pass
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _native_stack_on_fatal_signals():
+    """GPU runs: a SIGABRT / SIGSEGV inside the HIP runtime, RCCL or libaddk leaves its NATIVE frames on stderr (faulthandler, which pytest
+    installs, shows Python frames only — two aborts of earlier rounds could not be explained for lack of them: DESIGN.md §7)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import addk
+            addk.load().addk_debug_trace_fatal_signals()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np

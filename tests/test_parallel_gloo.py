@@ -295,3 +295,92 @@ def test_bench_multi_rank_control_flow_world2(mode):
             assert d['ms_per_step_by_mode']['hip_graph'] < d['ms_per_step_by_mode']['eager_list']
         else:
             assert d['config']['hip_graph'] is False and isinstance(d['ms_per_step_by_mode']['hip_graph'], str)
+
+
+# ---- the small-message exchange of the SyncBN statistics (addk.parallel.SmallComm, csrc/comm.hip) on host memory ---------------------------
+def _small_comm_protocol(rank, world):
+    """Handle exchange through the process group, collective agreement, the start-up self-test against dist.all_reduce, then 9 exchanges of
+    both dtypes (odd count: both flag / data sets are reused several times): every result equals the rank-ordered sum bit for bit and is
+    identical on both ranks; the SyncBNComm wrapper routes fitting vectors through the mailboxes and oversized ones through the stock call."""
+    from addk.parallel import SmallComm, SyncBNComm
+    from _host_mailbox import HostMailbox
+    cpu = torch.device('cpu')
+    sc = SmallComm.create(max_bytes=4096, device=cpu, transport=HostMailbox(), ctl_device=cpu)
+    assert sc is not None and sc.t.status() == (4, 0)
+    out = []
+    for i in range(9):
+        dt = torch.float64 if i % 2 == 0 else torch.float32
+        n = 16 + 8 * i
+        mine = [torch.from_numpy(np.random.default_rng(1000 * r + i).standard_normal(n)).to(dt) for r in range(world)]
+        want = mine[0].clone()
+        for r in range(1, world):
+            want = want + mine[r]
+        got = mine[rank].clone()
+        assert sc.fits(got) and sc.allreduce(got, 0) == 0
+        assert torch.equal(got, want), (i, float((got - want).abs().max()))
+        out.append(got.double().sum().item())
+    assert sc.check() == 13
+    comm = SyncBNComm(small=sc)
+    comm.log = []
+    small = torch.full((64,), float(rank + 1), dtype=torch.float64)
+    big = torch.full((4096,), float(rank + 1), dtype=torch.float64)          # 32 KB > max_bytes: stock all_reduce
+    comm._allreduce(small, 0); comm._allreduce(big, 0)
+    tot = float(sum(range(1, world + 1)))
+    assert torch.all(small == tot) and torch.all(big == tot) and sc.calls == 10 and comm.calls == 2
+    comm.close()
+    return out
+
+
+def _small_comm_timeout(rank, world):
+    """Rank 1 never publishes exchange 6 (not even into its own mailbox): every rank's poll is bounded — it returns, the error word names the
+    exchange and the missing rank, check() raises.  Nobody hangs."""
+    from addk.parallel import SmallComm
+    from addk._lib import AddkError
+    from _host_mailbox import HostMailbox
+    cpu = torch.device('cpu')
+    sc = SmallComm.create(max_bytes=1024, device=cpu, transport=HostMailbox(timeout_s=0.5, skip=(6,) if rank == 1 else ()), ctl_device=cpu)
+    assert sc is not None
+    v = torch.ones(8, dtype=torch.float64)
+    sc.allreduce(v, 0)                      # exchange 5: fine
+    assert torch.all(v == world)
+    sc.allreduce(torch.ones(8, dtype=torch.float64), 0)      # exchange 6
+    try:
+        sc.check()
+        res = 'clean'
+    except AddkError as e:
+        res = str(e)
+    dist.barrier()
+    sc.close()
+    return res
+
+
+def _small_comm_refused(rank, world):
+    """One rank cannot allocate its mailbox: EVERY rank gets None (the decision is collective) and the stock collective stays in use."""
+    from addk.parallel import SmallComm, SyncBNComm
+    from _host_mailbox import HostMailbox
+
+    class Broken(HostMailbox):
+        def alloc(self, world, max_bytes):
+            raise RuntimeError('no hipIpc here')
+    cpu = torch.device('cpu')
+    sc = SmallComm.create(max_bytes=1024, device=cpu, transport=Broken() if rank == 1 else HostMailbox(), ctl_device=cpu)
+    comm = SyncBNComm(small=None)
+    comm._small_tried = True
+    v = torch.full((8,), float(rank + 1), dtype=torch.float64)
+    comm._allreduce(v, 0)
+    return sc is None and bool(torch.all(v == 3.0))
+
+
+def test_small_comm_protocol_on_two_ranks():
+    a, b = _spawn(_small_comm_protocol)
+    assert a == b
+
+
+def test_small_comm_timeout_is_bounded_and_reported():
+    a, b = _spawn(_small_comm_timeout)
+    assert 'exchange 6 timed out waiting for rank 1' in a, a
+    assert 'exchange 6 timed out waiting for rank 1' in b, b
+
+
+def test_small_comm_is_all_or_nothing():
+    assert _spawn(_small_comm_refused) == [True, True]
