@@ -100,16 +100,17 @@ __device__ unsigned long long g_c3b_diag[64][12];       // 64 slots: the workgro
 // Reduce-scatter of 16 per-lane values over the 32 pixel lanes of a half-wave (lane bits 4..0): four halving exchanges (xor 16, 8, 4, 2) and a
 // final pair add leave in v[0] of lane l the sum over the 32 lanes of value (l & 31) >> 1 — 15 + 1 cross-lane moves for 16 sums where an
 // all-reduce butterfly per value takes 80.  Fixed order: bit-reproducible.
-__device__ __forceinline__ void rs32(float (&v)[16], const int lp32) {
+template <int N, int M>
+__device__ __forceinline__ void rs32_step(float (&v)[16], const int lp32) {
+  const bool b = (lp32 & M) != 0;
 #pragma unroll
-  for (int n = 8, m = 16; n >= 1; n >>= 1, m >>= 1) {
-    const bool b = (lp32 & m) != 0;
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      const float keep = b ? v[i + n] : v[i], send = b ? v[i] : v[i + n];
-      v[i] = keep + __shfl_xor(send, m);
-    }
+  for (int i = 0; i < N; ++i) {
+    const float keep = b ? v[i + N] : v[i], send = b ? v[i] : v[i + N];
+    v[i] = keep + __shfl_xor(send, M);
   }
+}
+__device__ __forceinline__ void rs32(float (&v)[16], const int lp32) {
+  rs32_step<8, 16>(v, lp32); rs32_step<4, 8>(v, lp32); rs32_step<2, 4>(v, lp32); rs32_step<1, 2>(v, lp32);      // (written as a loop over (N, M) the steps are not unrolled and v[] lands in scratch)
   v[0] += __shfl_xor(v[0], 1);
 }
 

@@ -6,14 +6,17 @@
 #   scripts/c3b_ablation.sh run OUTFILE      (GPU box)
 ROOT=$(cd $(dirname $0)/.. && pwd)
 SRC=$ROOT/auto-dynamic-deeplab_amd/csrc
-VARIANTS="d0: a1:1 a2:2 a4:4 a8:8 a16:16 a15:15 a31:31"
+VARIANTS=${VARIANTS:-"d0: a1:1 a2:2 a4:4 a8:8 a16:16 a15:15 a31:31"}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wno-unused-result -ffp-contract=off"
 if [ "$1" = build ]; then
   (cd $SRC && make -j8 > /dev/null) || exit 1
   for v in $VARIANTS; do
     name=${v%%:*}; mask=${v##*:}; d=$ROOT/build/abl/$name; mkdir -p $d
-    ( /opt/rocm/bin/hipcc $FLAGS -DADDK_C3B_DIAG ${mask:+-DADDK_C3B_ABL=$mask} -c $SRC/conv3.hip -o $d/conv3.o 2> $d/build.log && \
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $SRC/*.o | grep -v /conv3.o) $d/conv3.o -o $d/libaddk.so && rm $d/conv3.o && echo "built $name" ) &
+    ( for u in conv3 conv3b_tr3 conv3b_tr5 conv3b_row conv3b_s2; do
+        /opt/rocm/bin/hipcc $FLAGS -DADDK_C3B_DIAG ${mask:+-DADDK_C3B_ABL=$mask} -c $SRC/$u.hip -o $d/$u.o 2>> $d/build.log || exit 1
+      done
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $SRC/*.o | grep -v "/conv3") $d/conv3*.o -o $d/libaddk.so && rm $d/conv3*.o && echo "built $name" ) &
+    while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 2; done
   done
   wait
   exit 0
