@@ -67,7 +67,10 @@ __global__ void __launch_bounds__(256) comm_allreduce_kernel(const CommK k) {
     const u64 v = buf[i];
     for (int r = 0; r < k.world; ++r) st_sys(reinterpret_cast<u64*>(k.box[r] + comm_data_off(set, k.rank, k.world, k.slot)) + i, v);
   }
-  __threadfence_system();
+  // every access of the protocol is a system-scope (sc0 sc1) access that bypasses the caches, so ordering needs no cache maintenance: the pushed
+  // vector has LEFT this GPU once its stores have been acknowledged (vmcnt 0), and only then the flags follow.  (__threadfence_system() here cost a
+  // write-back AND invalidate of the whole L2 — buffer_wbl2 / buffer_inv — twice per exchange: +3.8 us per exchange, and cold caches for what follows.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t < k.world) st_sys(reinterpret_cast<u64*>(k.box[t] + comm_flag_off(set, k.rank)), seq);
   // 2. wait (bounded) until every rank's flag of this set carries seq: thread r watches rank r, in this rank's own memory
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256) comm_allreduce_kernel(const CommK k) {
     }
     if (!ok) { atomicOr(&bad, 1u); st_sys(&k.dev->err, (1ull << 63) | (seq << 8) | (u64)t); }
   }
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the polls have returned; the slots are read with cache-bypassing loads below
   __syncthreads();
   // 3. rank-ordered sum from the own mailbox (a timed-out exchange still writes something: the host raises on the error word)
   const u64* base = reinterpret_cast<const u64*>(k.box[k.rank] + comm_data_off(set, 0, k.world, k.slot));

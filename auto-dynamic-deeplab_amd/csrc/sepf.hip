@@ -61,6 +61,10 @@ struct SepfGeo {
 // keeps the earliest start / latest end of the launch, so that the in-kernel time can be set against the launch's wall time
 __device__ unsigned long long g_sepf_diag[64][8];
 __device__ unsigned long long g_sepf_span[2] = {~0ull, 0ull};
+// [r5] per LAUNCH of a dependent chain: first / last workgroup start, first / last workgroup end; the launch index is a device
+// counter the last-finishing workgroup advances (launches of the chain never overlap)
+__device__ unsigned long long g_sepf_chain[64][4];
+__device__ unsigned int g_sepf_launch = 0, g_sepf_ticket = 0;
 #define SEPF_STAMP(i) const unsigned long long diag_t##i = __builtin_amdgcn_s_memrealtime()
 #else
 #define SEPF_STAMP(i)
@@ -387,6 +391,11 @@ __device__ __forceinline__ void sepf_body(const SepfK& p, float* sm) {
     atomicAdd(&d[0], diag_t1 - diag_t0); atomicAdd(&d[1], diag_t23 - diag_t1); atomicAdd(&d[2], 0ull);
     atomicAdd(&d[3], diag_t4 - diag_t23); atomicAdd(&d[4], diag_t5 - diag_t4); atomicAdd(&d[5], 1ull);
     atomicMin(&g_sepf_span[0], diag_t0); atomicMax(&g_sepf_span[1], diag_t5);
+    const unsigned id = __hip_atomic_load(&g_sepf_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 63u;
+    atomicMin(&g_sepf_chain[id][0], diag_t0); atomicMax(&g_sepf_chain[id][1], diag_t0);
+    atomicMin(&g_sepf_chain[id][2], diag_t5); atomicMax(&g_sepf_chain[id][3], diag_t5);
+    __threadfence();
+    if (atomicAdd(&g_sepf_ticket, 1u) == (unsigned)p.gx - 1u) { g_sepf_ticket = 0; __threadfence(); atomicAdd(&g_sepf_launch, 1u); }
   }
 #endif
   if (p.slab) {            // butterfly over the 16 pixel lanes (fp64), the four waves through LDS, one slab row per workgroup
@@ -504,6 +513,17 @@ int sepf_dispatch(const SepfCfg& c, bool batch, dim3 grid, hipStream_t st, const
 #ifdef ADDK_SEPF_DIAG
 // out[0..4]: phase ticks (weights, patch loads + LDS stores, barrier, compute, epilogue issue) summed over workgroups, out[5]: workgroups,
 // out[6]: latest end - earliest start of all workgroups since the last call (10 ns ticks); resets
+// the chain record: out[64][4] = (first start, last start, first end, last end) of the launches since the last call, 10 ns ticks; *n = launches; resets
+extern "C" int addk_sepf_chain(unsigned long long* out256, unsigned int* n) {
+  unsigned long long h[64][4]; unsigned int z = 0;
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sepf_chain), sizeof h) != hipSuccess) return ADDK_ERR_INVALID;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_sepf_launch), sizeof z) != hipSuccess) return ADDK_ERR_INVALID;
+  memcpy(out256, h, sizeof h);
+  for (int i = 0; i < 64; ++i) { h[i][0] = ~0ull; h[i][1] = 0; h[i][2] = ~0ull; h[i][3] = 0; }
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sepf_launch), &z, sizeof z);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sepf_ticket), &z, sizeof z);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sepf_chain), h, sizeof h) == hipSuccess ? ADDK_OK : ADDK_ERR_INVALID;
+}
 extern "C" int addk_sepf_diag(unsigned long long* out8) {
   unsigned long long h[64][8], sp[2];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sepf_diag), sizeof h) != hipSuccess) return ADDK_ERR_INVALID;

@@ -80,6 +80,28 @@ def main():
                 line += ' | %d workgroups, in-kernel span %.1f us; mean per workgroup: weights %.2f  patch load+store %.2f  barrier %.2f  compute %.2f  epilogue issue %.2f us (sum %.2f)' % (
                     n, out8[6] * 0.01, ph[0], ph[1], ph[2], ph[3], ph[4], sum(ph))
             print(line, flush=True)
+            chain = getattr(raw, 'addk_sepf_chain', None)
+            if chain is not None:
+                # [r5] the same 20 dependent launches, ONE graph replay, every launch's own clock readings: where the wall time between two
+                # dependent launches goes — boundary (last workgroup end -> next launch's first workgroup start), ramp (first -> last
+                # workgroup START: the dispatcher placing 512 workgroups of 65 KB LDS at two per CU), body, drain (first -> last END)
+                buf = (C.c_ulonglong * 256)()
+                nl = C.c_uint()
+                chain(buf, C.byref(nl))                      # reset
+                g.replay()
+                torch.cuda.synchronize()
+                chain(buf, C.byref(nl))
+                rec = [[buf[4 * i + j] for j in range(4)] for i in range(min(int(nl.value), 20))]
+                if len(rec) >= 3:
+                    gap = [(rec[i + 1][0] - rec[i][3]) * 0.01 for i in range(1, len(rec) - 1)]
+                    ramp = [(r[1] - r[0]) * 0.01 for r in rec[1:]]
+                    drain = [(r[3] - r[2]) * 0.01 for r in rec[1:]]
+                    span = [(r[3] - r[0]) * 0.01 for r in rec[1:]]
+                    first = [(r[2] - r[0]) * 0.01 for r in rec[1:]]
+                    period = [(rec[i + 1][0] - rec[i][0]) * 0.01 for i in range(1, len(rec) - 1)]
+                    med = lambda v: sorted(v)[len(v) // 2]
+                    print('      in the chain (median of %d launches): period %.1f us = span %.1f (ramp: first -> last workgroup start %.1f; first workgroup start -> first end %.1f; '
+                          'drain: first -> last end %.1f) + boundary (last end -> next first start) %.1f us' % (len(period), med(period), med(span), med(ramp), med(first), med(drain), med(gap)), flush=True)
 
 
 if __name__ == '__main__':

@@ -11,5 +11,3 @@ rm -f $D/pkg/csrc/sepf.o
 (cd $D/pkg/csrc && make -j16 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-result -ffp-contract=off -DADDK_SEPF_DIAG" > /dev/null 2>&1)
 cd $GRAFT_REPO_ROOT
 ADDK_LIB=$D/pkg/libaddk.so python3 scripts/sepf_phases.py 2>&1 | grep -v amdgpu.ids
-echo '--- ADDK_SEPF_WT=0: write-back output stores (the default is write-through, sc1)'
-ADDK_SEPF_WT=0 ADDK_LIB=$D/pkg/libaddk.so python3 scripts/sepf_phases.py 2>&1 | grep -v amdgpu.ids
