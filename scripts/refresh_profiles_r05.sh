@@ -1,10 +1,10 @@
 #!/bin/bash
-# Regenerates the round-4 measurement artefacts under gpurun_out/r04/ (copy into profiles/ what is to be judged):
+# Regenerates the round-5 measurement artefacts under gpurun_out/r05/ (copy into profiles/ what is to be judged):
 #   bench lines (default with every extra; fp32; bf16x3; config 5's architecture), rocprofv3 kernel stats of the same command (two
 #   streams and single stream = true durations), SQ counters of EVERY kernel of the step (two --pmc passes, kernel-trace only),
 #   SQ counters + HBM-side traffic of the dominant kernel on the stand-alone harness, the inference forward trace.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04; rm -rf $O; mkdir -p $O
+O=gpurun_out/r05; rm -rf $O; mkdir -p $O
 timeout -k 10 700 python3 bench.py --steps 20 --warmup 3 > $O/bench_bf16x6.json 2> $O/bench_bf16x6.err || { tail -5 $O/bench_bf16x6.err; exit 1; }
 echo "bench default done: $(python3 -c "import json;d=json.load(open('$O/bench_bf16x6.json'));print(d['ms_per_step'], d['value'])")"
 for m in fp32 bf16x3 tail_x3; do
@@ -26,9 +26,9 @@ head -3 $O/step_last_step_summary_2stream.txt
 rm -rf $O/pmc_a $O/pmc_b
 ADDK_STREAMS=1 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_a -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-graph > /dev/null 2>&1
 ADDK_STREAMS=1 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc_b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-graph > /dev/null 2>&1
-python3 - <<'PY' > gpurun_out/r04/pmc_step_sq_summary.txt
+python3 - <<'PY' > gpurun_out/r05/pmc_step_sq_summary.txt
 import csv, glob, collections
-O = 'gpurun_out/r04'
+O = 'gpurun_out/r05'
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for d in ('pmc_a', 'pmc_b'):
     f = glob.glob('%s/%s/*/*counter_collection.csv' % (O, d))
@@ -57,7 +57,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<'PY'
 import csv, glob, json
-O = 'gpurun_out/r04'
+O = 'gpurun_out/r05'
 res = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob('%s/pmc_%s/*/*counter_collection.csv' % (O, c))
@@ -81,7 +81,6 @@ rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 for m in eval train; do
   rm -rf $O/ft; timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/ft -- python3 scripts/fwd_trace.py --mode $m --real > /dev/null 2>&1 && python3 scripts/fwd_trace.py --csv $(ls $O/ft/*/*kernel_trace.csv | head -1) --top 50 > $O/fwd_${m}_kernels_two_streams_batched.txt 2>&1; rm -rf $O/ft
 done
-timeout -k 10 300 bash scripts/sepf_phases.sh > $O/sepf_phases.txt 2>&1
 # inference forward, kernel by kernel
 rm -rf $O/ft; timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/ft -- python3 scripts/fwd_trace.py --mode eval > /dev/null 2>&1 && python3 scripts/fwd_trace.py --csv $(ls $O/ft/*/*kernel_trace.csv | head -1) --top 60 > $O/fwd_eval_kernels.txt 2>&1; rm -rf $O/ft
 head -3 $O/fwd_eval_kernels.txt
