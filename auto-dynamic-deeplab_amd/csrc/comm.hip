@@ -10,8 +10,8 @@
 //   * every rank owns a MAILBOX in its own HBM (fine-grained allocation, exported once as a hipIpc handle and mapped by every peer):
 //       flags[2][W]           one 64-byte line per (set, sending rank)
 //       data [2][W][slot]     the sending rank's vector of exchange set = seq & 1
-//   * exchange seq: a rank WRITES its vector into slot [seq & 1][rank] of EVERY mailbox (posted xGMI writes), fences at system scope, then
-//     writes flags[seq & 1][rank] = seq in every mailbox; it POLLS only its own mailbox (local HBM) until all W flags carry seq, and adds the
+//   * exchange seq: a rank WRITES its vector into slot [seq & 1][rank] of EVERY mailbox (posted xGMI writes), waits for their acknowledgement, then
+//     writes flags[seq & 1][rank] = seq in every PEER's mailbox; it POLLS only its own mailbox (local HBM) until the W - 1 peer flags carry seq, and adds the
 //     W slots in RANK ORDER — every rank adds the same numbers in the same order: results are bit-identical across ranks, as the reference's
 //     master copy makes them.
 //   * two sets suffice: a peer can publish exchange seq + 1 (other set) while this rank still reads seq, but seq + 2 only after its own
@@ -65,19 +65,20 @@ __global__ void __launch_bounds__(256) comm_allreduce_kernel(const CommK k) {
   // 1. push this rank's vector into every mailbox (own included), then the flags
   for (long i = t; i < k.n; i += 256) {
     const u64 v = buf[i];
-    for (int r = 0; r < k.world; ++r) st_sys(reinterpret_cast<u64*>(k.box[r] + comm_data_off(set, k.rank, k.world, k.slot)) + i, v);
+    for (int r = 0; r < k.world; ++r)
+      if (r != k.rank) st_sys(reinterpret_cast<u64*>(k.box[r] + comm_data_off(set, k.rank, k.world, k.slot)) + i, v);      // (the own share is taken from `buf` below)
   }
   // every access of the protocol is a system-scope (sc0 sc1) access that bypasses the caches, so ordering needs no cache maintenance: the pushed
   // vector has LEFT this GPU once its stores have been acknowledged (vmcnt 0), and only then the flags follow.  (__threadfence_system() here cost a
   // write-back AND invalidate of the whole L2 — buffer_wbl2 / buffer_inv — twice per exchange: +3.8 us per exchange, and cold caches for what follows.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (t < k.world) st_sys(reinterpret_cast<u64*>(k.box[t] + comm_flag_off(set, k.rank)), seq);
+  if (t < k.world && t != k.rank) st_sys(reinterpret_cast<u64*>(k.box[t] + comm_flag_off(set, k.rank)), seq);
   // 2. wait (bounded) until every rank's flag of this set carries seq: thread r watches rank r, in this rank's own memory
   __shared__ unsigned int bad;
   if (t == 0) bad = 0;
   __syncthreads();
-  if (t < k.world) {
+  if (t < k.world && t != k.rank) {
     const u64* f = reinterpret_cast<const u64*>(k.box[k.rank] + comm_flag_off(set, t));
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
     bool ok = false;
@@ -94,9 +95,10 @@ __global__ void __launch_bounds__(256) comm_allreduce_kernel(const CommK k) {
   const u64* base = reinterpret_cast<const u64*>(k.box[k.rank] + comm_data_off(set, 0, k.world, k.slot));
   const long stride = k.slot / 8;
   for (long i = t; i < k.n; i += 256) {
-    u64 acc = ld_sys(base + i);
+    const u64 own = buf[i];
+    u64 acc = k.rank == 0 ? own : ld_sys(base + i);
     for (int r = 1; r < k.world; ++r) {
-      const u64 v = ld_sys(base + r * stride + i);
+      const u64 v = r == k.rank ? own : ld_sys(base + r * stride + i);
       if (F64) acc = __builtin_bit_cast(u64, __builtin_bit_cast(double, acc) + __builtin_bit_cast(double, v));
       else {
         const float a0 = __uint_as_float((unsigned)acc) + __uint_as_float((unsigned)v);

@@ -45,22 +45,24 @@ class HostMailbox:
         set_ = seq & 1
         raw = t.numpy().view(np.uint64)
         n = raw.size
+        peers = [r for r in range(self.world) if r != self.rank]          # the own share never leaves the rank (csrc/comm.hip)
         if seq not in self.skip:
-            for r in range(self.world):
+            for r in peers:
                 self.box[r][self._data(set_, self.rank):self._data(set_, self.rank) + n] = raw
-            for r in range(self.world):
+            for r in peers:
                 self.box[r][self._flag(set_, self.rank)] = seq
         t0 = time.monotonic()
-        for r in range(self.world):
+        for r in peers:
             while self.box[self.rank][self._flag(set_, r)] < seq:
                 if time.monotonic() - t0 > self.timeout_s:
                     self.err = (1 << 63) | (seq << 8) | r
                     break
                 time.sleep(0.0005)
         dt = np.float64 if t.dtype == torch.float64 else np.float32
-        acc = self.box[self.rank][self._data(set_, 0):self._data(set_, 0) + n].copy().view(dt)
+        share = lambda r: raw.copy().view(dt) if r == self.rank else self.box[self.rank][self._data(set_, r):self._data(set_, r) + n].copy().view(dt)
+        acc = share(0)
         for r in range(1, self.world):
-            acc = acc + self.box[self.rank][self._data(set_, r):self._data(set_, r) + n].view(dt)
+            acc = acc + share(r)
         t.copy_(torch.from_numpy(acc.copy()))
         self.seq = seq
         return 0

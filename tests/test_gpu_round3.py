@@ -143,8 +143,8 @@ def test_full_size_frozen_bn_gradients_on_sentinel_convs(dev):
     """BASELINE config 2 at 2x1024x2048, BatchNorm frozen (eval mode): see sentinel_gate.  Asserted: error against the reference's fp64 within
     max(4x the fp32 oracle's own, 1e-3) per sentinel in max-abs and rms metrics (measured worst ratios 8-13x on the split-bf16 weight gradients
     of the exit heads, at absolute errors <= 1e-5: they pass by the 1e-3 floor, which is north_star's tolerance), and every element within
-    1e-2 / 1e-3 of the live fp32 oracle."""
-    sentinel_gate(dev, 'full_sentinels', False, 4.0, 1e-3, 1e-2, 2e-3)
+    5e-3 (max-abs) / 3e-3 (rms) of the live fp32 oracle (measured <= 1.4e-3)."""
+    sentinel_gate(dev, 'full_sentinels', False, 4.0, 1e-3, 5e-3, 3e-3)
 
 
 def test_tail_x3_mode_holds_the_full_size_sentinel_gate(dev):

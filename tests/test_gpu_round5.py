@@ -45,7 +45,7 @@ def test_full_size_train_mode_gradients_on_sentinel_convs(dev):
     rounding differences by 10^4..10^5, so no fp32 implementation can be held elementwise to 1e-3 against fp64 here.  Asserted: addk's error
     against fp64 within max(3x the live fp32 oracle's, 1e-3) per sentinel in both metrics, and every element within the spread two fp32
     realisations show against each other."""
-    res = R3.sentinel_gate(dev, 'full_train_sentinels', True, 3.0, 1e-3, 0.5, 0.25, log=_log)
+    res = R3.sentinel_gate(dev, 'full_train_sentinels', True, 3.0, 1e-3, 0.15, 0.10, log=_log)      # every element vs the fp32 oracle: measured max 6.0e-2, rms 5.4e-2 (two fp32 realisations, each 5e-2 from fp64)
     import math
     gm = math.exp(sum(math.log(max(ea, 1e-30) / max(eo, 1e-30)) for ea, eo, _ in res.values()) / len(res))
     _log('config2 2x1024x2048 train-mode sentinel gradients: geometric mean of addk / fp32-oracle error ratios %.2f', gm)
