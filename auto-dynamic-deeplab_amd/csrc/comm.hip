@@ -16,7 +16,7 @@
 //     master copy makes them.
 //   * two sets suffice: a peer can publish exchange seq + 1 (other set) while this rank still reads seq, but seq + 2 only after its own
 //     wait for seq + 1 has seen this rank's flag, which this rank writes after it has finished reading seq.
-//   * polls are BOUNDED by the 100 MHz real-time counter (default 2 s, ADDK_COMM_TIMEOUT_MS): a flag that never arrives sets the error word
+//   * polls are BOUNDED by the 100 MHz real-time counter (default 20 s, ADDK_COMM_TIMEOUT_MS: ranks of a node drift by launch jitter, a one-time code-object load, a host stall — never by that much): a flag that never arrives sets the error word
 //     (sequence number and the missing peer) and the kernel returns; addk_comm_status hands it to the host, which raises.  Never an
 //     unbounded spin (a hung wave can take the node down).
 // Latency over xGMI is UNMEASURED (the builder's box has one GPU): the two-process rehearsal of tests/test_gpu_comm.py runs both ranks on
@@ -78,7 +78,8 @@ __global__ void __launch_bounds__(256) comm_allreduce_kernel(const CommK k) {
   __shared__ unsigned int bad;
   if (t == 0) bad = 0;
   __syncthreads();
-  if (t < k.world && t != k.rank) {
+  const bool dead = ld_sys(&k.dev->err) != 0;      // an earlier exchange timed out: the communicator is broken, later exchanges do not wait again (the host raises)
+  if (t < k.world && t != k.rank && !dead) {
     const u64* f = reinterpret_cast<const u64*>(k.box[k.rank] + comm_flag_off(set, t));
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
     bool ok = false;
@@ -148,7 +149,7 @@ extern "C" int addk_comm_open(int32_t rank, int32_t world, int64_t max_bytes, vo
   ADDK_REQUIRE(addk_comm_mailbox_bytes(world, max_bytes) > 0, "comm_open: max_bytes");
   Comm* c = new Comm();
   c->rank = rank; c->world = world; c->slot = (max_bytes + 63) / 64 * 64;
-  c->timeout_ticks = (unsigned long long)addk_env("ADDK_COMM_TIMEOUT_MS", 2000) * 100000ull;      // 100 MHz ticks
+  c->timeout_ticks = (unsigned long long)addk_env("ADDK_COMM_TIMEOUT_MS", 20000) * 100000ull;      // 100 MHz ticks
   for (int r = 0; r < COMM_MAXW; ++r) c->box[r] = nullptr;
   c->box[rank] = reinterpret_cast<char*>(my_mailbox);
   for (int r = 0; r < world; ++r) {
