@@ -37,7 +37,8 @@ struct PackK {
   int planes;               // 0: fp32 fragments for conv3_kernel; 2 / 3: bf16 planes (h, m[, l]) in 32-row fragment order for conv3b_kernel
   int dil_odd;              // conv3b checkerboard accumulation (see conv3b_kernel): 1 = odd dilation, taps with odd (kh + kw) carry a minus sign;
                             // 2 = stride 2, the taps of kernel column 2 carry it
-  int s2d;                  // conv3b: 1 = the four parity-class packs of the stride-2 data gradient (c3b_pack_s2d_body)
+  int s2d;                  // conv3b: 1 = the four parity-class packs of the stride-2 data gradient (c3b_pack_s2d_body); 2 = the 16-wide-tile kernel's pack (c3n_pack_body)
+  int sbase[C3_MAXCH];      // s2d == 2: first K-step of the chunk (conv3n.hip: two taps x 16 channels per step, four taps x 8 for a chunk of <= 8 channels)
 };
 
 // out[colblk][T = chunk*taps + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
@@ -347,7 +348,46 @@ __device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, lo
   }
 }
 
+// conv3n_kernel (conv3n.hip): out (16-byte units) [K-step T][16-row tile i (3)][plane][lane] = 8 bf16: row co = 16 i + lane % 16; lane group g = lane / 16 holds, in a
+// pair step, channels 8 (g & 1) .. + 7 of tap 2 st + (g >> 1), in a quad step (chunk of <= 8 channels) channels 0..7 of tap 4 st + g; taps beyond the kernel: zeros
+__device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long stride) {
+  const int NP = p.planes;
+  const int ks = p.taps == 9 ? 3 : 5;
+  const int last = p.nchunks - 1;
+  const int steps = p.sbase[last] + (p.cvalid[last] <= 8 ? (p.taps + 3) / 4 : (p.taps + 1) / 2);
+  uint4* out = reinterpret_cast<uint4*>(p.out);
+  for (long idx = first; idx < (long)steps * 3 * 64; idx += stride) {
+    const int lane = (int)(idx & 63);
+    const int r = (int)(idx >> 6);
+    const int i = r % 3, T = r / 3;
+    int chunk = 0;
+    while (chunk < last && p.sbase[chunk + 1] <= T) ++chunk;
+    const int st = T - p.sbase[chunk];
+    const bool quad = p.cvalid[chunk] <= 8;
+    const int g = lane >> 4, row = 16 * i + (lane & 15);
+    const int tap = quad ? 4 * st + g : 2 * st + (g >> 1), kc0 = quad ? 0 : 8 * (g & 1);
+    const bool flip = p.dil_odd == 1 && tap < p.taps && (((tap / ks) + (tap % ks)) & 1) != 0;
+    unsigned b[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      const int kk = kc0 + j;
+      if (row < p.Cn && tap < p.taps && kk < p.cvalid[chunk]) {
+        if (p.mode == MODE_FWD) v = p.w[(long)row * p.ldw + (long)tap * p.cin_total + p.cbase[chunk] + kk];
+        else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
+      }
+      if (flip) v = -v;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
+    }
+    uint4* o = out + ((long)(T * 3 + i) * NP) * 64 + lane;
+    for (int k = 0; k < NP; ++k)
+      o[k * 64] = make_uint4(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16), b[k][4] | (b[k][5] << 16), b[k][6] | (b[k][7] << 16));
+  }
+}
+
 __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride) {
+  if (p.s2d == 2) { c3n_pack_body(p, first, stride); return; }
   if (p.s2d) { c3b_pack_s2d_body(p, first, stride); return; }
   const int BC = 32 * p.bct, NP = p.planes;
   const int nT = p.nchunks * p.taps;
@@ -434,7 +474,18 @@ int c3_bct(int Cn, long P) {
   }
   return best;
 }
-long c3_pack_floats(int Cn, int nchunks, long P, int taps) {
+// [r5] the 16-wide-tile kernel (conv3n.hip) takes the stride-1 3x3 / 5x5 launches at dilation <= 2 with at most 48 output channels (the cells' dilated convs at 40
+// channels, forward and data gradient).  ADDK_C3N=0: those launches stay on conv3b_kernel's 64-channel blocks.
+inline bool c3n_shape(int Cn, int taps, int dil, int stride) {
+  // (the 3x3 stays on conv3b_kernel: 24.8 against 25.4-26.8 us at 2x125x253 — one workgroup per CU leaves its 13 K-steps nothing to hide the staging behind;
+  //  ADDK_C3N=2 routes it here too)
+  const int on = addk_env("ADDK_C3N", 1);
+  return on != 0 && Cn <= 48 && (taps == 25 || (taps == 9 && on == 2)) && dil <= 2 && stride == 1 && c3_planes(Cn, taps) != 0;
+}
+inline int c3n_steps(int taps, int valid) { return valid <= 8 ? (taps + 3) / 4 : (taps + 1) / 2; }
+long c3_pack_floats(int Cn, int nchunks, long P, int taps, int dil = 0, int stride = 1) {
+  if (dil > 0 && c3n_shape(Cn, taps, dil, stride))     // 16-wide tiles: 1 KB per (K-step, 16-row tile, plane); a chunk has at most (taps + 1) / 2 steps
+    return (long)nchunks * ((taps + 1) / 2) * 3 * c3_planes(Cn, taps) * 256;
   if (const int np = c3_planes(Cn, taps)) {            // bf16 planes: 1 KB per (tap, 32-row tile, plane)
     const int wc = c3b_wc(Cn, P);
     return (long)cdiv(Cn, 32 * wc) * nchunks * taps * wc * np * 256;
@@ -493,6 +544,7 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
     c.ntiles = c.N * c.H * c.spr;
     c.red32 = 1;
     if (c.slab) c.slab += (long)row0 * c.slab_ld * 2;
+    c.slab_rows = rc;
     q.row0[cls] = row0;
     row0 += rc;
   }
@@ -503,9 +555,33 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
   return addk_check_launch("conv3b stride-2 data gradient");
 }
 
+// the <= 48-channel launches on 16-wide tiles (conv3n.hip)
+int c3n_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
+  pk.bct = 3; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = k.dil & 1; pk.s2d = 2;
+  int steps = 0;
+  for (int c = 0; c < pk.nchunks; ++c) { pk.sbase[c] = steps; steps += c3n_steps(pk.taps, pk.cvalid[c]); }
+  const int ks = pk.taps == 9 ? 3 : 5;
+  k.nT = steps;
+  k.wp = pk.out;
+  k.wp_blk = 0;
+  k.HT = cdiv(k.H, 2 * k.dil) * k.dil;
+  k.spr = cdiv(k.W, 128);
+  k.ntiles = k.N * k.HT * k.spr;
+  k.red32 = 1;
+  if (desc_out) { *desc_out = pk; return ADDK_OK; }
+  const long total = (long)steps * 3 * 64;
+  int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
+  if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
+  // one workgroup per tile at most: a workgroup without a tile would still queue for a CU's LDS and registers (989 slab rows against 252 tiles at 2x125x253)
+  k.slab_rows = rows;
+  if (!c3n_run(&k, ks, mode, np, dim3(rows < k.ntiles ? rows : k.ntiles, 1), st)) { addk_set_error("conv3n: no instantiation for %d taps", pk.taps); return ADDK_ERR_UNSUPPORTED; }
+  return addk_check_launch("conv3n");
+}
+
 int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
   pk.s2d = 0;
   if (k.st == 2 && mode == MODE_DGRAD) return c3b_s2_dgrad(k, pk, rows, st, packed, desc_out, np);
+  if (k.om == 1 && c3n_shape(k.Cn, pk.taps, k.dil, k.st)) return c3n_launch(k, pk, mode, rows, st, packed, desc_out, np);
   const int wc = c3b_wc(k.Cn, k.P);
   pk.bct = wc; pk.mode = mode; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = k.st == 2 ? 2 : (k.dil & 1);
   k.nT = pk.nchunks * pk.taps;
@@ -535,7 +611,8 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
   if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
   const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * (tworow ? ks + 1 : ks) * cb_pwmax(ks, bigd, rpx, k.st) * 32;
-  dim3 grid(rows, cdiv(k.Cn, 32 * wc));
+  k.slab_rows = rows;
+  dim3 grid(rows < k.ntiles ? rows : k.ntiles, cdiv(k.Cn, 32 * wc));      // no workgroups without a tile (they would queue for LDS and registers just to write zeros)
   // the instantiations live in conv3b_tr3 / conv3b_tr5 / conv3b_row / conv3b_s2.hip (compiled in parallel)
   const bool done = tworow ? (ks == 3 ? c3b_run_tr3(&k, wc, rpx, mode, np, grid, lds, st) : c3b_run_tr5(&k, wc, rpx, mode, np, grid, lds, st)) != 0
                   : k.st == 2 ? (ks == 3 && mode == MODE_FWD && c3b_run_s2f(&k, wc, bpx, np, grid, lds, st) != 0)
@@ -583,7 +660,7 @@ extern "C" int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a) {
   int nch = 0;
   for (int i = 0; i < a->nsrc; ++i) { if (a->src[i].C % 4 || a->src[i].ld % 4) return 0; nch += cdiv(a->src[i].C, C3_BK); }
   if (nch > C3_MAXCH || a->ldy % 4) return 0;
-  return c3_pack_floats(a->Cout, nch, (long)a->N * a->OH * a->OW, a->KH * a->KW);
+  return c3_pack_floats(a->Cout, nch, (long)a->N * a->OH * a->OW, a->KH * a->KW, a->dil, a->stride);
 }
 extern "C" int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a) {
   if (!a) return 0;
@@ -591,7 +668,7 @@ extern "C" int64_t addk_conv_dgrad_pack_floats(const addk_conv_dgrad_args* a) {
   if (a->Cout % 4 || a->lddy % 4 || a->ldg % 4 || a->dst.ld % 4 || a->dst.C % 4) return 0;
   const int nch = cdiv(a->Cout, C3_BK);
   if (nch > C3_MAXCH) return 0;
-  return c3_pack_floats(a->dst.C, nch, (long)a->N * a->H * a->W, a->KH * a->KW);
+  return c3_pack_floats(a->dst.C, nch, (long)a->N * a->H * a->W, a->KH * a->KW, a->dil, a->stride);
 }
 
 // 0 = launched, 1 = not covered (caller falls back to the generic kernel), <0 = error

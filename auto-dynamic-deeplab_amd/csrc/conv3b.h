@@ -26,7 +26,7 @@ struct C3K {
   long wp_blk;              // floats per column block in wp
   int nT;                   // chunks * taps
   const float* bias; const float* bias_n;
-  double* slab; int slab_ld;
+  double* slab; int slab_ld; int slab_rows;      // slab_rows: rows the caller allocated; the launch has min(rows, tiles) workgroups along x and zero-fills the rest
   addk_src dst; int accumulate;
   int vecY, red32;
   long P; int ntiles, spr;
@@ -496,6 +496,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
     if (t < BC && n0 + t < p.Cn) {
       double* o = p.slab + ((long)bx * p.slab_ld + n0 + t) * 2;
       o[0] = red[2 * t] + (PH > 1 ? red[2 * (BC + t)] : 0.0); o[1] = red[2 * t + 1] + (PH > 1 ? red[2 * (BC + t) + 1] : 0.0);
+      for (int r = bx + gx; r < p.slab_rows; r += gx) { double* z = p.slab + ((long)r * p.slab_ld + n0 + t) * 2; z[0] = 0.0; z[1] = 0.0; }      // rows no workgroup owns
     }
   }
 }
@@ -523,6 +524,7 @@ int c3b_run_tr5(const void* k, int wc, int rpx, int mode, int np, dim3 grid, siz
 int c3b_run_row(const void* k, int wc, int ks, bool bigd, int bpx, int mode, int np, dim3 grid, size_t lds, hipStream_t st);
 int c3b_run_s2f(const void* k, int wc, int bpx, int np, dim3 grid, size_t lds, hipStream_t st);
 int c3b_run_s2d(const void* k4, int np, dim3 grid, size_t lds, hipStream_t st);
+int c3n_run(const void* k, int ks, int mode, int np, dim3 grid, hipStream_t st);      // conv3n.hip: the <= 48-channel launches on 16-wide tiles
 #ifdef ADDK_C3B_DIAG
 void c3b_diag_tr3(unsigned long long* acc12); void c3b_diag_tr5(unsigned long long* acc12); void c3b_diag_row(unsigned long long* acc12); void c3b_diag_s2(unsigned long long* acc12);
 #endif
