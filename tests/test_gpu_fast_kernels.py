@@ -29,6 +29,11 @@ SHAPES = [
     ('cell_dil5_80',   2, 63, 127, (80,), 80, 2, 5),       # level 2 (5 column tiles)
     ('cell_dil3_40',   1, 70, 125, (40,), 40, 2, 3),       # dil_conv_3x3
     ('cell_dil3_160',  2, 40, 104, (32,), 160, 2, 3),      # two 5-tile column blocks
+    # [r5] the 16-wide-tile kernel of the <= 48-channel 5x5 (conv3n.hip): two sources whose chunks are 16 + 8 | 16 (pair and quad K-steps), 48 outputs (no padding
+    # row), an odd row count (the second row of the last pair lies beyond the map), a 200-pixel row (second column tile 72 wide)
+    ('n16_two_src',    2, 33, 200, (24, 16), 48, 2, 5),
+    ('n16_k8_d1',      2, 40, 130, (8,), 40, 1, 5),        # a single 8-channel chunk: quad steps only, dilation 1
+    ('n16_c36',        1, 90, 100, (36,), 36, 2, 5),       # 36 outputs: the third 16-row tile is a quarter full
     ('l3_dil5_160',    2, 32,  64, (48,), 160, 2, 5),      # level-3 map: 3-wave column blocks on QUARTER-width (32-pixel) tiles, one accumulator tile per wave
     ('l3_dil3_160',    2, 32,  64, (32,), 160, 2, 3),
     # the wide pointwise heads on the split kernel as a plain GEMM (KS = 1, conv3.hip c3_geometry_ok): ASPP 1x1 400 -> 256 and the
