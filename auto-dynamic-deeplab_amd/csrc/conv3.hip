@@ -521,37 +521,20 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
   const int wc = 2;
   pk.bct = wc; pk.mode = MODE_DGRAD; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = 0; pk.s2d = 1;
   if (desc_out) { *desc_out = pk; return ADDK_OK; }
-  if (rows < 9) return 1;
   const long unit = (long)cdiv(k.Cn, 32 * wc) * pk.nchunks * wc * 64;
   if (!packed) { int pb = cdiv(9 * unit, 256); if (pb > 4096) pb = 4096; hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk); }
-  C3K4 q;
-  int row0 = 0;
-  // share of the workgroups per class: a tile costs (staging + barriers) + taps * MFMA time, not taps alone
-  const int share[4] = {3, 4, 4, 6};      // measured at stem2's shape: 0.481 ms against 0.494 for 1:2:2:4
-  const int shsum = share[0] + share[1] + share[2] + share[3];
-  for (int cls = 0; cls < 4; ++cls) {
-    const int pi = cls >> 1, pj = cls & 1, tc = (1 + pi) * (1 + pj), pre = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
-    const int rc = cls == 3 ? rows - row0 : (rows * share[cls]) / shsum;
-    C3K& c = q.c[cls];
-    c = k;
-    c.H = (k.OHo - pi + 1) / 2; c.W = (k.OWo - pj + 1) / 2;
-    c.om = 2; c.oro = pi; c.oco = pj;
-    c.nT = pk.nchunks * tc;
-    c.wp = pk.out + pre * unit * np * 4;
-    c.wp_blk = (long)pk.nchunks * tc * wc * np * 64;
-    c.spr = cdiv(c.W, C3_BP);
-    c.HT = c.H;
-    c.ntiles = c.N * c.H * c.spr;
-    c.red32 = 1;
-    if (c.slab) c.slab += (long)row0 * c.slab_ld * 2;
-    c.slab_rows = rc;
-    q.row0[cls] = row0;
-    row0 += rc;
-  }
-  q.row0[4] = rows;
-  const size_t lds = (size_t)((2 * 32 * wc * 16 + 15) & ~15) + (size_t)np * 2 * cb_pwmax(22, false, C3_BP) * 32;
-  dim3 grid(rows, cdiv(k.Cn, 32 * wc));
-  if (!c3b_run_s2d(&q, np, grid, lds, st)) { addk_set_error("conv3b stride-2 data gradient: no instantiation"); return ADDK_ERR_UNSUPPORTED; }
+  // one launch: a tile is dy row a x 64 positions b (gradient rows 2a, 2a + 1 x 128 pixels), every workgroup runs all four parity classes from one staged image
+  const int HA = (k.OHo + 1) / 2, WA = (k.OWo + 1) / 2;
+  k.H = k.OHo; k.W = k.OWo;                 // the gradient map (k.IH, k.IW: the dy map)
+  k.HT = HA; k.spr = cdiv(WA, 64);
+  k.ntiles = k.N * HA * k.spr;
+  k.wp = pk.out;
+  k.wp_blk = unit * np;                       // 16-byte units per tap unit of the four class streams (c3b_pack_s2d_body)
+  k.nT = 9 * pk.nchunks;
+  k.red32 = 1;
+  k.slab_rows = rows;
+  dim3 grid(rows < k.ntiles ? rows : k.ntiles, 1);
+  if (!c3b_run_s2d(&k, np, grid, 0, st)) { addk_set_error("conv3b stride-2 data gradient: no instantiation"); return ADDK_ERR_UNSUPPORTED; }
   return addk_check_launch("conv3b stride-2 data gradient");
 }
 

@@ -1,4 +1,4 @@
-// conv3b.h — the split-bf16 halo-patch convolution kernel template (conv3b_body / conv3b_kernel / conv3b_s2d_kernel) shared by the translation units
+// conv3b.h — the split-bf16 halo-patch convolution kernel template (conv3b_body / conv3b_kernel) shared by the translation units
 // that instantiate it: conv3b_tr3.hip (two-row 3x3 tiles), conv3b_tr5.hip (two-row 5x5), conv3b_row.hip (one-row tiles: wide dilations, half / quarter
 // widths, the pointwise GEMM form) and conv3b_s2.hip (stride 2: stem2 forward and data gradient).  One file used to hold all ~140 instantiations and took
 // three minutes to compile; host logic, weight packing and the fp32 halo kernel stay in conv3.hip.  Everything here has internal linkage.
@@ -505,17 +505,6 @@ template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_
 __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
   conv3b_body<WC, KS, MODE, NP, BIGD, PH, BPX, ST, TR>(p, blockIdx.x, gridDim.x);
 }
-// the four parity classes of the stride-2 data gradient in ONE launch: workgroups [row0[c], row0[c + 1]) run class c
-struct C3K4 { C3K c[4]; int row0[5]; };
-template <int NP>
-__global__ void __launch_bounds__(256, 2) conv3b_s2d_kernel(const C3K4 q) {
-  const int bx = blockIdx.x;
-  if (bx < q.row0[1])      conv3b_body<2, 1,  MODE_DGRAD, NP, false, 2>(q.c[0], bx, q.row0[1]);
-  else if (bx < q.row0[2]) conv3b_body<2, 12, MODE_DGRAD, NP, false, 2>(q.c[1], bx - q.row0[1], q.row0[2] - q.row0[1]);
-  else if (bx < q.row0[3]) conv3b_body<2, 21, MODE_DGRAD, NP, false, 2>(q.c[2], bx - q.row0[2], q.row0[3] - q.row0[2]);
-  else                     conv3b_body<2, 22, MODE_DGRAD, NP, false, 2>(q.c[3], bx - q.row0[3], q.row0[4] - q.row0[3]);
-}
-
 }  // namespace
 
 // dispatch entry points of the instantiating translation units: 1 = launched, 0 = no instantiation for this shape
