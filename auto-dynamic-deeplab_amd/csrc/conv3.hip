@@ -39,7 +39,11 @@ struct PackK {
                             // 2 = stride 2, the taps of kernel column 2 carry it
   int s2d;                  // conv3b: 1 = the four parity-class packs of the stride-2 data gradient (c3b_pack_s2d_body); 2 = the 16-wide-tile kernel's pack (c3n_pack_body)
   int sbase[C3_MAXCH];      // s2d == 2: first K-step of the chunk (conv3n.hip: two taps x 16 channels per step, four taps x 8 for a chunk of <= 8 channels)
+  float* amax;              // planes == 2 (split-fp16, conv3b.h): the 128-float trailer of the pack buffer — [0..63] the amax pass's per-workgroup maxima of |w|,
+                            // [64] = 2^-kw for the kernel's epilogue (C3K.wsc), [65] = 2^kw
 };
+constexpr int C3_AMAX_WG = 64;             // workgroups of the amax pass = partial maxima in the trailer
+constexpr int C3_TRAILER = 128;            // floats
 
 // out[colblk][T = chunk*taps + tap][tile i][lane][m]  =  W(row = colblk*BC + i*16 + li, tap, k = 8*(m>>1) + 2*kq + (m&1))
 __device__ __forceinline__ void c3_pack_body(const PackK& p, long first, long stride);
@@ -48,9 +52,38 @@ __global__ void __launch_bounds__(256) c3_pack_kernel(const PackK p) { c3_pack_b
 __global__ void __launch_bounds__(256) c3_pack_batch_kernel(const PackK* __restrict__ descs) {
   c3_pack_body(descs[blockIdx.y], (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
-__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride);
+template <bool AMAX> __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride, float& amax);
+// split-fp16 packs (planes == 2): the pass in front of the pack walks the same elements and leaves the largest |w| each of its C3_AMAX_WG workgroups saw in
+// the trailer (max is order-independent: bit-reproducible); every pack thread folds the 64 partials into the tensor's scale 2^kw itself
+__device__ __forceinline__ void c3_amax_body(const PackK& p) {
+  if (p.planes != 2) return;
+  float m = 0.f;
+  c3b_pack_body<true>(p, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256, m);
+  __shared__ unsigned wm[4];
+  const unsigned b = wave_umax(__float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned r = wm[0];
+    for (int i = 1; i < 4; ++i) r = wm[i] > r ? wm[i] : r;
+    p.amax[blockIdx.x] = __uint_as_float(r);
+  }
+}
+__global__ void __launch_bounds__(256) c3_pack_amax_kernel(const PackK p) { c3_amax_body(p); }
+__global__ void __launch_bounds__(256) c3_pack_amax_batch_kernel(const PackK* __restrict__ descs) { c3_amax_body(descs[blockIdx.y]); }
+// scale of a split-fp16 pack from the amax pass's partials; the first thread of the pack leaves its inverse for the convolution's epilogue
+__device__ __forceinline__ float c3_pack_scale(const PackK& p, long first) {
+  if (p.planes != 2) return 1.f;
+  float m = 0.f;
+  const float4* q = reinterpret_cast<const float4*>(p.amax);
+#pragma unroll
+  for (int i = 0; i < C3_AMAX_WG / 4; ++i) { const float4 v = q[i]; m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w)); }
+  const int kf = f16_scale_field(__float_as_uint(m));
+  if (first == 0) { p.amax[C3_AMAX_WG] = __uint_as_float((unsigned)(254 - kf) << 23); p.amax[C3_AMAX_WG + 1] = __uint_as_float((unsigned)kf << 23); }
+  return __uint_as_float((unsigned)kf << 23);
+}
 __device__ __forceinline__ void c3_pack_body(const PackK& p, long first, long stride) {
-  if (p.planes) { c3b_pack_body(p, first, stride); return; }
+  if (p.planes) { float unused = 0.f; c3b_pack_body<false>(p, first, stride, unused); return; }
   const int BC = 16 * p.bct;
   const int nT = p.nchunks * p.taps;
   const long per_blk = (long)nT * p.bct * 256;
@@ -315,8 +348,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
 // kh = 1 for pi = 0, else {2, 0}[th] (same for columns) — 1, 2, 2, 4 of the nine taps per parity class.  Four packs back to back, class
 // c = 2 pi + pj at (taps of the classes before) * unit, each [colblk][chunk * tc + tap][tile][plane][lane]; tap (th, tw) carries
 // (-1)^(th + tw), its share of the checkerboard sign over the class grid (a, b).
-__device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, long stride) {
+template <bool AMAX>
+__device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, long stride, float& amax) {
   const int BC = 32 * p.bct, NP = p.planes;
+  const float wsc = AMAX ? 1.f : c3_pack_scale(p, first);
   const long unit = (long)((p.Cn + BC - 1) / BC) * p.nchunks * p.bct * 64;          // lanes per tap
   uint4* out = reinterpret_cast<uint4*>(p.out);
   for (long idx = first; idx < 9 * unit; idx += stride) {
@@ -333,16 +368,21 @@ __device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, lo
     const int kh = pi ? (th ? 0 : 2) : 1, kw = pj ? (tw ? 0 : 2) : 1;
     const int row = blk * BC + i * 32 + (lane & 31), k0 = 8 * (lane >> 5);
     unsigned b[3][8];
+    float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = 0.f;
       const int kk = k0 + j;
       if (row < p.Cn && kk < p.cvalid[chunk]) v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(kh * 3 + kw) * p.cin_total + p.w_choff + row];
       if ((th + tw) & 1) v = -v;
+      if (AMAX) { amax = fmaxf(amax, fabsf(v)); continue; }
+      vv[j] = v * wsc;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
     }
+    if (AMAX) continue;
     uint4* o = out + pre * unit * NP + (((long)blk * nT + T) * p.bct + i) * NP * 64 + lane;
+    if (NP == 2) { split8h(vv, o[0], o[64]); continue; }
     for (int k = 0; k < NP; ++k)
       o[k * 64] = make_uint4(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16), b[k][4] | (b[k][5] << 16), b[k][6] | (b[k][7] << 16));
   }
@@ -350,8 +390,10 @@ __device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, lo
 
 // conv3n_kernel (conv3n.hip): out (16-byte units) [K-step T][16-row tile i (3)][plane][lane] = 8 bf16: row co = 16 i + lane % 16; lane group g = lane / 16 holds, in a
 // pair step, channels 8 (g & 1) .. + 7 of tap 2 st + (g >> 1), in a quad step (chunk of <= 8 channels) channels 0..7 of tap 4 st + g; taps beyond the kernel: zeros
-__device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long stride) {
+template <bool AMAX>
+__device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long stride, float& amax) {
   const int NP = p.planes;
+  const float wsc = AMAX ? 1.f : c3_pack_scale(p, first);
   const int ks = p.taps == 9 ? 3 : 5;
   const int last = p.nchunks - 1;
   const int steps = p.sbase[last] + (p.cvalid[last] <= 8 ? (p.taps + 3) / 4 : (p.taps + 1) / 2);
@@ -368,6 +410,7 @@ __device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long s
     const int tap = quad ? 4 * st + g : 2 * st + (g >> 1), kc0 = quad ? 0 : 8 * (g & 1);
     const bool flip = p.dil_odd == 1 && tap < p.taps && (((tap / ks) + (tap % ks)) & 1) != 0;
     unsigned b[3][8];
+    float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = 0.f;
@@ -377,19 +420,25 @@ __device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long s
         else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
       }
       if (flip) v = -v;
+      if (AMAX) { amax = fmaxf(amax, fabsf(v)); continue; }
+      vv[j] = v * wsc;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
     }
+    if (AMAX) continue;
     uint4* o = out + ((long)(T * 3 + i) * NP) * 64 + lane;
+    if (NP == 2) { split8h(vv, o[0], o[64]); continue; }
     for (int k = 0; k < NP; ++k)
       o[k * 64] = make_uint4(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16), b[k][4] | (b[k][5] << 16), b[k][6] | (b[k][7] << 16));
   }
 }
 
-__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride) {
-  if (p.s2d == 2) { c3n_pack_body(p, first, stride); return; }
-  if (p.s2d) { c3b_pack_s2d_body(p, first, stride); return; }
+template <bool AMAX>
+__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride, float& amax) {
+  if (p.s2d == 2) { c3n_pack_body<AMAX>(p, first, stride, amax); return; }
+  if (p.s2d) { c3b_pack_s2d_body<AMAX>(p, first, stride, amax); return; }
   const int BC = 32 * p.bct, NP = p.planes;
+  const float wsc = AMAX ? 1.f : c3_pack_scale(p, first);
   const int nT = p.nchunks * p.taps;
   const long per_blk = (long)nT * p.bct * 64;
   const long total = (long)((p.Cn + BC - 1) / BC) * per_blk;
@@ -405,6 +454,7 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
     const bool flip = p.dil_odd == 1 ? (((tap / ks) + (tap % ks)) & 1) != 0      // (-1)^((kh+kw) d): the tap's share of the checkerboard sign
                     : p.dil_odd == 2 ? (tap % ks) == 2 : false;
     unsigned b[3][8];
+    float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = 0.f;
@@ -414,10 +464,14 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
         else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
       }
       if (flip) v = -v;
+      if (AMAX) { amax = fmaxf(amax, fabsf(v)); continue; }
+      vv[j] = v * wsc;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
     }
+    if (AMAX) continue;
     uint4* o = out + (((long)blk * nT + T) * p.bct + i) * NP * 64 + lane;
+    if (NP == 2) { split8h(vv, o[0], o[64]); continue; }
     for (int k = 0; k < NP; ++k)
       o[k * 64] = make_uint4(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16), b[k][4] | (b[k][5] << 16), b[k][6] | (b[k][7] << 16));
   }
@@ -485,10 +539,10 @@ inline bool c3n_shape(int Cn, int taps, int dil, int stride) {
 inline int c3n_steps(int taps, int valid) { return valid <= 8 ? (taps + 3) / 4 : (taps + 1) / 2; }
 long c3_pack_floats(int Cn, int nchunks, long P, int taps, int dil = 0, int stride = 1) {
   if (dil > 0 && c3n_shape(Cn, taps, dil, stride))     // 16-wide tiles: 1 KB per (K-step, 16-row tile, plane); a chunk has at most (taps + 1) / 2 steps
-    return (long)nchunks * ((taps + 1) / 2) * 3 * c3_planes(Cn, taps) * 256;
-  if (const int np = c3_planes(Cn, taps)) {            // bf16 planes: 1 KB per (tap, 32-row tile, plane)
+    return (long)nchunks * ((taps + 1) / 2) * 3 * c3_planes(Cn, taps) * 256 + (c3_planes(Cn, taps) == 2 ? C3_TRAILER : 0);
+  if (const int np = c3_planes(Cn, taps)) {            // bf16 / fp16 planes: 1 KB per (tap, 32-row tile, plane); split-fp16: + the scale trailer (PackK.amax)
     const int wc = c3b_wc(Cn, P);
-    return (long)cdiv(Cn, 32 * wc) * nchunks * taps * wc * np * 256;
+    return (long)cdiv(Cn, 32 * wc) * nchunks * taps * wc * np * 256 + (np == 2 ? C3_TRAILER : 0);
   }
   const int bct = c3_bct(Cn, P);
   return (long)cdiv(Cn, 16 * bct) * nchunks * taps * bct * 256;
@@ -515,6 +569,12 @@ bool c3_geometry_ok(int KH, int KW, int stride, int pad, int dil, int H, int W, 
   return W >= 100 && P >= 8192;
 }
 
+// the pack of one launch on its own stream position (the plans hoist all packs into one addk_conv_pack_batch): split-fp16 packs run the amax pass first
+void c3_pack_now(const PackK& pk, int pb, hipStream_t st) {
+  if (pk.planes == 2) hipLaunchKernelGGL(c3_pack_amax_kernel, dim3(C3_AMAX_WG), dim3(256), 0, st, pk);
+  hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
+}
+
 // stride-2 data gradient: one launch per parity class of the input pixel (each a stride-1 gather over dy with 1 / 2 / 2 / 4 taps and a
 // strided scatter of its outputs); the statistics-slab rows (= workgroups) are shared out in proportion to the tap counts
 int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK* desc_out, int np) {
@@ -522,7 +582,7 @@ int c3b_s2_dgrad(C3K& k, PackK& pk, int rows, hipStream_t st, bool packed, PackK
   pk.bct = wc; pk.mode = MODE_DGRAD; pk.Cn = k.Cn; pk.planes = np; pk.dil_odd = 0; pk.s2d = 1;
   if (desc_out) { *desc_out = pk; return ADDK_OK; }
   const long unit = (long)cdiv(k.Cn, 32 * wc) * pk.nchunks * wc * 64;
-  if (!packed) { int pb = cdiv(9 * unit, 256); if (pb > 4096) pb = 4096; hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk); }
+  if (!packed) { int pb = cdiv(9 * unit, 256); if (pb > 4096) pb = 4096; c3_pack_now(pk, pb, st); }
   // one launch: a tile is dy row a x 64 positions b (gradient rows 2a, 2a + 1 x 128 pixels), every workgroup runs all four parity classes from one staged image
   const int HA = (k.OHo + 1) / 2, WA = (k.OWo + 1) / 2;
   k.H = k.OHo; k.W = k.OWo;                 // the gradient map (k.IH, k.IW: the dy map)
@@ -554,7 +614,7 @@ int c3n_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   if (desc_out) { *desc_out = pk; return ADDK_OK; }
   const long total = (long)steps * 3 * 64;
   int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
-  if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
+  if (!packed) c3_pack_now(pk, pb, st);
   // one workgroup per tile at most: a workgroup without a tile would still queue for a CU's LDS and registers (989 slab rows against 252 tiles at 2x125x253)
   k.slab_rows = rows;
   if (!c3n_run(&k, ks, mode, np, dim3(rows < k.ntiles ? rows : k.ntiles, 1), st)) { addk_set_error("conv3n: no instantiation for %d taps", pk.taps); return ADDK_ERR_UNSUPPORTED; }
@@ -592,7 +652,7 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   if (desc_out) { *desc_out = pk; return ADDK_OK; }
   const long total = (long)cdiv(k.Cn, 32 * wc) * k.nT * wc * 64;   // pack threads: one per (tile, lane)
   int pb = cdiv(total, 256); if (pb > 4096) pb = 4096;
-  if (!packed) hipLaunchKernelGGL(c3_pack_kernel, dim3(pb), dim3(256), 0, st, pk);
+  if (!packed) c3_pack_now(pk, pb, st);
   const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * (tworow ? ks + 1 : ks) * cb_pwmax(ks, bigd, rpx, k.st) * 32;
   k.slab_rows = rows;
   dim3 grid(rows < k.ntiles ? rows : k.ntiles, cdiv(k.Cn, 32 * wc));      // no workgroups without a tile (they would queue for LDS and registers just to write zeros)
@@ -673,6 +733,7 @@ static int c3_fwd(const addk_conv_args* a, int rows, void* stream, PackK* desc_o
     choff += a->src[i].C;
   }
   pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = 0; pk.out = a->wpack;
+  pk.amax = c3_planes(a->Cout, pk.taps) == 2 ? a->wpack + (need - C3_TRAILER) : nullptr; k.wsc = pk.amax ? pk.amax + C3_AMAX_WG : nullptr;
   k.N = a->N; k.H = a->OH; k.W = a->OW; k.IH = a->H; k.IW = a->W; k.dil = a->dil; k.st = a->stride;
   k.om = 1; k.oro = k.oco = 0; k.OHo = a->OH; k.OWo = a->OW;
   k.Cn = a->Cout; k.ldy = a->ldy; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n;
@@ -697,6 +758,7 @@ static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK
     ++nch;
   }
   pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = a->w_choff; pk.out = a->wpack;
+  pk.amax = c3_planes(a->dst.C, pk.taps) == 2 ? a->wpack + (need - C3_TRAILER) : nullptr; k.wsc = pk.amax ? pk.amax + C3_AMAX_WG : nullptr;
   k.N = a->N; k.H = a->H; k.W = a->W; k.IH = a->OH; k.IW = a->OW; k.dil = a->dil; k.st = a->stride;      // the gather runs over dy (OH x OW)
   k.om = 1; k.oro = k.oco = 0; k.OHo = a->H; k.OWo = a->W;
   k.Cn = a->dst.C; k.ldy = a->ldg; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr;
@@ -736,6 +798,9 @@ extern "C" int addk_conv_dgrad_pack_desc(const addk_conv_dgrad_args* a, void* ho
 }
 extern "C" int addk_conv_pack_batch(const void* dev_descs, int32_t n, void* stream) {
   ADDK_REQUIRE(dev_descs && n > 0, "conv_pack_batch: bad args");
+  const int m = addk_get_conv_precision();
+  if (m == 1 || m == 3)        // modes with split-fp16 launches: their packs take the tensor's scale from the amax pass (descriptors of other packs return at once)
+    hipLaunchKernelGGL(c3_pack_amax_batch_kernel, dim3(C3_AMAX_WG, n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackK*>(dev_descs));
   hipLaunchKernelGGL(c3_pack_batch_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackK*>(dev_descs));
   return addk_check_launch("conv_pack_batch");
 }

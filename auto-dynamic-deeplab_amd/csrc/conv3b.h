@@ -23,6 +23,7 @@ struct C3K {
   int Cn, ldy;
   float* y;
   const float* wp;          // packed weights of this launch
+  const float* wsc;         // NP = 2 (split-fp16): [0] = 2^-kw, the inverse of the scale the pack pass applied to the weights (trailer of the pack buffer)
   long wp_blk;              // floats per column block in wp
   int nT;                   // chunks * taps
   const float* bias; const float* bias_n;
@@ -54,15 +55,66 @@ struct C3K {
 // 32-pixel fragment then touches all 64 banks once per 16-lane group for every tap shift (no padding needed).
 // ======================================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CB_PT = 4;                   // 32-pixel tiles per wave (128 pixels)
 constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP, int st = 1) { return st == 2 ? 2 * bpx + 16 : ks > 10 ? bpx + 4 : ks == 1 ? bpx : ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
 
 __device__ __forceinline__ unsigned bf16_hi(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b << 16); }
-// 4 floats -> 4 bf16 per plane (8 bytes each)
+// ======================================================================================================================
+// [r5] NP = 2 is the SPLIT-FP16 form ("f16x3"): x = h + l with h = fp16(x), l = fp16(x - h) — 2 x 11 significand bits = 22 of fp32's 24 —
+// and a product is the sum of its three largest terms on v_mfma_f32_32x32x16_f16 (l*wh + h*wl + h*wh; dropped: l*wl ~ 2^-22 relative, rms
+// 2^-24).  Half the matrix instructions of the six-term bf16 form at fp32-class accuracy: the split error (rms 3e-9 of sum |a b| at K = 2736)
+// is BELOW the rounding noise of an fp32 accumulation chain (1e-8) and 60x below the three-term bf16 form it replaces (1.9e-7).
+// What fp16 lacks is RANGE (2^-14 .. 2^16), so both operands carry a power-of-two scale, exact in both directions:
+//   * weights: the pack pass scales the tensor by 2^kw so that its largest magnitude lands in [2^14, 2^15) (c3_pack_amax_kernel, PackK.amax);
+//   * activations / gradients: every staged 16-channel chunk of a tile publishes its largest magnitude (after the prologue) and the workgroup keeps a
+//     RUNNING scale 2^k — the scale of the largest chunk seen so far in this tile; when a chunk arrives that would overflow it, the accumulators
+//     are multiplied by the (exact) ratio and the scale drops.  Elements more than 2^17 below the running maximum lose low-part bits gradually
+//     (absolute error <= max * 2^-40): they cannot matter to a sum that contains the maximum.  No tensor-wide pass, no producer-side bookkeeping.
+//   The epilogue multiplies by 2^-k 2^-kw.  Inf / NaN inputs give Inf / NaN outputs as in fp32.
+// ======================================================================================================================
+__device__ __forceinline__ void split4h(const float4 v, uint2 (&pl)[2]) {
+  const f16x2 h01 = {(_Float16)v.x, (_Float16)v.y}, h23 = {(_Float16)v.z, (_Float16)v.w};
+  const f16x2 l01 = {(_Float16)(v.x - (float)h01[0]), (_Float16)(v.y - (float)h01[1])}, l23 = {(_Float16)(v.z - (float)h23[0]), (_Float16)(v.w - (float)h23[1])};
+  pl[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  pl[1] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+// 8 scaled floats -> the two fp16 planes of a packed weight fragment (16 bytes each)
+__device__ __forceinline__ void split8h(const float (&v)[8], uint4& ph, uint4& pl) {
+  uint2 a[2], b[2];
+  split4h(make_float4(v[0], v[1], v[2], v[3]), a); split4h(make_float4(v[4], v[5], v[6], v[7]), b);
+  ph = make_uint4(a[0].x, a[0].y, b[0].x, b[0].y); pl = make_uint4(a[1].x, a[1].y, b[1].x, b[1].y);
+}
+// largest of a non-negative bit pattern (|x| as unsigned: order-preserving) over the 64 lanes, wave-uniform: two quad steps and two row rotations on the DPP
+// path, then the four rows by readlane
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  auto mx = [](unsigned a, int b) { return a > (unsigned)b ? a : (unsigned)b; };
+  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));       // quad_perm [1, 0, 3, 2]
+  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));       // quad_perm [2, 3, 0, 1]
+  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true));      // row_ror:4
+  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true));      // row_ror:8
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ unsigned absbits4(const float4 v) {
+  return __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+// exponent field of the power of two that takes a tensor / chunk of largest magnitude `amax_bits` into [2^14, 2^15): 268 - exponent field, kept in [13, 253]
+// (zero / denormal maxima: 2^126; Inf / NaN: 2^-114) so that the scale and its inverse (field 254 - k) are normal numbers
+__device__ __forceinline__ int f16_scale_field(unsigned amax_bits) {
+  const int want = 268 - (int)(amax_bits >> 23);
+  return want > 253 ? 253 : want;
+}
+
+// 4 floats -> 4 bf16 per plane (8 bytes each); NP = 2: the two fp16 planes
 template <int NP>
 __device__ __forceinline__ void split4(const float4 v, uint2 (&pl)[NP]) {
+  if constexpr (NP == 2) { split4h(v, pl); return; } else {
   float r[4] = {v.x, v.y, v.z, v.w};
   unsigned b[NP][4];
 #pragma unroll
@@ -73,6 +125,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2 (&pl)[NP]) {
   }
 #pragma unroll
   for (int k = 0; k < NP; ++k) pl[k] = make_uint2(b[k][0] | (b[k][1] << 16), b[k][2] | (b[k][3] << 16));
+  }
 }
 
 // PH = 2 (the <= 64-channel launches): the block's waves are also split over the two 64-pixel halves of the tile — wave w owns
@@ -139,6 +192,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   constexpr int PLANE = PR_ * PWP * 2;                             // uint4 units per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* red = reinterpret_cast<double*>(smem);                  // [PH][BC][2] running statistics of this block (per pixel half)
+  unsigned* wmax = reinterpret_cast<unsigned*>(smem);             // NP = 2: [waves] largest staged magnitude of the chunk on its way to LDS (aliases red[], which is written once, behind the last tile's barriers)
   uint4* Pl = reinterpret_cast<uint4*>(smem + ((PH * BC * 16 + 15) & ~15));   // [NP][KS][PWP][2] 16-byte halves
   uint2* Pl2 = reinterpret_cast<uint2*>(Pl);
 
@@ -173,6 +227,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   }
   const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)blockIdx.y * p.wp_blk + (long)wave * NP * 64 + lane);
   const int nT = p.nT;
+  const float winv = NP == 2 ? p.wsc[0] : 1.f;
   unsigned pmask = 0;                         // bit k: parity of (r*d + pj) of this thread's patch slot k (checkerboard sign, below)
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
@@ -222,6 +277,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
     float4 ra[NS];
     float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4();
     bool prelu = false, pch = false;
+    int kf = 0;                                   // NP = 2: exponent field of the tile's running operand scale 2^(kf - 127); 0 = no chunk seen yet
     auto load_patch = [&](int s_, int c0_) {      // branch-free: masked slots read the source base and are zeroed at store time
       const addk_src S = p.src[s_];
       const int c = c0_ + 4 * q;
@@ -239,11 +295,53 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
         ra[k] = ld4(sb + (long)po * S.ld);
       }
     };
-    auto store_patch = [&]() {                    // prologue, zero padding, split into planes
+    // NP = 2 (split-fp16): the prologue runs BEFORE the barrier in front of the staging (prep_patch: ra[] <- prologue, zero padding, sign; the wave's largest
+    // magnitude goes to wmax[]), and after it every thread folds the waves' maxima into the tile's running scale (update_scale) — no extra barrier
+    auto prep_patch = [&]() {
+      unsigned mx = 0;
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         float4 v = ra[k];
-        if (!(ADDK_C3B_ABL & 2)) {
+        v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
+        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const bool ok = pch && ((vmask >> k) & 1u);
+        const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
+        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
+        ra[k] = v;
+        const unsigned b = absbits4(v);
+        mx = b > mx ? b : mx;
+      }
+      mx = wave_umax(mx);
+      if (lane == 0) wmax[wv] = mx;
+    };
+    auto update_scale = [&]() {
+      unsigned m = 0;
+#pragma unroll
+      for (int w = 0; w < WC * PH; ++w) { const unsigned b = wmax[w]; m = b > m ? b : m; }
+      const int want = f16_scale_field(m);
+      if (kf != 0 && want < kf) {                  // (workgroup-uniform) a larger chunk: what was accumulated at the finer scale moves to the new one, exactly
+        const int rf = 127 + want - kf;
+        const float r = rf > 0 ? __uint_as_float((unsigned)rf << 23) : 0.f;
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[j][e] *= r;
+        if (BLK) {
+#pragma unroll
+          for (int j = 0; j < PT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[j][e] *= r;
+        }
+      }
+      if (kf == 0 || want < kf) kf = want;
+    };
+    auto store_patch = [&]() {                    // prologue, zero padding, split into planes
+      const float sc = NP == 2 ? __uint_as_float((unsigned)kf << 23) : 1.f;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        float4 v = ra[k];
+        if (NP == 2) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        else if (!(ADDK_C3B_ABL & 2)) {
         v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
         if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         // zero padding and the checkerboard sign in one factor: 0 outside the image, -1 for input pixels of odd (ih + iw), else +1
@@ -292,6 +390,14 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
     // on the operand of tap (kh, kw); the second factor is uniform per tap and is baked into the packed weights; the epilogue undoes the
     // pixel's sign.  The floor bias then alternates from pixel to pixel and averages out in every window and every sum.
     auto mma = [&](f32x16& c, const uint4* w, const uint4* x) {
+      if constexpr (NP == 2) {          // split-fp16: l*wh + h*wl + h*wh, smallest terms first
+        auto Wh = [&](int m) { return __builtin_bit_cast(f16x8, w[m]); };
+        auto Xh = [&](int m) { return __builtin_bit_cast(f16x8, x[m]); };
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wh(1), Xh(0), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wh(0), Xh(1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wh(0), Xh(0), c, 0, 0, 0);
+        return;
+      }
       auto W = [&](int m) { return __builtin_bit_cast(bf16x8, w[m]); };
       auto X = [&](int m) { return __builtin_bit_cast(bf16x8, x[m]); };
       if (ADDK_C3B_ABL & 16) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(0), c, 0, 0, 0); return; }
@@ -314,7 +420,9 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
     load_w(0, wr[0]);
     load_w(1, wr[1]);
     load_patch(0, 0);
-    __syncthreads();                 // every wave is done with the previous tile's patch (and red[] is initialised)
+    if (NP == 2) prep_patch();
+    __syncthreads();                 // every wave is done with the previous tile's patch
+    if (NP == 2) update_scale();
     store_patch();
     __syncthreads();
     C3B_STAMP(dt_b);
@@ -356,6 +464,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
           for (int e = 0; e < 16; ++e) { acc2[j][e] += acc[j][e]; acc[j][e] = 0.f; }
       }
       C3B_STAMP(dt_1);
+      if (NP == 2 && more) prep_patch();
       __syncthreads();
       C3B_STAMP(dt_2);
 #ifdef ADDK_C3B_DIAG
@@ -363,6 +472,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
 #endif
       if (!more) break;
       s = s2; c0 = c2;
+      if (NP == 2) update_scale();
       store_patch();
       C3B_STAMP(dt_3);
       __syncthreads();
@@ -377,6 +487,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
       for (int j = 0; j < PT; ++j) acc[j] = acc2[j];
     }
 
+    const float inv_run = NP == 2 ? __uint_as_float((unsigned)(254 - kf) << 23) : 1.f;
     // ---- epilogue: lane holds pixel (32 j + lane%32), channels n0 + 32 wave + 8 g + 4 (lane/32) + {0..3}, g = 0..3 ----
     const bool want_red = p.slab != nullptr && !(ADDK_C3B_ABL & 4);
     float s1[4][4], s2v[4][4];
@@ -440,7 +551,11 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
           const int nrem = p.Cn - c;
           if (!pin || nrem <= 0) continue;
           float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-          if ((par0 + (unsigned)(jr * d + lp32)) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
+          const bool odd = ((par0 + (unsigned)(jr * d + lp32)) & 1u) != 0;                                           // undo the checkerboard sign of pixel (oh, ow0 + 32 j + lane%32)
+          if (NP == 2) {                 // ... and the two operand scales (exact powers of two, one after the other: their product may leave the fp32 range where the result does not)
+            const float f = odd ? -inv_run : inv_run;
+            v.x = v.x * f * winv; v.y = v.y * f * winv; v.z = v.z * f * winv; v.w = v.w * f * winv;
+          } else if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
           if (MODE == MODE_FWD) {
             v.x += eav[g].x; v.y += eav[g].y; v.z += eav[g].z; v.w += eav[g].w;
             st4g(p.y + pp * p.ldy + c, v, nrem, p.vecY);

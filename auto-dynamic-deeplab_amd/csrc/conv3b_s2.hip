@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
   constexpr int BPX = 64, PWP = BPX + 16, PLANE = 2 * PWP * 2, NS = (2 * PWP * 4 + 255) / 256, BC = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* red = reinterpret_cast<double*>(smem);                  // [2 position halves][64][2]
+  unsigned* wmax = reinterpret_cast<unsigned*>(smem);             // NP = 2 (split-fp16, conv3b.h): the waves' largest staged magnitudes (aliases red[], written once at the very end)
   uint4* Pl = reinterpret_cast<uint4*>(smem + 2 * BC * 16);
   uint2* Pl2 = reinterpret_cast<uint2*>(Pl);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, ct = wv & 1, bh = wv >> 1, lp32 = lane & 31, hh = lane >> 5;
@@ -57,6 +58,7 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
   const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + (long)ct * NP * 64 + lane;
   const long cls_stride = p.wp_blk;                                // uint4 units per "tap unit" of the class streams (pack: unit * planes)
   const int nch = (p.src[0].C + C3_BK - 1) / C3_BK;
+  const float winv = NP == 2 ? p.wsc[0] : 1.f;
 
   for (int tlin = bx; tlin < p.ntiles; tlin += gx) {
     const int rowid = tlin / p.spr, sx = tlin - rowid * p.spr;
@@ -78,6 +80,7 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
       for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
     float4 ra[NS];
     bool pch = false;
+    int kf = 0;                                   // NP = 2: exponent field of the tile's running operand scale (conv3b.h)
     auto load_patch = [&](int c0_) {
       const addk_src S = p.src[0];                                  // dy: no lazy BatchNorm, no ReLU (the BatchNorm backward has been applied in place)
       const int c = c0_ + 4 * q;
@@ -90,13 +93,47 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
         ra[k] = ld4(sb + (long)po * S.ld);
       }
     };
-    auto store_patch = [&]() {
+    auto signed_slot = [&](int k) {
+      float4 v = ra[k];
+      const bool ok = pch && ((vmask >> k) & 1u);
+      const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
+      v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
+      return v;
+    };
+    auto prep_patch = [&]() {                     // NP = 2: sign / zero padding before the barrier, the wave's largest magnitude to wmax[] (conv3b.h)
+      unsigned mx = 0;
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        float4 v = ra[k];
-        const bool ok = pch && ((vmask >> k) & 1u);
-        const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
-        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
+        const float4 v = signed_slot(k);
+        ra[k] = v;
+        const unsigned b = absbits4(v);
+        mx = b > mx ? b : mx;
+      }
+      mx = wave_umax(mx);
+      if (lane == 0) wmax[wv] = mx;
+    };
+    auto update_scale = [&]() {
+      unsigned m = wmax[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const unsigned b = wmax[w]; m = b > m ? b : m; }
+      const int want = f16_scale_field(m);
+      if (kf != 0 && want < kf) {
+        const int rf = 127 + want - kf;
+        const float r = rf > 0 ? __uint_as_float((unsigned)rf << 23) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[c][e] *= r;
+      }
+      if (kf == 0 || want < kf) kf = want;
+    };
+    auto store_patch = [&]() {
+      const float sc = NP == 2 ? __uint_as_float((unsigned)kf << 23) : 1.f;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        float4 v;
+        if (NP == 2) { v = ra[k]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        else v = signed_slot(k);
         int r, sp; slot_geo(k, r, sp);
         if (r < 2) {
           uint2 pl[NP];
@@ -115,6 +152,14 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
       for (int m = 0; m < NP; ++m) dst[m] = src[m * 64];
     };
     auto mma = [&](f32x16& c, const uint4* w, const uint4* x) {
+      if constexpr (NP == 2) {          // split-fp16: l*wh + h*wl + h*wh
+        auto Wh = [&](int m) { return __builtin_bit_cast(f16x8, w[m]); };
+        auto Xh = [&](int m) { return __builtin_bit_cast(f16x8, x[m]); };
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wh(1), Xh(0), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wh(0), Xh(1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wh(0), Xh(0), c, 0, 0, 0);
+        return;
+      }
       auto W = [&](int m) { return __builtin_bit_cast(bf16x8, w[m]); };
       auto X = [&](int m) { return __builtin_bit_cast(bf16x8, x[m]); };
       if (NP == 3) {
@@ -130,7 +175,9 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
     load_w(0, 0, wr[0]);
     load_w(0, 1, wr[1]);
     load_patch(0);
+    if (NP == 2) prep_patch();
     __syncthreads();
+    if (NP == 2) update_scale();
     store_patch();
     __syncthreads();
     for (int chunk = 0; chunk < nch; ++chunk) {
@@ -153,8 +200,10 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       // (9 pairs: the two sets fetched ahead sit in ring slots 0 and 1 again — no rotation)
+      if (NP == 2 && more) prep_patch();
       __syncthreads();
       if (!more) break;
+      if (NP == 2) update_scale();
       store_patch();
       __syncthreads();
     }
@@ -174,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
     }
     const int b = b0 + 32 * bh + lp32;
     const bool flip = ((par0 + (unsigned)lp32) & 1u) != 0;          // the checkerboard sign of position (a, b) (32 bh is even)
+    const float inv_run = NP == 2 ? __uint_as_float((unsigned)(254 - kf) << 23) : 1.f, fsc = flip ? -inv_run : inv_run;
 #pragma unroll
     for (int c0 = 0; c0 < 4; c0 += 2) {                             // two classes at a time: request everything they read, then compute and store
       float4 xq[2][4], oq[2][4];
@@ -203,7 +253,8 @@ __global__ void __launch_bounds__(256, 2) conv3s_kernel(const C3K p) {
           const int nrem = p.Cn - c;
           if (!pin || nrem <= 0) continue;
           float4 v = make_float4(acc[cl][4 * g], acc[cl][4 * g + 1], acc[cl][4 * g + 2], acc[cl][4 * g + 3]);
-          if (flip) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
+          if (NP == 2) { v.x = v.x * fsc * winv; v.y = v.y * fsc * winv; v.z = v.z * fsc * winv; v.w = v.w * fsc * winv; }      // sign and the two operand scales
+          else if (flip) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
           const float4 x = xq[cc][g];
           float4 gq;
 #pragma unroll

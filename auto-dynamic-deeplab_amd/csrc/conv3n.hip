@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
   constexpr bool BLK = KS == 3;                                    // blocked accumulation, as conv3b's narrow 3x3 (the 5x5 keeps one set there too)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* red = reinterpret_cast<double*>(smem);                  // [4 waves][48][2]
+  unsigned* wmax = reinterpret_cast<unsigned*>(smem);             // NP = 2 (split-fp16, conv3b.h): the waves' largest staged magnitudes (aliases red[], written once at the very end)
   uint4* Pl = reinterpret_cast<uint4*>(smem + 4 * 48 * 16);
   uint2* Pl2 = reinterpret_cast<uint2*>(Pl);
 
@@ -76,6 +77,7 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
     xbp[kw] = xbq[kw] + (g & 1);
   }
   const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + lane;
+  const float winv = NP == 2 ? p.wsc[0] : 1.f;
 
   const int tpx = p.ntiles >> 3;
   const bool swz = (p.ntiles & 7) == 0 && p.ntiles >= 64;
@@ -105,6 +107,7 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
     float4 ra[NS];
     float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = zero4();
     bool prelu = false, pch = false, ptail = false;
+    int kf = 0;                                   // NP = 2: exponent field of the tile's running operand scale (conv3b.h)
     auto load_patch = [&](int s_, int c0_) {      // branch-free: masked slots read the source base and are zeroed at store time
       const addk_src S = p.src[s_];
       const int c = c0_ + 4 * q;
@@ -122,15 +125,51 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
         ra[k] = ld4(sb + (long)po * S.ld);
       }
     };
-    auto store_patch = [&]() {                    // prologue, zero padding, checkerboard sign, split into planes (linear image)
+    auto prologue = [&](int k) {
+      float4 v = ra[k];
+      v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
+      if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const bool ok = pch && ((vmask >> k) & 1u);
+      const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
+      v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
+      return v;
+    };
+    // NP = 2 (split-fp16): prologue before the barrier in front of the staging, the wave's largest magnitude to wmax[]; behind the barrier every thread folds the
+    // four maxima into the tile's running scale (conv3b.h)
+    auto prep_patch = [&]() {
+      unsigned mx = 0;
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        float4 v = ra[k];
-        v.x = fmaf(pa.x, v.x, pb.x); v.y = fmaf(pa.y, v.y, pb.y); v.z = fmaf(pa.z, v.z, pb.z); v.w = fmaf(pa.w, v.w, pb.w);
-        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        const bool ok = pch && ((vmask >> k) & 1u);
-        const float sg = ok ? ((((pmask >> k) ^ par0) & 1u) ? -1.f : 1.f) : 0.f;
-        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;
+        const float4 v = prologue(k);
+        ra[k] = v;
+        const unsigned b = absbits4(v);
+        mx = b > mx ? b : mx;
+      }
+      mx = wave_umax(mx);
+      if (lane == 0) wmax[wave] = mx;
+    };
+    auto update_scale = [&]() {
+      unsigned m = wmax[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const unsigned b = wmax[w]; m = b > m ? b : m; }
+      const int want = f16_scale_field(m);
+      if (kf != 0 && want < kf) {
+        const int rf = 127 + want - kf;
+        const float r = rf > 0 ? __uint_as_float((unsigned)rf << 23) : 0.f;
+#pragma unroll
+        for (int i = 0; i < CN_CT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[i][j] *= r; if (BLK) acc2[i][j] *= r; }
+      }
+      if (kf == 0 || want < kf) kf = want;
+    };
+    auto store_patch = [&]() {                    // prologue, zero padding, checkerboard sign, split into planes (linear image)
+      const float sc = NP == 2 ? __uint_as_float((unsigned)kf << 23) : 1.f;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        float4 v;
+        if (NP == 2) { v = ra[k]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        else v = prologue(k);
         int r, sp; bool live;
         slot_geo(k, r, sp, live);
         if (r < PR_ && !(ptail && q >= 2)) {
@@ -152,6 +191,14 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
         for (int m = 0; m < NP; ++m) dst[i][m] = src[(i * NP + m) * 64];
     };
     auto mma = [&](f32x4& c, const uint4* w, const uint4* x) {
+      if constexpr (NP == 2) {          // split-fp16: l*wh + h*wl + h*wh
+        auto Wh = [&](int m) { return __builtin_bit_cast(f16x8, w[m]); };
+        auto Xh = [&](int m) { return __builtin_bit_cast(f16x8, x[m]); };
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh(1), Xh(0), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh(0), Xh(1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh(0), Xh(0), c, 0, 0, 0);
+        return;
+      }
       auto W = [&](int m) { return __builtin_bit_cast(bf16x8, w[m]); };
       auto X = [&](int m) { return __builtin_bit_cast(bf16x8, x[m]); };
       if (NP == 3) {          // smallest terms first
@@ -186,7 +233,9 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
     int s = 0, c0 = 0, T = 0;
     load_w(0, wr[0]);
     load_patch(0, 0);
+    if (NP == 2) prep_patch();
     __syncthreads();                 // every wave is done with the previous tile's patch
+    if (NP == 2) update_scale();
     store_patch();
     __syncthreads();
     while (true) {
@@ -231,9 +280,11 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       }
+      if (NP == 2 && more) prep_patch();
       __syncthreads();
       if (!more) break;
       s = s2; c0 = c2;
+      if (NP == 2) update_scale();
       store_patch();
       __syncthreads();
     }
@@ -244,6 +295,7 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = acc2[i][j];
     }
 
+    const float inv_run = NP == 2 ? __uint_as_float((unsigned)(254 - kf) << 23) : 1.f;
     // ---- epilogue: lane holds pixel (64 wh + 16 j + l16) of tile row jr, channels 16 i + 4 g + {0..3} ----
     const bool want_red = p.slab != nullptr;
     float s1[CN_CT][4], s2v[CN_CT][4];
@@ -294,7 +346,9 @@ __global__ void __launch_bounds__(256, 1) conv3n_kernel(const C3K p) {
           const int nrem = p.Cn - c;
           if (!pin || nrem <= 0) continue;
           float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          if ((par0 + (unsigned)(jr * d + lp)) & 1u) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }       // undo the checkerboard sign of this pixel
+          const bool odd = ((par0 + (unsigned)(jr * d + lp)) & 1u) != 0;                                             // undo the checkerboard sign of this pixel
+          if (NP == 2) { const float f = odd ? -inv_run : inv_run; v.x = v.x * f * winv; v.y = v.y * f * winv; v.z = v.z * f * winv; v.w = v.w * f * winv; }      // ... and the two operand scales
+          else if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
           if (MODE == MODE_FWD) {
             v.x += eav[i].x; v.y += eav[i].y; v.z += eav[i].z; v.w += eav[i].w;
             st4g(p.y + pp * p.ldy + c, v, nrem, p.vecY);
