@@ -13,12 +13,14 @@ __version__ = '0.1.0'
 
 
 def set_precision(mode):
-    """Arithmetic of the halo-patch convolutions (wide k x k stride-1 convs, forward and data gradient): 'fp32' = exact fp32
-    MFMA; 'bf16x6' = every operand split into three bf16 terms, six product terms on the bf16 matrix pipe with fp32
-    accumulation (as accurate as the fp32 MFMA chain, 2.5x its rate); 'bf16x3' = three terms (fast mode, ~5e-7 rms per
-    dot product).  Process-wide; set it before plans are built (packed-weight buffers are sized per mode)."""
-    _lib.check(load().addk_set_conv_precision({'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'tail_x3': 3}[mode]), 'set_precision')
+    """Arithmetic of the halo-patch convolutions and their weight gradients (the k x k convs and the wide 1x1 heads): 'fp32' = exact fp32
+    MFMA; 'f16x3' (default) = every operand split into two fp16 terms (2 x 11 = 22 significand bits) under an exact power-of-two
+    scale, three product terms on the fp16 matrix pipe with fp32 accumulation — split error below the rounding noise of an fp32
+    accumulation chain; 'bf16x6' = three bf16 terms, six product terms (rounds 2-5's default, same accuracy, twice the matrix
+    instructions); 'tail_x3' = f16x3 in the exit heads, bf16x6 elsewhere.  'bf16x3' is accepted as the old name of mode 1.
+    Process-wide; set it before plans are built (packed-weight buffers are sized per mode)."""
+    _lib.check(load().addk_set_conv_precision({'fp32': 0, 'f16x3': 1, 'bf16x3': 1, 'bf16x6': 2, 'tail_x3': 3}[mode]), 'set_precision')
 
 
 def get_precision():
-    return ('fp32', 'bf16x3', 'bf16x6', 'tail_x3')[load().addk_get_conv_precision()]
+    return ('fp32', 'f16x3', 'bf16x6', 'tail_x3')[load().addk_get_conv_precision()]

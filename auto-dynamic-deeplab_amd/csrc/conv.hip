@@ -473,11 +473,11 @@ int pick_ct(int Cn, long ntiles) {
 }
 int pick_pt(long P) { return P >= 128L * 512 ? 2 : 1; }
 
-// Arithmetic of the wide k x k contractions (the halo-patch kernels of conv3.hip): 0 = exact fp32 MFMA
-// (v_mfma_f32_16x16x4_f32), 2 = split-bf16 with six product terms (fp32-equivalent accuracy at 2.5x the rate), 1 = three
-// terms (fast mode, ~5e-7 rms), 3 = "tail_x3": three terms in the exit heads only (launches with >= 192 output / gradient channels:
-// ASPP and decoder forward, data and weight gradients — nothing downstream amplifies their rounding), six everywhere else.
-// addk_set_conv_precision / ADDK_MATH=fp32|bf16x3|bf16x6|tail_x3.  Every other kernel is fp32.
+// Arithmetic of the wide k x k contractions (the halo-patch kernels of conv3.hip, the split weight gradients of wgrad.hip): 0 = exact fp32 MFMA
+// (v_mfma_f32_16x16x4_f32), 1 = "f16x3" (default): split-fp16, two terms per operand under an exact power-of-two scale, three product terms
+// (conv3b.h), 2 = split-bf16 with six product terms (the same accuracy at twice the matrix instructions), 3 = "tail_x3": f16x3 in the exit heads
+// only (launches with >= 192 output / gradient channels: ASPP and decoder forward, data and weight gradients), bf16x6 everywhere else.
+// addk_set_conv_precision / ADDK_MATH=fp32|f16x3|bf16x6|tail_x3.  Every other kernel is fp32.
 int g_prec = -1;
 int conv_precision() {
   if (g_prec < 0) {
@@ -533,7 +533,7 @@ __global__ void mfma_selftest_kernel(float* out) {
 }  // namespace
 
 extern "C" int addk_set_conv_precision(int mode) {
-  if (mode < 0 || mode > 3) { addk_set_error("conv precision must be 0 (fp32), 1 (bf16x3), 2 (bf16x6) or 3 (tail_x3)"); return ADDK_ERR_INVALID; }
+  if (mode < 0 || mode > 3) { addk_set_error("conv precision must be 0 (fp32), 1 (f16x3), 2 (bf16x6) or 3 (tail_x3)"); return ADDK_ERR_INVALID; }
   g_prec = mode;
   return ADDK_OK;
 }

@@ -55,8 +55,6 @@ struct C3K {
 // 32-pixel fragment then touches all 64 banks once per 16-lane group for every tap shift (no padding needed).
 // ======================================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CB_PT = 4;                   // 32-pixel tiles per wave (128 pixels)
 constexpr int cb_pwmax(int ks, bool bigd, int bpx = C3_BP, int st = 1) { return st == 2 ? 2 * bpx + 16 : ks > 10 ? bpx + 4 : ks == 1 ? bpx : ks == 3 ? (bigd ? bpx + 2 * 18 : bpx + 2 * 2) : bpx + 4 * 2; }
@@ -76,41 +74,6 @@ __device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b <
 //     (absolute error <= max * 2^-40): they cannot matter to a sum that contains the maximum.  No tensor-wide pass, no producer-side bookkeeping.
 //   The epilogue multiplies by 2^-k 2^-kw.  Inf / NaN inputs give Inf / NaN outputs as in fp32.
 // ======================================================================================================================
-__device__ __forceinline__ void split4h(const float4 v, uint2 (&pl)[2]) {
-  const f16x2 h01 = {(_Float16)v.x, (_Float16)v.y}, h23 = {(_Float16)v.z, (_Float16)v.w};
-  const f16x2 l01 = {(_Float16)(v.x - (float)h01[0]), (_Float16)(v.y - (float)h01[1])}, l23 = {(_Float16)(v.z - (float)h23[0]), (_Float16)(v.w - (float)h23[1])};
-  pl[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-  pl[1] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
-}
-// 8 scaled floats -> the two fp16 planes of a packed weight fragment (16 bytes each)
-__device__ __forceinline__ void split8h(const float (&v)[8], uint4& ph, uint4& pl) {
-  uint2 a[2], b[2];
-  split4h(make_float4(v[0], v[1], v[2], v[3]), a); split4h(make_float4(v[4], v[5], v[6], v[7]), b);
-  ph = make_uint4(a[0].x, a[0].y, b[0].x, b[0].y); pl = make_uint4(a[1].x, a[1].y, b[1].x, b[1].y);
-}
-// largest of a non-negative bit pattern (|x| as unsigned: order-preserving) over the 64 lanes, wave-uniform: two quad steps and two row rotations on the DPP
-// path, then the four rows by readlane
-__device__ __forceinline__ unsigned wave_umax(unsigned v) {
-  auto mx = [](unsigned a, int b) { return a > (unsigned)b ? a : (unsigned)b; };
-  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));       // quad_perm [1, 0, 3, 2]
-  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));       // quad_perm [2, 3, 0, 1]
-  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true));      // row_ror:4
-  v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true));      // row_ror:8
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
-}
-__device__ __forceinline__ unsigned absbits4(const float4 v) {
-  return __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-}
-// exponent field of the power of two that takes a tensor / chunk of largest magnitude `amax_bits` into [2^14, 2^15): 268 - exponent field, kept in [13, 253]
-// (zero / denormal maxima: 2^126; Inf / NaN: 2^-114) so that the scale and its inverse (field 254 - k) are normal numbers
-__device__ __forceinline__ int f16_scale_field(unsigned amax_bits) {
-  const int want = 268 - (int)(amax_bits >> 23);
-  return want > 253 ? 253 : want;
-}
-
 // 4 floats -> 4 bf16 per plane (8 bytes each); NP = 2: the two fp16 planes
 template <int NP>
 __device__ __forceinline__ void split4(const float4 v, uint2 (&pl)[NP]) {

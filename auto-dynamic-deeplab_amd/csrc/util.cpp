@@ -44,7 +44,7 @@ int addk_env(const char* name, int dflt) {
   if (n < 64) { seen[n].name = name; seen[n].value = v; ++n; }
   return v;
 }
-// ADDK_MATH is the one switch with names for values: fp32 | bf16x6 | bf16x3 | tail_x3, or the mode number
+// ADDK_MATH is the one switch with names for values: fp32 | f16x3 (old name: bf16x3) | bf16x6 | tail_x3, or the mode number
 int addk_env_math(int dflt) {
   static std::once_flag once; static int v;
   std::call_once(once, [&] {
@@ -52,7 +52,7 @@ int addk_env_math(int dflt) {
     const char* e = getenv("ADDK_MATH");
     if (!e || !*e) return;
     if (!strcmp(e, "fp32") || !strcmp(e, "0")) v = 0;
-    else if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) v = 1;
+    else if (!strcmp(e, "f16x3") || !strcmp(e, "bf16x3") || !strcmp(e, "1")) v = 1;
     else if (!strcmp(e, "bf16x6") || !strcmp(e, "2")) v = 2;
     else if (!strcmp(e, "tail_x3") || !strcmp(e, "3")) v = 3;
   });

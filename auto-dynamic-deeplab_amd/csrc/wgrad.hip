@@ -500,8 +500,32 @@ __device__ __forceinline__ unsigned wg_cvt2(float a, float b) {
   const wg_f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_bf16x2));
 }
+// [r5] NP = 2 is the split-fp16 form (common.h / conv3b.h): both operands of a weight gradient are activations, so BOTH carry a running power-of-two scale
+// per workgroup — the largest magnitude of each staged segment goes through LDS in front of the barrier that ends the matrix phase (wg_publish_max), behind it
+// every thread folds the waves' maxima into the two scales and, when a larger segment arrives, multiplies the accumulators by the exact ratio (wg_rescale).
+// The partial tiles leave the kernel unscaled.
+struct WgScale { int kfy, kfz; };
+__device__ __forceinline__ void wg_publish_max(unsigned* wmx, int nw, int wave, int lane, unsigned my, unsigned mz) {
+  my = wave_umax(my); mz = wave_umax(mz);
+  if (lane == 0) { wmx[wave] = my; wmx[nw + wave] = mz; }
+}
+// returns the factor for the accumulators (1 = unchanged)
+__device__ __forceinline__ float wg_rescale(const unsigned* wmx, int nw, WgScale& sc) {
+  unsigned my = 0, mz = 0;
+  for (int w = 0; w < nw; ++w) { const unsigned a = wmx[w], b = wmx[nw + w]; my = a > my ? a : my; mz = b > mz ? b : mz; }
+  const int wy = f16_scale_field(my), wz = f16_scale_field(mz);
+  int sh = 0;
+  if (sc.kfy == 0) sc.kfy = wy; else if (wy < sc.kfy) { sh += wy - sc.kfy; sc.kfy = wy; }
+  if (sc.kfz == 0) sc.kfz = wz; else if (wz < sc.kfz) { sh += wz - sc.kfz; sc.kfz = wz; }
+  if (sh == 0) return 1.f;
+  const int rf = 127 + sh;
+  return rf > 0 ? __uint_as_float((unsigned)rf << 23) : 0.f;
+}
+__device__ __forceinline__ float wg_pow2(int field) { return __uint_as_float((unsigned)field << 23); }
+__device__ __forceinline__ float4 wg_mul4(float4 v, float s) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; return v; }
 template <int NP>
 __device__ __forceinline__ void wg_split4(const float4 v, uint2 (&pl)[NP]) {
+  if constexpr (NP == 2) { split4h(v, pl); return; }
   float a = v.x, b = v.y, c = v.z, d = v.w;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -550,6 +574,8 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   unsigned char* Yb = wsm;                                        // [NP][YT][64 px][16 co]
   unsigned char* Zb = wsm + NP * YPL;                             // [NP][NG tiles][3 rows][ZWP px][16 ci]
+  unsigned* wmx = reinterpret_cast<unsigned*>(wsm + NP * (YPL + ZPL));      // NP = 2: [2][4 NG] the waves' largest dy / activation magnitudes of the segment being staged
+  WgScale fsc = {0, 0};
 
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
   const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6), wave = wave8 & 3, grp = wave8 >> 2;      // output-channel tiles of this wave; its input-channel tile
@@ -640,8 +666,9 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
   };
   // The split runs BEFORE the barrier that ends the matrix phase, into registers (the SIMD's arbiter serves the older of its two waves first: the wave that
   // leaves the matrix phase early splits under the other one's MFMAs instead of waiting at the barrier), the LDS stores behind it.
-  constexpr bool PRE_Z = !(NT == 2 && (NP == 3 || NG == 1));      // (the two-tile six-term forms have no registers for the patch's planes: only dy is split early,
-  constexpr bool PRE_Y = !(NT == 2 && NP == 3 && NG == 1);      //  and nothing at all in the 256-thread form, whose threads hold eight dy rows)
+  constexpr bool PRE_Z = NP != 2 && !(NT == 2 && (NP == 3 || NG == 1));      // (the two-tile six-term forms have no registers for the patch's planes: only dy is split early,
+  constexpr bool PRE_Y = NP != 2 && !(NT == 2 && NP == 3 && NG == 1);      //  and nothing at all in the 256-thread form, whose threads hold eight dy rows)
+  // (NP = 2, split-fp16: the conversion needs the segment's scale, which exists behind that barrier only — prep2 in front of it, rescale2 + write_step behind)
   uint2 py[NYJ][NP], pz[6][NP];
   auto split_z = [&]() {
     const bool c0ok = __builtin_amdgcn_inverse_ballot_w64(zcm0), c1ok = __builtin_amdgcn_inverse_ballot_w64(zcm1);
@@ -665,7 +692,41 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
       }
     }
   };
+  auto prep2 = [&]() {                                              // NP = 2: masks and prologue in place, the wave's maxima to LDS
+    unsigned my = 0, mz = 0;
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      if (st_skip && yrow0 + k * YRS < st_skip) ry[k] = zero4();
+      const unsigned b = absbits4(ry[k]); my = b > my ? b : my;
+    }
+    const bool c0ok = __builtin_amdgcn_inverse_ballot_w64(zcm0), c1ok = __builtin_amdgcn_inverse_ballot_w64(zcm1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool rok = (zrows >> r) & 1u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 v = rz[2 * r + h];
+        if (zaff) { v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w); }
+        if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const bool ok = rok && (h ? c1ok : c0ok) && (h == 0 || zhalf1);
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        rz[2 * r + h] = v;
+        const unsigned b = absbits4(v); mz = b > mz ? b : mz;
+      }
+    }
+    wg_publish_max(wmx, 4 * NG, wave8, lane, my, mz);
+  };
+  auto rescale2 = [&]() {
+    const float r = wg_rescale(wmx, 4 * NG, fsc);
+    if (r != 1.f) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[i][j] *= r;
+    }
+  };
   auto split_step = [&]() {
+    if (NP == 2) { prep2(); return; }
 #ifdef ADDK_WG_DIAG2
     WG_STAMP(sa);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -687,6 +748,27 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
     if (PRE_Z) split_z();
   };
   auto write_step = [&]() {
+    if (NP == 2) {
+      const float sy = wg_pow2(fsc.kfy), sz = wg_pow2(fsc.kfz);
+#pragma unroll
+      for (int k = 0; k < NYJ; ++k) {
+        wg_split4<NP>(wg_mul4(ry[k], sy), py[0]);
+        unsigned char* o = Yb + ((k & 1) ? ysw1 : ysw0) + k * (YRS << 5);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * YPL) = py[0][m];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && !zhalf1) continue;
+          wg_split4<NP>(wg_mul4(rz[2 * r + h], sz), pz[0]);
+          unsigned char* o = Zb + zsw + r * ZROW + h * (H3_KP * 32);
+#pragma unroll
+          for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * ZPL) = pz[0][m];
+        }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NYJ; ++k) {
       if (!PRE_Y) wg_split4<NP>(ry[k], py[k]);
@@ -721,9 +803,12 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
   // one tap: the product terms smallest first, the NT accumulator chains interleaved term by term
   auto mma = [&](f32x4 (&c)[NT][9], int tap, const wg_bf16x8 (&y)[NT][NP], const wg_bf16x8* z) {
 #define WG_TERM(YI, ZI) _Pragma("unroll") for (int i = 0; i < NT; ++i) c[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i][YI], z[ZI], c[i][tap], 0, 0, 0);
+#define WG_TERMH(YI, ZI) _Pragma("unroll") for (int i = 0; i < NT; ++i) c[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, y[i][YI]), __builtin_bit_cast(f16x8, z[ZI]), c[i][tap], 0, 0, 0);
+    if constexpr (NP == 2) { WG_TERMH(1, 0) WG_TERMH(0, 1) WG_TERMH(0, 0) } else {
     if (NP == 3) { WG_TERM(2, 0) WG_TERM(0, 2) WG_TERM(1, 1) }
-    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0)
+    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0) }
 #undef WG_TERM
+#undef WG_TERMH
   };
 
 #ifdef ADDK_WG_DIAG
@@ -736,6 +821,7 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_item(i);
     split_step();
+    if (NP == 2) { __syncthreads(); rescale2(); }
     write_step();
     __syncthreads();
     for (int seg = sbeg; seg < send; ++seg) {
@@ -774,7 +860,7 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt4);
 #endif
-      if (more) { write_step(); __syncthreads(); }
+      if (more) { if (NP == 2) rescale2(); write_step(); __syncthreads(); }
 #ifdef ADDK_WG_DIAG
       WG_STAMP(dt5);
       dph[0] += dt1 - dt0; dph[1] += dt2 - dt1; dph[2] += dt3 - dt2; dph[3] += dt4 - dt3; dph[4] += dt5 - dt4;
@@ -794,6 +880,13 @@ __global__ void __launch_bounds__(256 * NG, 2) wgrad_h3b_kernel(const WgK pv, co
   const int C = p.src.C;
   gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * 9 * C;
   const int c = c0 + 16 * grp + li;
+  if (NP == 2) {                       // the two operand scales leave the partial tile (exact; one after the other)
+    const float iy = wg_pow2(254 - fsc.kfy), iz = wg_pow2(254 - fsc.kfz);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[i][j] = acc[i][j] * iy * iz;
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -826,6 +919,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_h1b_kernel(const WgK pv, const W
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   unsigned char* Yb = wsm;                                           // [NP][YT][64 px][16 co]
   unsigned char* Zb = wsm + NP * YPL;                                // [NP][TP][64 px][16 ci]
+  unsigned* wmx = reinterpret_cast<unsigned*>(wsm + NP * (YPL + ZPL));      // NP = 2: [2][4] the waves' largest magnitudes of the segment being staged (wgrad_h3b_kernel)
+  WgScale fsc = {0, 0};
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
@@ -880,26 +975,51 @@ __global__ void __launch_bounds__(256, 2) wgrad_h1b_kernel(const WgK pv, const W
     if (i < NYJ) ry[i] = ld4so(yseg + i * ystep, yoff);
     else if (i < NIT) rz[i - NYJ] = ld4so(zseg, zoffk[i - NYJ]);
   };
+  auto zpro = [&](int k) {
+    float4 v = rz[k];
+    if (zaff) { v.x = fmaf(za[k].x, v.x, zb[k].x); v.y = fmaf(za[k].y, v.y, zb[k].y); v.z = fmaf(za[k].z, v.z, zb[k].z); v.w = fmaf(za[k].w, v.w, zb[k].w); }
+    if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    const bool ok = (zvalid >> k) & 1u;
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+  };
+  auto prep2 = [&]() {                                               // NP = 2: masks and prologue in place, the wave's maxima to LDS (in front of the barrier)
+    unsigned my = 0, mz = 0;
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) {
+      if (st_skip && yrow0 + k * YRS < st_skip) ry[k] = zero4();
+      const unsigned b = absbits4(ry[k]); my = b > my ? b : my;
+    }
+#pragma unroll
+    for (int k = 0; k < TP; ++k) { rz[k] = zpro(k); const unsigned b = absbits4(rz[k]); mz = b > mz ? b : mz; }
+    wg_publish_max(wmx, 4, wave, lane, my, mz);
+  };
+  auto rescale2 = [&]() {
+    const float r = wg_rescale(wmx, 4, fsc);
+    if (r != 1.f) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] *= r;
+    }
+  };
   auto store_step = [&]() {
-    if (st_skip) {
+    const float sy = NP == 2 ? wg_pow2(fsc.kfy) : 1.f, sz = NP == 2 ? wg_pow2(fsc.kfz) : 1.f;
+    if (NP != 2 && st_skip) {
 #pragma unroll
       for (int k = 0; k < NYJ; ++k) if (yrow0 + k * YRS < st_skip) ry[k] = zero4();
     }
 #pragma unroll
     for (int k = 0; k < NYJ; ++k) {
       uint2 pl[NP];
-      wg_split4<NP>(ry[k], pl);
+      wg_split4<NP>(NP == 2 ? wg_mul4(ry[k], sy) : ry[k], pl);
       unsigned char* o = Yb + ((k & 1) ? ysw1 : ysw0) + k * (YRS << 5);
 #pragma unroll
       for (int m = 0; m < NP; ++m) *reinterpret_cast<uint2*>(o + m * YPL) = pl[m];
     }
 #pragma unroll
     for (int k = 0; k < TP; ++k) {
-      float4 v = rz[k];
-      if (zaff) { v.x = fmaf(za[k].x, v.x, zb[k].x); v.y = fmaf(za[k].y, v.y, zb[k].y); v.z = fmaf(za[k].z, v.z, zb[k].z); v.w = fmaf(za[k].w, v.w, zb[k].w); }
-      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const bool ok = (zvalid >> k) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      const float4 v = NP == 2 ? wg_mul4(rz[k], sz) : zpro(k);
       uint2 pl[NP];
       wg_split4<NP>(v, pl);
       unsigned char* o = Zb + k * YIMG + zsw;
@@ -919,14 +1039,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_h1b_kernel(const WgK pv, const W
   };
   auto mma = [&](f32x4 (&c)[NT][TP], int j, const wg_bf16x8 (&y)[NT][NP], const wg_bf16x8* z) {
 #define WG_TERM(YI, ZI) _Pragma("unroll") for (int i = 0; i < NT; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i][YI], z[ZI], c[i][j], 0, 0, 0);
+#define WG_TERMH(YI, ZI) _Pragma("unroll") for (int i = 0; i < NT; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, y[i][YI]), __builtin_bit_cast(f16x8, z[ZI]), c[i][j], 0, 0, 0);
+    if constexpr (NP == 2) { WG_TERMH(1, 0) WG_TERMH(0, 1) WG_TERMH(0, 0) } else {
     if (NP == 3) { WG_TERM(2, 0) WG_TERM(0, 2) WG_TERM(1, 1) }
-    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0)
+    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0) }
 #undef WG_TERM
+#undef WG_TERMH
   };
   if (sbeg < send) {
     load_prep(true);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_item(i);
+    if (NP == 2) { prep2(); __syncthreads(); rescale2(); }
     store_step();
     __syncthreads();
     for (int seg = sbeg; seg < send; ++seg) {
@@ -948,12 +1072,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_h1b_kernel(const WgK pv, const W
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (NP == 2 && more) prep2();
       __syncthreads();
-      if (more) { store_step(); __syncthreads(); }
+      if (more) { if (NP == 2) rescale2(); store_step(); __syncthreads(); }
     }
   }
   const int C = p.src.C;
   gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * C;
+  if (NP == 2) {
+    const float iy = wg_pow2(254 - fsc.kfy), iz = wg_pow2(254 - fsc.kfz);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < TP; ++j) acc[i][j] = acc[i][j] * iy * iz;
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -966,11 +1098,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_h1b_kernel(const WgK pv, const W
       }
     }
 }
-constexpr size_t wg_h1b_lds(int np) { return (size_t)np * ((128 / 16) + H1_TP) * (H3_KP * 32 + 32); }
+constexpr size_t wg_h1b_lds(int np) { return (size_t)np * ((128 / 16) + H1_TP) * (H3_KP * 32 + 32) + 64; }      // + the waves' maxima (NP = 2)
 
 inline bool wgrad_split_narrow() { return addk_env("ADDK_WGRAD_SPLIT_NARROW", 1) != 0; }
 inline bool wgrad_split_enabled() { return addk_env("ADDK_WGRAD_SPLIT", 1) != 0; }
-constexpr size_t wg_h3b_lds(int nt, int np, int ng) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + ng * (3 * 104 * 32 + (ng > 1 ? 64 : 0))); }
+constexpr size_t wg_h3b_lds(int nt, int np, int ng) { return (size_t)np * ((64 * nt / 16) * (H3_KP * 32 + 32) + ng * (3 * 104 * 32 + (ng > 1 ? 64 : 0))) + 64; }      // + the waves' maxima (NP = 2)
 
 // Halo-patch weight gradient of the cells' dense dilated convolutions (dil_conv_3x3 / dil_conv_5x5: 40/80/160 channels,
 // dilation <= 2).  Same staging as wgrad_h3_kernel — per 64-pixel row segment dy [64][16*CT] and the KS activation rows
@@ -1150,6 +1282,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_hkb_kernel(const WgK pv, const W
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   unsigned char* Yb = wsm;                                        // [NP][CT][64 px][16 co]
   unsigned char* Zb = wsm + NP * YPL;                             // [NP][KS rows][HKB_ZWP px][16 ci]
+  unsigned* wmx = reinterpret_cast<unsigned*>(wsm + NP * (YPL + ZPL));      // NP = 2: [2][4] the waves' largest magnitudes of the segment being staged (wgrad_h3b_kernel)
+  WgScale fsc = {0, 0};
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
   const int zt = blk_x % p.nzt, yt = blk_x / p.nzt;
@@ -1211,12 +1345,42 @@ __global__ void __launch_bounds__(256, 2) wgrad_hkb_kernel(const WgK pv, const W
       zmask |= (ok ? 1u : 0u) << k;
     }
   };
+  auto ypro = [&](int k) {
+    float4 v = ry[k];
+    const bool ok = (ymask >> k) & 1u;
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+  };
+  auto zpro = [&](int k) {
+    float4 v = rz[k];
+    v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
+    if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    const bool ok = (zmask >> k) & 1u;
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+  };
+  auto prep2 = [&]() {                                               // NP = 2: masks and prologue in place, the wave's maxima to LDS (in front of the barrier)
+    unsigned my = 0, mz = 0;
+#pragma unroll
+    for (int k = 0; k < NYJ; ++k) { ry[k] = ypro(k); const unsigned b = absbits4(ry[k]); my = b > my ? b : my; }
+#pragma unroll
+    for (int k = 0; k < NZJ; ++k) { rz[k] = zpro(k); const unsigned b = absbits4(rz[k]); mz = b > mz ? b : mz; }
+    wg_publish_max(wmx, 4, wave, lane, my, mz);
+  };
+  auto rescale2 = [&]() {
+    const float r = wg_rescale(wmx, 4, fsc);
+    if (r != 1.f) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[i][j] *= r;
+    }
+  };
   auto store_step = [&]() {
+    const float sy = NP == 2 ? wg_pow2(fsc.kfy) : 1.f, sz = NP == 2 ? wg_pow2(fsc.kfz) : 1.f;
 #pragma unroll
     for (int k = 0; k < NYJ; ++k) {
-      float4 v = ry[k];
-      const bool ok = (ymask >> k) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      const float4 v = NP == 2 ? wg_mul4(ry[k], sy) : ypro(k);
       if (yrow[k] < H3_KP) {
         uint2 pl[NP];
         wg_split4<NP>(v, pl);
@@ -1227,11 +1391,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_hkb_kernel(const WgK pv, const W
     }
 #pragma unroll
     for (int k = 0; k < NZJ; ++k) {
-      float4 v = rz[k];
-      v.x = fmaf(za.x, v.x, zb.x); v.y = fmaf(za.y, v.y, zb.y); v.z = fmaf(za.z, v.z, zb.z); v.w = fmaf(za.w, v.w, zb.w);
-      if (zrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const bool ok = (zmask >> k) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      const float4 v = NP == 2 ? wg_mul4(rz[k], sz) : zpro(k);
       if (zr[k] < KS) {
         uint2 pl[NP];
         wg_split4<NP>(v, pl);
@@ -1253,13 +1413,17 @@ __global__ void __launch_bounds__(256, 2) wgrad_hkb_kernel(const WgK pv, const W
   };
   auto mma = [&](f32x4 (&c)[CT][TPW], int j, const wg_bf16x8 (&y)[CT][NP], const wg_bf16x8* z) {
 #define WG_TERM(YI, ZI) _Pragma("unroll") for (int i = 0; i < CT; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i][YI], z[ZI], c[i][j], 0, 0, 0);
+#define WG_TERMH(YI, ZI) _Pragma("unroll") for (int i = 0; i < CT; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, y[i][YI]), __builtin_bit_cast(f16x8, z[ZI]), c[i][j], 0, 0, 0);
+    if constexpr (NP == 2) { WG_TERMH(1, 0) WG_TERMH(0, 1) WG_TERMH(0, 0) } else {
     if (NP == 3) { WG_TERM(2, 0) WG_TERM(0, 2) WG_TERM(1, 1) }
-    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0)
+    WG_TERM(1, 0) WG_TERM(0, 1) WG_TERM(0, 0) }
 #undef WG_TERM
+#undef WG_TERMH
   };
 
   if (sbeg < send) {
     load_step(sbeg);
+    if (NP == 2) { prep2(); __syncthreads(); rescale2(); }
     store_step();
     __syncthreads();
     for (int seg = sbeg; seg < send; ++seg) {
@@ -1280,12 +1444,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_hkb_kernel(const WgK pv, const W
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (NP == 2 && more) prep2();
       __syncthreads();
-      if (more) { store_step(); __syncthreads(); }
+      if (more) { if (NP == 2) rescale2(); store_step(); __syncthreads(); }
     }
   }
   const int C = p.src.C;
   gfloat* wsb = (gfloat*)p.ws + (long)blk_y * p.Cout * TAPS * C;
+  if (NP == 2) {
+    const float iy = wg_pow2(254 - fsc.kfy), iz = wg_pow2(254 - fsc.kfz);
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) acc[i][j] = acc[i][j] * iy * iz;
+  }
   const int c = c0 + li;
 #pragma unroll
   for (int i = 0; i < CT; ++i)
@@ -1302,7 +1474,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_hkb_kernel(const WgK pv, const W
       }
     }
 }
-constexpr size_t wg_hkb_lds(int ks, int ct, int np) { return (size_t)np * ((size_t)ct * (H3_KP * 32 + 32) + (size_t)ks * HKB_ZWP * 32); }
+constexpr size_t wg_hkb_lds(int ks, int ct, int np) { return (size_t)np * ((size_t)ct * (H3_KP * 32 + 32) + (size_t)ks * HKB_ZWP * 32) + 64; }      // + the waves' maxima (NP = 2)
 
 // Register-streaming weight gradient for the narrow cell convolutions (Cout, C <= 160; 1x1, dilated k x k, strided):
 // no LDS staging and no barrier in the main loop.  A wave walks its own pixel range four pixels per MFMA k-step; lane

@@ -9,8 +9,9 @@
 Prints ONE JSON line on rank 0.  Synthetic data (N(0,1) images, uniform labels with 5 % ignore), random-init
 weights of the named architecture (kaiming-scaled normals keyed on parameter names, so the CPU oracle gets the SAME
 weights and the first-step loss can be asserted against it), fp32 storage; the wide k x k contractions run in the
-arithmetic `--math` names (library default otherwise; bf16x6 = fp32 operands as three bf16 terms, six product terms, fp32
-accumulation — as accurate as the fp32 MFMA chain).
+arithmetic `--math` names (library default otherwise: f16x3 = fp32 operands as two fp16 terms under an exact power-of-two scale, three
+product terms on the fp16 matrix pipe, fp32 accumulation — split error below the rounding noise of an fp32 accumulation chain, see
+DESIGN.md §4.1; bf16x6, the default of rounds 2-5 = three bf16 terms, six product terms, is timed beside it as a second value).
 
 Besides the contract's fields the line carries, measured in this run on rank 0 at N=1:
   roofline           dominant kernel (decoder 3x3) AND `segment`: the north-star "ASPP + cell forward" segment, eval and
@@ -420,16 +421,15 @@ def timed_region(ts, steps, warmup, world, rank, barrier, max_over_ranks, contra
     return dt, modes, losses
 
 
-def tail_x3_step(genotype, a, x, t, dev, steps=10):
-    """Second value beside the headline (NOT the headline): the same step with three product terms in the exit heads only (`tail_x3`: ASPP
-    and decoder forward, data and weight gradients; six terms everywhere else).  Its parity gates are the bf16x6 ones, unchanged
-    (tests/test_gpu_parity.py::test_tail_x3_..., tests/test_gpu_round3.py::test_tail_x3_...)."""
+def alt_math_step(mode, genotype, a, x, t, dev, steps=10):
+    """Second value beside the headline (NOT the headline): the same step in another arithmetic of the wide contractions — `bf16x6`, the
+    six-term split-bf16 form that was the default through round 5, beside today's `f16x3`."""
     import addk
     from addk.modeling.ADD import ADD
     from addk.train import TrainStep
     prev = addk.get_precision()
     try:
-        addk.set_precision('tail_x3')
+        addk.set_precision(mode)
         m = ADD(NETWORK_ARCH, C_INDEX, genotype, 19, make_args(a.F), 0)
         init_weights(m)
         m.to(dev)
@@ -448,7 +448,7 @@ def tail_x3_step(genotype, a, x, t, dev, steps=10):
         dt = (time.perf_counter() - t0) / steps
         ts.close()
         return {'ms_per_step': dt * 1e3, 'images_per_sec': x.shape[0] / dt, 'first_step_losses': losses,
-                'what': 'three bf16 product terms in ASPP + decoder (fwd, dgrad, wgrad), six elsewhere; fp32 storage and accumulation'}
+                'what': 'the same step with --math %s; fp32 storage and accumulation' % mode}
     finally:
         addk.set_precision(prev)
 
@@ -466,7 +466,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the segment roofline / per-exit latency / drop-in measurements')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--math', choices=['fp32', 'bf16x6', 'bf16x3', 'tail_x3'], default=None,
+    ap.add_argument('--math', choices=['fp32', 'f16x3', 'bf16x6', 'bf16x3', 'tail_x3'], default=None,
                     help='arithmetic of the wide k x k contractions (default: the library default, see addk.get_precision())')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--extras-child', action='store_true', help=argparse.SUPPRESS)
@@ -528,8 +528,8 @@ def main():
             guarded('segment_train', lambda: segment_roofline(model, x, 'train'))
         guarded('per_exit_ms', lambda: per_exit_latency(model, dev))
         guarded('drop_in', lambda: drop_in_step(model, x, t))
-        if math == 'bf16x6':
-            guarded('tail_x3', lambda: tail_x3_step(genotype, a, x, t, dev))
+        if math == 'f16x3':
+            guarded('bf16x6', lambda: alt_math_step('bf16x6', genotype, a, x, t, dev))
         json_out.write(json.dumps(res) + '\n')
         json_out.flush()                               # before the last, least proven extra: a crash there keeps the others
         guarded('ddp_path_world1', lambda: ddp_path_world1(genotype, a, x, t, dev))
@@ -557,7 +557,7 @@ def main():
         line = {'metric': 'Cityscapes 1024x2048 images/sec fwd+bwd @ bs=2/GPU', 'value': world * n * a.steps / d, 'unit': 'images/sec',
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': d / a.steps * 1e3, 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'f32' if math == 'fp32' else 'f32 storage and accumulation; k x k contractions as %s split-bf16 MFMA products' % math,
+                'dtype': 'f32' if math == 'fp32' else 'f32 storage and accumulation; k x k contractions as %s %s MFMA products' % (math, 'split-fp16' if math == 'f16x3' else 'split-bf16'),
                 'data': 'synthetic',
                 'config': {'workload': 'ADD F=%d searched_arch/%s C=2 all exits, %dx%d bs=%d/GPU fwd+CE+bwd+SGD(nesterov)' % (a.F, a.genotype, h, w, n),
                            'global_batch': world * n, 'parallelism': 'dp%d' % world, 'sync_bn': comm is not None,
@@ -586,21 +586,23 @@ def main():
     tk = time_launch(top['cmd'])
     fwd_flops = sum(m['flops'] for m in convs)
     halo = bool(top.get('halo'))
-    terms = {'fp32': 1, 'bf16x6': 6, 'bf16x3': 3, 'tail_x3': 3}[math] if halo else 1          # (the dominant launch is a decoder conv: a tail launch)
+    terms = {'fp32': 1, 'bf16x6': 6, 'f16x3': 3, 'tail_x3': 3}[math] if halo else 1          # (the dominant launch is a decoder conv: a tail launch)
     if terms == 1:
         peak, kern = PEAK_MFMA_F32_TFLOPS, ('conv3_kernel' if halo else 'conv_kernel') + ' (v_mfma_f32_16x16x4_f32)'
         peak_note = 'fp32 matrix peak'
     else:
         peak = PEAK_MFMA_BF16_TFLOPS / terms
-        kern = 'conv3b_kernel (v_mfma_f32_32x32x16_bf16, %d bf16 product terms per fp32 product)' % terms
-        peak_note = 'dense bf16 MFMA peak %.0f TFLOP/s / %d matrix instructions per fp32 multiply-add' % (PEAK_MFMA_BF16_TFLOPS, terms)
+        el = 'bf16' if terms == 6 else 'f16'
+        kern = 'conv3b_kernel (v_mfma_f32_32x32x16_%s, %d %s product terms per fp32 product)' % (el, terms, 'bf16' if terms == 6 else 'fp16')
+        peak_note = 'dense %s MFMA peak %.0f TFLOP/s / %d matrix instructions per fp32 multiply-add' % (el, PEAK_MFMA_BF16_TFLOPS, terms)
     ach = top['flops'] / tk / 1e12
     # HBM-side traffic of that launch: PMC passes cannot run inside this process; the committed rocprofv3 --pmc measurement of the
     # same kernel and shape (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes: scripts/refresh_profiles_r04.sh) is quoted, labelled
     traffic, tsrc = None, None
-    tpath = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_pmc_traffic_decoder_conv3b.json' % r) for r in (4, 3, 2)) if os.path.exists(q)),
+    tname = 'pmc_traffic_decoder_conv3b_f16x3' if math == 'f16x3' else 'pmc_traffic_decoder_conv3b'
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', 'r0%d_%s.json' % (r, tname)) for r in (5, 4, 3, 2)) if os.path.exists(q)),
                  os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_decoder_conv3b.json'))
-    if halo and math == 'bf16x6' and (n, h, w, a.F, a.genotype) == (2, 1024, 2048, 20, 'autodeeplab/genotype') and os.path.exists(tpath):
+    if halo and math in ('bf16x6', 'f16x3') and (n, h, w, a.F, a.genotype) == (2, 1024, 2048, 20, 'autodeeplab/genotype') and os.path.exists(tpath):
         try:
             traffic, tsrc = json.load(open(tpath)).get('traffic_bytes_per_launch'), 'profiles/%s (rocprofv3 --pmc passes of the same kernel and shape; not measured in this run)' % os.path.basename(tpath)
         except Exception:
@@ -671,9 +673,9 @@ def main():
             roof['segment'] = {'error': str(merged.get('segment_eval', merged.get('error', 'extras child produced no output')))}
         for key in ('per_exit_ms', 'drop_in', 'ddp_path_world1'):
             out[key] = merged.get(key, {'error': merged.get('error', 'extras child produced no output')})
-        if isinstance(merged.get('tail_x3'), dict) and 'ms_per_step' in merged['tail_x3']:
-            out['ms_per_step_by_mode']['tail_x3'] = merged['tail_x3']['ms_per_step']          # a second value; `value` / `dtype` stay the bf16x6 ones
-            out['tail_x3'] = merged['tail_x3']
+        if isinstance(merged.get('bf16x6'), dict) and 'ms_per_step' in merged['bf16x6']:
+            out['ms_per_step_by_mode']['bf16x6'] = merged['bf16x6']['ms_per_step']          # a second value; `value` / `dtype` are the f16x3 ones
+            out['bf16x6'] = merged['bf16x6']
     if not a.no_cpu_baseline and world == 1 and default_cfg:
         cb = cpu_baseline(n, h, w)
         out['cpu_baseline'] = cb

@@ -121,17 +121,20 @@ int addk_conv_fwd(const addk_conv_args* a, void* stream);
 int addk_conv_fwd_resample_ok(const addk_conv_args* a);
 /* floats of `wpack` this launch can use; 0 = the halo-patch kernel does not cover the shape */
 int64_t addk_conv_fwd_pack_floats(const addk_conv_args* a);
-/* Arithmetic of the wide k x k stride-1 contractions (the halo-patch kernels, forward and data gradient):
+/* Arithmetic of the wide k x k stride-1 contractions (the halo-patch kernels: forward, data gradient, weight gradient):
  *   0 = exact fp32 products on v_mfma_f32_16x16x4_f32;
- *   2 = split-bf16, six terms (default): every fp32 operand is x = h + m + l with h, m, l in bf16 (3 x 8 bits = fp32's 24, exact)
- *       and a product is the sum of its six largest bf16 x bf16 terms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation —
- *       as accurate as the fp32 MFMA chain (rms 5.6e-8 vs 6.8e-8 of sum|a*b| at K = 2048) at 2.5x its rate;
- *   1 = three terms (h*h, h*m, m*h): fast mode, rms ~5e-7;
- *   3 = "tail_x3": three terms in the exit heads only (launches with >= 192 output / gradient channels: ASPP and decoder forward,
- *       data gradient and weight gradient — decoder.py:14-21, aspp_train.py:16-25), six terms everywhere else.  The reference's own
- *       GPU path is 16-bit throughout (apex O1, train.py:145-165); this mode spends the short products where nothing amplifies them.
+ *   1 = "f16x3", split-fp16 (default since round 5): every fp32 operand is x = h + l with h = fp16(x), l = fp16(x - h) (2 x 11 = 22 of
+ *       fp32's 24 significand bits) under an exact power-of-two scale (weights: per tensor, from an amax pass in front of the pack;
+ *       activations / gradients: a running scale per tile, csrc/conv3b.h), and a product is the sum of its three largest terms on
+ *       v_mfma_f32_32x32x16_f16 with fp32 accumulation.  Split error rms 3e-9 of sum|a*b| at K = 2736 — below an fp32 accumulation chain's
+ *       rounding noise (1e-8) — at half the matrix instructions of mode 2;
+ *   2 = "bf16x6", split-bf16, six terms: x = h + m + l in bf16 (3 x 8 bits = fp32's 24, exact), the six largest bf16 x bf16 terms on
+ *       v_mfma_f32_32x32x16_bf16 (rms 5.6e-8 vs the fp32 MFMA chain's 6.8e-8 of sum|a*b| at K = 2048);
+ *   3 = "tail_x3": mode 1 in the exit heads only (launches with >= 192 output / gradient channels: ASPP and decoder forward,
+ *       data gradient and weight gradient — decoder.py:14-21, aspp_train.py:16-25), mode 2 everywhere else.
+ * The reference's own GPU path is 16-bit throughout (apex O1, train.py:145-165).
  * Every other kernel computes in fp32.  Process-wide; set before plans are built (packed-weight buffers are sized per mode).
- * Environment: ADDK_MATH=fp32|bf16x6|bf16x3|tail_x3. */
+ * Environment: ADDK_MATH=fp32|f16x3|bf16x6|tail_x3 (bf16x3: the old name of mode 1). */
 int addk_set_conv_precision(int mode);
 /* Split-bf16 modes: launches with fewer output channels than this stay on the exact fp32 kernel (default 0 = none, see
  * conv3.hip; 65 = round-2's first rule, kept for A/B runs).  c < 0 restores the default. */
