@@ -655,7 +655,8 @@ int c3b_launch(C3K& k, PackK& pk, int mode, int rows, hipStream_t st, bool packe
   if (!packed) c3_pack_now(pk, pb, st);
   const size_t lds = (size_t)((ph * 32 * wc * 16 + 15) & ~15) + (size_t)np * (tworow ? ks + 1 : ks) * cb_pwmax(ks, bigd, rpx, k.st) * 32;
   k.slab_rows = rows;
-  dim3 grid(rows < k.ntiles ? rows : k.ntiles, cdiv(k.Cn, 32 * wc));      // no workgroups without a tile (they would queue for LDS and registers just to write zeros)
+  k.ny = cdiv(k.Cn, 32 * wc);
+  dim3 grid((rows < k.ntiles ? rows : k.ntiles) * k.ny, 1);      // no workgroups without a tile (they would queue for LDS and registers just to write zeros); the channel blocks of a tile side by side (conv3b_kernel)
   // the instantiations live in conv3b_tr3 / conv3b_tr5 / conv3b_row / conv3b_s2.hip (compiled in parallel)
   const bool done = tworow ? (ks == 3 ? c3b_run_tr3(&k, wc, rpx, mode, np, grid, lds, st) : c3b_run_tr5(&k, wc, rpx, mode, np, grid, lds, st)) != 0
                   : k.st == 2 ? (ks == 3 && mode == MODE_FWD && c3b_run_s2f(&k, wc, bpx, np, grid, lds, st) != 0)

@@ -31,6 +31,7 @@ struct C3K {
   addk_src dst; int accumulate;
   int vecY, red32;
   long P; int ntiles, spr;
+  int ny;                   // conv3b_kernel: channel blocks per tile (the grid is one-dimensional: tile workgroups x ny)
   int st;                   // stride (host-side dispatch; 2 = the de-interleaved 3x3 forward of conv3b_kernel)
   int om, oro, oco, OHo, OWo;   // output pixel of tile-grid position (oh, ow): (om oh + oro, om ow + oco) in an OHo x OWo map (om = 1: the grid itself)
 };
@@ -134,7 +135,7 @@ __device__ __forceinline__ void rs32(float (&v)[16], const int lp32) {
 #define ADDK_C3B_ABL 0          // ablation study (scripts/c3b_ablation.sh): bit 0 no weight-fragment loads, 1 no prologue / split (raw bits stored), 2 no statistics,
 #endif                          // 3 only the first chunk's patch is loaded, 4 one MFMA per (tap, tile) instead of NP*(NP+1)/2 — every ablated build computes WRONG numbers
 template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1, int TR = 1>
-__device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const int gx) {      // workgroup bx of gx along x (tiles, slab row)
+__device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const int gx, const int by) {      // workgroup bx of gx along x (tiles, slab row), channel block by
 #ifdef ADDK_C3B_DIAG
   const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long dph[6] = {0, 0, 0, 0, 0, 0};
@@ -160,7 +161,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   uint2* Pl2 = reinterpret_cast<uint2*>(Pl);
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wave = wv % WC, wpx = wv / WC, lp32 = lane & 31, hh = lane >> 5;
-  const int n0 = blockIdx.y * BC;
+  const int n0 = by * BC;
   const int d = p.dil;
   // statistics of this workgroup: after each tile's reduce-scatter (rs32) lane l holds the tile's sums of channel value (l & 31) >> 1 and adds them
   // here in double; red[] is written ONCE, after the last tile (it was 64 dependent LDS read-modify-writes by one lane per tile and wave:
@@ -188,7 +189,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
     const int pj = ST == 2 ? (kw == 1 ? OB + lp32 : lp32 + (kw >> 1)) : lp32 + kw * d;
     xb[kw] = pj * 2 + (hh ^ ((pj >> 3) & 1)) + (wrow * PWP + wcol * 32) * 2;
   }
-  const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)blockIdx.y * p.wp_blk + (long)wave * NP * 64 + lane);
+  const uint4* wpl = reinterpret_cast<const uint4*>(p.wp) + ((long)by * p.wp_blk + (long)wave * NP * 64 + lane);
   const int nT = p.nT;
   const float winv = NP == 2 ? p.wsc[0] : 1.f;
   unsigned pmask = 0;                         // bit k: parity of (r*d + pj) of this thread's patch slot k (checkerboard sign, below)
@@ -557,7 +558,7 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
   }
 #ifdef ADDK_C3B_DIAG
   if (t == 0) {
-    unsigned long long* dslot = g_c3b_diag[(bx + 7 * blockIdx.y) & 63];
+    unsigned long long* dslot = g_c3b_diag[(bx + 7 * by) & 63];
     atomicAdd(&dslot[0], __builtin_amdgcn_s_memtime() - diag_c0); atomicAdd(&dslot[1], __builtin_amdgcn_s_memrealtime() - diag_r0);
     atomicAdd(&dslot[2], 1ull);
     for (int i = 0; i < 6; ++i) atomicAdd(&dslot[4 + i], dph[i]);
@@ -581,7 +582,15 @@ __device__ __forceinline__ void conv3b_body(const C3K& p, const int bx, const in
 
 template <int WC, int KS, int MODE, int NP, bool BIGD, int PH = 1, int BPX = C3_BP, int ST = 1, int TR = 1>
 __global__ void __launch_bounds__(64 * WC * PH, 2) conv3b_kernel(const C3K p) {
-  conv3b_body<WC, KS, MODE, NP, BIGD, PH, BPX, ST, TR>(p, blockIdx.x, gridDim.x);
+  // [r5] one-dimensional grid of (tile workgroups) x (channel blocks) with the channel blocks of a tile NEXT to each other on ONE XCD: workgroups are dealt
+  // round-robin over the 8 XCDs, so linear ids l and l + 8 share an L2 — with a two-dimensional grid the second channel block of a tile started after ALL
+  // first ones and fetched the same input rows from HBM again (PMC: 1.97x the algorithmic bytes for the decoder conv, rounds 2-5)
+  const int ny = p.ny, gx = (int)gridDim.x / ny, lin = (int)blockIdx.x;
+  int bx, by;
+  if (ny == 1) { bx = lin; by = 0; }
+  else if ((gx & 7) == 0) { const int q = lin >> 3; by = q % ny; bx = (q / ny) * 8 + (lin & 7); }
+  else { by = lin % ny; bx = lin / ny; }
+  conv3b_body<WC, KS, MODE, NP, BIGD, PH, BPX, ST, TR>(p, bx, gx, by);
 }
 }  // namespace
 
