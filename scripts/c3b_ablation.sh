@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   (cd $SRC && make -j8 > /dev/null) || exit 1
   for v in $VARIANTS; do
     name=${v%%:*}; mask=${v##*:}; d=$ROOT/build/abl/$name; mkdir -p $d
-    ( for u in conv3 conv3b_tr3 conv3b_tr5 conv3b_row conv3b_s2; do
+    ( for u in conv3 conv3b_tr3 conv3b_tr5 conv3b_row conv3b_s2 conv3n; do
         /opt/rocm/bin/hipcc $FLAGS -DADDK_C3B_DIAG ${mask:+-DADDK_C3B_ABL=$mask} -c $SRC/$u.hip -o $d/$u.o 2>> $d/build.log || exit 1
       done
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $SRC/*.o | grep -v "/conv3") $d/conv3*.o -o $d/libaddk.so && rm $d/conv3*.o && echo "built $name" ) &
@@ -32,7 +32,7 @@ for sh in "stem 3x3" "dil 5x5 d2 40->40" "dil 3x3 d2 40->40" "dil 5x5 d2 80->80 
   for v in $VARIANTS; do
     name=${v%%:*}; mask=${v##*:}
     echo "--- [$name] ablation mask ${mask:-0} (1 no weight loads, 2 no prologue/split, 4 no statistics, 8 first patch only, 16 one MFMA per (tap, tile))"
-    SHAPES="$sh" PACKED=1 NOWGRAD=1 ADDK_MATH=bf16x6 /tmp/conv_bench_$name 20 2>&1 | grep -v amdgpu.ids
+    SHAPES="$sh" PACKED=1 NOWGRAD=1 ADDK_MATH=${MATH:-f16x3} /tmp/conv_bench_$name 20 2>&1 | grep -v amdgpu.ids
   done
 done
 } > $out

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Regenerates the round-5 measurement artefacts under gpurun_out/r05/ (copy into profiles/ what is to be judged):
-#   bench lines (default with every extra; fp32; bf16x3; config 5's architecture), rocprofv3 kernel stats of the same command (two
+#   bench lines (default = f16x3 with every extra; fp32; bf16x6; tail_x3; config 5's architecture), rocprofv3 kernel stats of the same command (two
 #   streams and single stream = true durations), SQ counters of EVERY kernel of the step (two --pmc passes, kernel-trace only),
 #   SQ counters + HBM-side traffic of the dominant kernel on the stand-alone harness, the inference forward trace.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05; rm -rf $O; mkdir -p $O
-timeout -k 10 700 python3 bench.py --steps 20 --warmup 3 > $O/bench_bf16x6.json 2> $O/bench_bf16x6.err || { tail -5 $O/bench_bf16x6.err; exit 1; }
-echo "bench default done: $(python3 -c "import json;d=json.load(open('$O/bench_bf16x6.json'));print(d['ms_per_step'], d['value'])")"
-for m in fp32 bf16x3 tail_x3; do
+timeout -k 10 700 python3 bench.py --steps 20 --warmup 3 > $O/bench_f16x3.json 2> $O/bench_f16x3.err || { tail -5 $O/bench_f16x3.err; exit 1; }
+echo "bench default done: $(python3 -c "import json;d=json.load(open('$O/bench_f16x3.json'));print(d['ms_per_step'], d['value'])")"
+for m in fp32 bf16x6 tail_x3; do
   timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --math $m > $O/bench_$m.json 2> /dev/null
   echo "bench $m: $(python3 -c "import json;d=json.load(open('$O/bench_$m.json'));print(d['ms_per_step'], d['roofline']['launch_ms'], d['roofline']['frac'])")"
 done
@@ -50,33 +50,8 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['pmc_a:SQ_WAVE_CYCLES'])[:
 PY
 rm -rf $O/pmc_a $O/pmc_b
 head -12 $O/pmc_step_sq_summary.txt
-ADDK_MATH=bf16x6 SHAPES="decoder 3x3 304" bash scripts/pmc_conv3b.sh > $O/pmc_conv3b.txt 2>&1; grep -A5 "conv3b_kernel<4, 3, 0" $O/pmc_conv3b.txt | head -8
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $O/pmc_$c
-  ADDK_MATH=bf16x6 SHAPES="decoder 3x3 304" timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- /tmp/conv_bench 2 > /dev/null 2>&1
-done
-python3 - <<'PY'
-import csv, glob, json
-O = 'gpurun_out/r05'
-res = {}
-for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    f = glob.glob('%s/pmc_%s/*/*counter_collection.csv' % (O, c))
-    if not f: continue
-    for r in csv.DictReader(open(f[0])):
-        if r['Counter_Name'] == c:
-            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-            res.setdefault(k, {}).setdefault(c, []).append(float(r['Counter_Value']))
-out = {}
-for k, v in res.items():
-    if 'conv3b_kernel<4, 3, 0' in k:
-        fs, ws = v.get('FETCH_SIZE', [0])[0], v.get('WRITE_SIZE', [0])[0]
-        out = {'kernel': k, 'shape': 'decoder 3x3 304->256 @ [2,128,256], bf16x6', 'FETCH_SIZE_KB_raw': fs, 'WRITE_SIZE_KB': ws,
-               'fetch_bytes_corrected_x2_gfx950': fs * 1024 * 2, 'write_bytes': ws * 1024, 'traffic_bytes_per_launch': fs * 1024 * 2 + ws * 1024,
-               'algorithmic_bytes_per_launch': 149602304.0}
-json.dump(out, open(O + '/pmc_traffic_decoder_conv3b.json', 'w'), indent=1)
-print(out)
-PY
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+ADDK_MATH=f16x3 bash scripts/pmc_traffic.sh $O | tail -1      # SQ counters + HBM-side traffic of the dominant launch (decoder 3x3), stand-alone harness
+ADDK_MATH=bf16x6 bash scripts/pmc_traffic.sh $O | tail -1
 # the list the model really runs (level-ordered, batched, two streams): inference and training forward, kernel by kernel
 for m in eval train; do
   rm -rf $O/ft; timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/ft -- python3 scripts/fwd_trace.py --mode $m --real > /dev/null 2>&1 && python3 scripts/fwd_trace.py --csv $(ls $O/ft/*/*kernel_trace.csv | head -1) --top 50 > $O/fwd_${m}_kernels_two_streams_batched.txt 2>&1; rm -rf $O/ft
