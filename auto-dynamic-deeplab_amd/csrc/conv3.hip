@@ -39,6 +39,7 @@ struct PackK {
                             // 2 = stride 2, the taps of kernel column 2 carry it
   int s2d;                  // conv3b: 1 = the four parity-class packs of the stride-2 data gradient (c3b_pack_s2d_body); 2 = the 16-wide-tile kernel's pack (c3n_pack_body)
   int sbase[C3_MAXCH];      // s2d == 2: first K-step of the chunk (conv3n.hip: two taps x 16 channels per step, four taps x 8 for a chunk of <= 8 channels)
+  int wrows;                // rows of the whole weight tensor [wrows][ldw] behind `w` (the amax pass scans it contiguously)
   float* amax;              // planes == 2 (split-fp16, conv3b.h): the 128-float trailer of the pack buffer — [0..63] the amax pass's per-workgroup maxima of |w|,
                             // [64] = 2^-kw for the kernel's epilogue (C3K.wsc), [65] = 2^kw
 };
@@ -52,13 +53,16 @@ __global__ void __launch_bounds__(256) c3_pack_kernel(const PackK p) { c3_pack_b
 __global__ void __launch_bounds__(256) c3_pack_batch_kernel(const PackK* __restrict__ descs) {
   c3_pack_body(descs[blockIdx.y], (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
-template <bool AMAX> __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride, float& amax);
-// split-fp16 packs (planes == 2): the pass in front of the pack walks the same elements and leaves the largest |w| each of its C3_AMAX_WG workgroups saw in
-// the trailer (max is order-independent: bit-reproducible); every pack thread folds the 64 partials into the tensor's scale 2^kw itself
+__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride);
+// split-fp16 packs (planes == 2): the pass in front of the pack scans the convolution's WHOLE weight tensor (contiguous, coalesced: forward and data-gradient
+// packs of one convolution, and the data gradients towards its several sources, get the same scale) and leaves the largest |w| each of its C3_AMAX_WG
+// workgroups saw in the trailer (max is order-independent: bit-reproducible); every pack thread folds the 64 partials into the tensor's scale 2^kw itself
 __device__ __forceinline__ void c3_amax_body(const PackK& p) {
   if (p.planes != 2) return;
   float m = 0.f;
-  c3b_pack_body<true>(p, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256, m);
+  const long n = (long)p.wrows * p.ldw;
+  const gfloat* w = (const gfloat*)p.w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
   __shared__ unsigned wm[4];
   const unsigned b = wave_umax(__float_as_uint(m));
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = b;
@@ -83,7 +87,7 @@ __device__ __forceinline__ float c3_pack_scale(const PackK& p, long first) {
   return __uint_as_float((unsigned)kf << 23);
 }
 __device__ __forceinline__ void c3_pack_body(const PackK& p, long first, long stride) {
-  if (p.planes) { float unused = 0.f; c3b_pack_body<false>(p, first, stride, unused); return; }
+  if (p.planes) { c3b_pack_body(p, first, stride); return; }
   const int BC = 16 * p.bct;
   const int nT = p.nchunks * p.taps;
   const long per_blk = (long)nT * p.bct * 256;
@@ -348,10 +352,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const C3K p) {
 // kh = 1 for pi = 0, else {2, 0}[th] (same for columns) — 1, 2, 2, 4 of the nine taps per parity class.  Four packs back to back, class
 // c = 2 pi + pj at (taps of the classes before) * unit, each [colblk][chunk * tc + tap][tile][plane][lane]; tap (th, tw) carries
 // (-1)^(th + tw), its share of the checkerboard sign over the class grid (a, b).
-template <bool AMAX>
-__device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, long stride, float& amax) {
+__device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, long stride) {
   const int BC = 32 * p.bct, NP = p.planes;
-  const float wsc = AMAX ? 1.f : c3_pack_scale(p, first);
+  const float wsc = c3_pack_scale(p, first);
   const long unit = (long)((p.Cn + BC - 1) / BC) * p.nchunks * p.bct * 64;          // lanes per tap
   uint4* out = reinterpret_cast<uint4*>(p.out);
   for (long idx = first; idx < 9 * unit; idx += stride) {
@@ -375,12 +378,10 @@ __device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, lo
       const int kk = k0 + j;
       if (row < p.Cn && kk < p.cvalid[chunk]) v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(kh * 3 + kw) * p.cin_total + p.w_choff + row];
       if ((th + tw) & 1) v = -v;
-      if (AMAX) { amax = fmaxf(amax, fabsf(v)); continue; }
       vv[j] = v * wsc;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
     }
-    if (AMAX) continue;
     uint4* o = out + pre * unit * NP + (((long)blk * nT + T) * p.bct + i) * NP * 64 + lane;
     if (NP == 2) { split8h(vv, o[0], o[64]); continue; }
     for (int k = 0; k < NP; ++k)
@@ -390,10 +391,9 @@ __device__ __forceinline__ void c3b_pack_s2d_body(const PackK& p, long first, lo
 
 // conv3n_kernel (conv3n.hip): out (16-byte units) [K-step T][16-row tile i (3)][plane][lane] = 8 bf16: row co = 16 i + lane % 16; lane group g = lane / 16 holds, in a
 // pair step, channels 8 (g & 1) .. + 7 of tap 2 st + (g >> 1), in a quad step (chunk of <= 8 channels) channels 0..7 of tap 4 st + g; taps beyond the kernel: zeros
-template <bool AMAX>
-__device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long stride, float& amax) {
+__device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long stride) {
   const int NP = p.planes;
-  const float wsc = AMAX ? 1.f : c3_pack_scale(p, first);
+  const float wsc = c3_pack_scale(p, first);
   const int ks = p.taps == 9 ? 3 : 5;
   const int last = p.nchunks - 1;
   const int steps = p.sbase[last] + (p.cvalid[last] <= 8 ? (p.taps + 3) / 4 : (p.taps + 1) / 2);
@@ -420,12 +420,10 @@ __device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long s
         else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
       }
       if (flip) v = -v;
-      if (AMAX) { amax = fmaxf(amax, fabsf(v)); continue; }
       vv[j] = v * wsc;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
     }
-    if (AMAX) continue;
     uint4* o = out + ((long)(T * 3 + i) * NP) * 64 + lane;
     if (NP == 2) { split8h(vv, o[0], o[64]); continue; }
     for (int k = 0; k < NP; ++k)
@@ -433,12 +431,11 @@ __device__ __forceinline__ void c3n_pack_body(const PackK& p, long first, long s
   }
 }
 
-template <bool AMAX>
-__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride, float& amax) {
-  if (p.s2d == 2) { c3n_pack_body<AMAX>(p, first, stride, amax); return; }
-  if (p.s2d) { c3b_pack_s2d_body<AMAX>(p, first, stride, amax); return; }
+__device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long stride) {
+  if (p.s2d == 2) { c3n_pack_body(p, first, stride); return; }
+  if (p.s2d) { c3b_pack_s2d_body(p, first, stride); return; }
   const int BC = 32 * p.bct, NP = p.planes;
-  const float wsc = AMAX ? 1.f : c3_pack_scale(p, first);
+  const float wsc = c3_pack_scale(p, first);
   const int nT = p.nchunks * p.taps;
   const long per_blk = (long)nT * p.bct * 64;
   const long total = (long)((p.Cn + BC - 1) / BC) * per_blk;
@@ -464,12 +461,10 @@ __device__ __forceinline__ void c3b_pack_body(const PackK& p, long first, long s
         else                    v = p.w[(long)(p.cbase[chunk] + kk) * p.ldw + (long)(p.taps - 1 - tap) * p.cin_total + p.w_choff + row];
       }
       if (flip) v = -v;
-      if (AMAX) { amax = fmaxf(amax, fabsf(v)); continue; }
       vv[j] = v * wsc;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { b[k][j] = bf16_hi(v); v = v - bf16_f(b[k][j]); }
     }
-    if (AMAX) continue;
     uint4* o = out + (((long)blk * nT + T) * p.bct + i) * NP * 64 + lane;
     if (NP == 2) { split8h(vv, o[0], o[64]); continue; }
     for (int k = 0; k < NP; ++k)
@@ -735,6 +730,7 @@ static int c3_fwd(const addk_conv_args* a, int rows, void* stream, PackK* desc_o
   }
   pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = 0; pk.out = a->wpack;
   pk.amax = c3_planes(a->Cout, pk.taps) == 2 ? a->wpack + (need - C3_TRAILER) : nullptr; k.wsc = pk.amax ? pk.amax + C3_AMAX_WG : nullptr;
+  pk.wrows = a->Cout;
   k.N = a->N; k.H = a->OH; k.W = a->OW; k.IH = a->H; k.IW = a->W; k.dil = a->dil; k.st = a->stride;
   k.om = 1; k.oro = k.oco = 0; k.OHo = a->OH; k.OWo = a->OW;
   k.Cn = a->Cout; k.ldy = a->ldy; k.y = a->y; k.bias = a->bias; k.bias_n = a->bias_n;
@@ -760,6 +756,7 @@ static int c3_dgrad(const addk_conv_dgrad_args* a, int rows, void* stream, PackK
   }
   pk.nchunks = nch; pk.taps = a->KH * a->KW; pk.w = a->w; pk.ldw = a->ldw; pk.cin_total = a->cin_total; pk.w_choff = a->w_choff; pk.out = a->wpack;
   pk.amax = c3_planes(a->dst.C, pk.taps) == 2 ? a->wpack + (need - C3_TRAILER) : nullptr; k.wsc = pk.amax ? pk.amax + C3_AMAX_WG : nullptr;
+  pk.wrows = a->Cout;
   k.N = a->N; k.H = a->H; k.W = a->W; k.IH = a->OH; k.IW = a->OW; k.dil = a->dil; k.st = a->stride;      // the gather runs over dy (OH x OW)
   k.om = 1; k.oro = k.oco = 0; k.OHo = a->H; k.OWo = a->W;
   k.Cn = a->dst.C; k.ldy = a->ldg; k.y = a->g; k.bias = nullptr; k.bias_n = nullptr;
