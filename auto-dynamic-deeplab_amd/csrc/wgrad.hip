@@ -1507,8 +1507,15 @@ __device__ __forceinline__ RsFrag<LAY> rs_load(const float* base, int li, bool o
 // channel (relative to the tile origin) held by component e, row/column index R of the MFMA tile
 template <int LAY> __device__ __forceinline__ int rs_chan(int e, int R) { return LAY == 4 ? 4 * R + e : (e < 2 ? 2 * R + e : 32 + R); }
 
-template <int LA, int LB, bool BATCH>
+// [r5] F16 = the split-fp16 arithmetic (common.h) in the same register-streaming form: a batch of RS_U = 4 k-steps (16 pixels per wave) becomes ONE k-step of
+// v_mfma_f32_16x16x16_f16 — the lane that loaded pixel 4 u + kq in k-step u supplies it as k-slot 4 kq + u of both operands (any bijection of the contraction
+// index serves as long as the two operands agree) — so the loads are exactly the fp32 form's and 36 fp32 matrix instructions (1152 pipe cycles per 16 pixels)
+// become 27 fp16 ones (432).  Every WAVE keeps its own running scales for dy and for the activation (it owns its accumulators until the fixed-order combine at
+// the end): per batch the wave's largest magnitudes by four DPP steps and readlanes, the accumulators rescaled when a scale drops, unscaled before the combine.
+typedef _Float16 wg_f16x4 __attribute__((ext_vector_type(4)));
+template <int LA, int LB, bool BATCH, bool F16 = false>
 __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const WgK* __restrict__ ops, const int4* __restrict__ work) {
+  static_assert(!F16 || RS_U == 4, "one fp16 k-step = four pixel quads");
   int op = 0, blk_x = blockIdx.x, blk_y = blockIdx.y;
   if (BATCH) {
     const int4 wk = work[blockIdx.x];
@@ -1582,6 +1589,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
       }
       return f;
     };
+    WgScale fsc = {0, 0};
     for (int s0 = s_beg; s0 < s_end; s0 += RS_U) {
       RsFrag<LA> dy4[RS_U]; RsFrag<LB> z4v[RS_U];
       bool zv[RS_U];
@@ -1602,6 +1610,57 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
         zv[u] = okz;
         pp += 4;
       }
+      if constexpr (F16) {
+        float my = 0.f, mz = 0.f;
+#pragma unroll
+        for (int u = 0; u < RS_U; ++u) {
+          const bool ok = zv[u];
+#pragma unroll
+          for (int f = 0; f < LB; ++f) {
+            float x = fmaf(za.v[f], z4v[u].v[f], zb.v[f]);
+            if (zrelu) x = fmaxf(x, 0.f);
+            x = ok ? x : 0.f;
+            z4v[u].v[f] = x;
+            mz = fmaxf(mz, fabsf(x));
+          }
+#pragma unroll
+          for (int e = 0; e < LA; ++e) my = fmaxf(my, fabsf(dy4[u].v[e]));
+        }
+        const int wy = f16_scale_field(wave_umax(__float_as_uint(my))), wz = f16_scale_field(wave_umax(__float_as_uint(mz)));
+        int sh = 0;
+        if (fsc.kfy == 0) fsc.kfy = wy; else if (wy < fsc.kfy) { sh += wy - fsc.kfy; fsc.kfy = wy; }
+        if (fsc.kfz == 0) fsc.kfz = wz; else if (wz < fsc.kfz) { sh += wz - fsc.kfz; fsc.kfz = wz; }
+        if (sh != 0) {                          // (wave-uniform) a larger batch: the sums move to the coarser scale, exactly
+          const int rf = 127 + sh;
+          const float r = rf > 0 ? wg_pow2(rf) : 0.f;
+#pragma unroll
+          for (int e = 0; e < LA; ++e)
+#pragma unroll
+            for (int f = 0; f < LB; ++f) acc[e][f] *= r;
+        }
+        const float sy = wg_pow2(fsc.kfy), sz = wg_pow2(fsc.kfz);
+        wg_f16x4 yh[LA], yl[LA], zh[LB], zl[LB];
+#pragma unroll
+        for (int e = 0; e < LA; ++e) {
+          uint2 pl[2];
+          split4h(make_float4(dy4[0].v[e] * sy, dy4[1].v[e] * sy, dy4[2].v[e] * sy, dy4[3].v[e] * sy), pl);
+          yh[e] = __builtin_bit_cast(wg_f16x4, pl[0]); yl[e] = __builtin_bit_cast(wg_f16x4, pl[1]);
+        }
+#pragma unroll
+        for (int f = 0; f < LB; ++f) {
+          uint2 pl[2];
+          split4h(make_float4(z4v[0].v[f] * sz, z4v[1].v[f] * sz, z4v[2].v[f] * sz, z4v[3].v[f] * sz), pl);
+          zh[f] = __builtin_bit_cast(wg_f16x4, pl[0]); zl[f] = __builtin_bit_cast(wg_f16x4, pl[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < LA; ++e)
+#pragma unroll
+          for (int f = 0; f < LB; ++f) {
+            acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x16f16(yl[e], zh[f], acc[e][f], 0, 0, 0);
+            acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x16f16(yh[e], zl[f], acc[e][f], 0, 0, 0);
+            acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x16f16(yh[e], zh[f], acc[e][f], 0, 0, 0);
+          }
+      } else {
 #pragma unroll
       for (int u = 0; u < RS_U; ++u) {
         RsFrag<LB> v = z4v[u];
@@ -1618,6 +1677,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_rs_kernel(const WgK pv, const Wg
           for (int f = 0; f < LB; ++f)
             acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy4[u].v[e], v.v[f], acc[e][f], 0, 0, 0);
       }
+      }
+    }
+    if (F16) {                                  // this wave's two scales leave its sums
+      const float iy = wg_pow2(254 - fsc.kfy), iz = wg_pow2(254 - fsc.kfz);
+#pragma unroll
+      for (int e = 0; e < LA; ++e)
+#pragma unroll
+        for (int f = 0; f < LB; ++f) acc[e][f] = acc[e][f] * iy * iz;
     }
   }
   // combine the four waves in a fixed order; acc[e][f][r] = dW[co0 + chanA(e, 4*kq + r)][c0 + chanB(f, li)]
@@ -2083,9 +2150,12 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     else hipLaunchKernelGGL((wgrad_st_kernel<false>), grid, dim3(256), 0, st, k, ops, work);
     done = true;
   }
+  const bool rs_f16 = addk_get_conv_precision() == 1 && addk_env("ADDK_WGRAD_RS_F16", 1) != 0;      // f16x3: the narrow cell convs' weight gradients on the fp16 matrix pipe too
 #define ADDK_RS(A_, B_) \
   if (kind == 6 && cty == A_ && ctz == B_) { \
-    if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true>), grid, dim3(256), 0, st, k, ops, work); \
+    if (rs_f16) { if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true, true>), grid, dim3(256), 0, st, k, ops, work); \
+                  else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false, true>), grid, dim3(256), 0, st, k, ops, work); } \
+    else if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true>), grid, dim3(256), 0, st, k, ops, work); \
     else hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, false>), grid, dim3(256), 0, st, k, ops, work); \
     done = true; }
   ADDK_RS(3, 3) ADDK_RS(3, 4) ADDK_RS(4, 3) ADDK_RS(4, 4)

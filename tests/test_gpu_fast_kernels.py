@@ -343,17 +343,20 @@ def test_logits_upsample_backward_tiled_matches_autograd(lib, N, H, W, OH, OW, C
     ('pw40', 2, 63, 127, 40, 40, 1, 1, 1), ('pw80', 1, 64, 128, 80, 80, 1, 1, 1), ('glue200', 1, 50, 90, 200, 40, 1, 1, 1),
     ('reduce_s2', 2, 128, 96, 80, 40, 1, 2, 1), ('dense3_s2', 2, 97, 129, 48, 96, 3, 2, 1), ('pw160', 2, 32, 64, 160, 160, 1, 1, 1),
     ('stem0_like', 2, 256, 511, 3, 64, 3, 2, 1)])           # 3 input channels (ADD.py:153-157): all 27 (tap, channel) columns in one workgroup (wgrad_st_kernel), odd width
-def test_register_streaming_wgrad_matches_fp64_reference(lib, name, N, H, W, Ci, Cout, k, s, d):
+@pytest.mark.parametrize('prec,dys', [('bf16x6', 1.0), ('f16x3', 1.0), ('f16x3', 1e-9)], ids=['fp32_mfma', 'f16x3', 'f16x3_tiny_dy'])
+def test_register_streaming_wgrad_matches_fp64_reference(lib, name, N, H, W, Ci, Cout, k, s, d, prec, dys):
     """Weight gradients of the narrow cell convolutions (1x1, strided, multi-tile) on wgrad_rs_kernel, and of stem0 on its few-input-channel
-    sibling wgrad_st_kernel, vs autograd in fp64."""
+    sibling wgrad_st_kernel, vs autograd in fp64: the fp32-MFMA form (every mode but f16x3) and the split-fp16 form with per-wave running scales
+    (f16x3; also with gradients of 1e-9, far below fp16's range)."""
     L = lib
     l = L.load()
+    L.check(l.addk_set_conv_precision(PREC[prec]), 'set_conv_precision')
     dev = torch.device('cuda:0')
     gen = torch.Generator(device='cpu').manual_seed(sum(map(ord, name)))
     rnd = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
     pad = d * (k // 2)
     OH, OW = (H + 2 * pad - d * (k - 1) - 1) // s + 1, (W + 2 * pad - d * (k - 1) - 1) // s + 1
-    x, a, b, dy = rnd(N * H * W, Ci), rnd(Ci), 0.3 * rnd(Ci), rnd(N * OH * OW, Cout)
+    x, a, b, dy = rnd(N * H * W, Ci), rnd(Ci), 0.3 * rnd(Ci), dys * rnd(N * OH * OW, Cout)
     xr = x.double().view(N, H, W, Ci).permute(0, 3, 1, 2)
     z = F.relu(a.double().view(1, -1, 1, 1) * xr + b.double().view(1, -1, 1, 1))
     w = torch.zeros(Cout, Ci, k, k, device=dev, dtype=torch.float64, requires_grad=True)
