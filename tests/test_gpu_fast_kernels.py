@@ -203,6 +203,7 @@ RANGE_CASES = [
     ('falling_src',    (1e4, 1e-6),          0.1,          1e-3,      0),
     ('zero_first',     (0.0, 1.0),           30.0,         1e-6,      0),        # an all-zero first chunk (scale 2^126), then ordinary values
     ('octaves',        (1.0, 1.0),           0.1,          1e-4,      12),       # magnitudes spread over 24 octaves inside every tensor
+    ('all_zero',       (0.0, 0.0),           0.0,          0.0,       0),        # zero operands: scales 2^126, results exactly zero (no NaN from the inverse scales)
 ]
 
 
@@ -231,6 +232,8 @@ def test_split_fp16_holds_fp32_accuracy_over_the_whole_fp32_range(lib, shape, ca
         if xs[i] != 0.0:
             errs['g%d' % i] = _rel(got['g'][i], ref['g'][i])
     assert all(torch.isfinite(v).all() for v in [got['y'], got['dw']] + got['g']), 'non-finite output'
+    if cname == 'all_zero':
+        assert not got['y'].any() and not got['dw'].any() and not any(g.any() for g in got['g'])
     bad = ['%s %.2e' % kv for kv in errs.items() if not kv[1] <= TOL]
     import os
     os.makedirs('gpurun_out', exist_ok=True)
