@@ -73,7 +73,8 @@ __device__ __forceinline__ float bf16_f(unsigned b) { return __uint_as_float(b <
 //     RUNNING scale 2^k — the scale of the largest chunk seen so far in this tile; when a chunk arrives that would overflow it, the accumulators
 //     are multiplied by the (exact) ratio and the scale drops.  Elements more than 2^17 below the running maximum lose low-part bits gradually
 //     (absolute error <= max * 2^-40): they cannot matter to a sum that contains the maximum.  No tensor-wide pass, no producer-side bookkeeping.
-//   The epilogue multiplies by 2^-k 2^-kw.  Inf / NaN inputs give Inf / NaN outputs as in fp32.
+//   The epilogue multiplies by 2^-k 2^-kw.  A NaN element stays out of the maxima (v_max drops it) and makes the outputs it touches NaN, as in fp32; an Inf element
+//   enters them: the outputs it touches become NaN and the finite elements staged under that scale flush to zero — a non-finite loss either way.
 // ======================================================================================================================
 // 4 floats -> 4 bf16 per plane (8 bytes each); NP = 2: the two fp16 planes
 template <int NP>
