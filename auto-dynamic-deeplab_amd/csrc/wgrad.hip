@@ -1962,7 +1962,7 @@ inline bool h3b_runs(int cty) { return wg_np_of(cty) && wgrad_split_enabled() &&
 // input-channel tiles per workgroup of the 3x3 halo-patch kernel: 2 (512 threads sharing one staged dy tile) on the split-bf16 kernel when the channels fill
 // whole pairs of tiles (a half-empty pair costs what the shared dy saves: 304 and 400 channels measured equal, 256 -7 %, stem1's 64 -> 64 -14 %)
 inline int h3_ng(int Cout, int C) {
-  if (addk_env("ADDK_H3_NG", 2) < 2) return 1;      // (A/B: with the split-fp16 arithmetic the shared dy tile still wins, 2.2 vs 2.38 ms per step)
+  // (re-measured with the split-fp16 arithmetic: the shared dy tile still wins, 2.2 vs 2.38 ms per step: profiles/r05_wgrad_h3b_f16_pipelined.txt)
   return (C % 32 == 0 && h3b_runs(Cout % 128 == 0 ? 8 : 4)) ? 2 : 1;
 }
 inline int h3_tiles(int Cout, int C) { const int nt = Cout % 128 == 0 ? 2 : 1; return (Cout / (64 * nt)) * cdiv(C, 16); }
@@ -2151,7 +2151,7 @@ static int wg_launch(int kind, int cty, int ctz, dim3 grid, hipStream_t st, cons
     else hipLaunchKernelGGL((wgrad_st_kernel<false>), grid, dim3(256), 0, st, k, ops, work);
     done = true;
   }
-  const bool rs_f16 = addk_get_conv_precision() == 1 && addk_env("ADDK_WGRAD_RS_F16", 1) != 0;      // f16x3: the narrow cell convs' weight gradients on the fp16 matrix pipe too
+  const bool rs_f16 = addk_get_conv_precision() == 1;      // f16x3: the narrow cell convs' weight gradients on the fp16 matrix pipe too (ABAB: step 29.57 -> 29.2 ms)
 #define ADDK_RS(A_, B_) \
   if (kind == 6 && cty == A_ && ctz == B_) { \
     if (rs_f16) { if (ops) hipLaunchKernelGGL((wgrad_rs_kernel<A_, B_, true, true>), grid, dim3(256), 0, st, k, ops, work); \
