@@ -5,7 +5,7 @@
    decoder) against an fp64 evaluation of the oracle — the backward check at the headline shape without train-mode amplification;
  * mIoU parity on fixed weights (north_star: "mIoU within 0.05"; utils/metrics.py:18-23, eval.py:183-193,218-224): addk and oracle
    predictions through `Evaluator`, config 2 static (both exits) and config 4 dynamic at 0 / 50 / 100 % early exits;
- * the O1-like fast arithmetic `bf16x3` at network level (F=40 genotype_1: eval logits, frozen-BN gradients, one train step);
+ * the O1-like arithmetic `f16x3` at network level (F=40 genotype_1: eval logits, frozen-BN gradients, one train step);
  * config 5's architecture (F=40) at 2x1024x2048: eval logits and first-step training loss against the CPU oracle."""
 import ctypes as C
 import os
@@ -227,15 +227,15 @@ def test_miou_parity_static_and_dynamic(dev):
     assert True
 
 
-def test_bf16x3_whole_network_parity(dev):
-    """The 3-term split-bf16 mode (`bf16x3`: the O1 analogue of train.py:145-165 — 16-bit products on the matrix pipe, fp32
-    accumulation and BatchNorm statistics, fp32 master weights) at NETWORK level on config 5's architecture: eval logits within
-    1e-3 of the oracle, frozen-BN conv-weight gradients at 2x256x512 median within 10x the fp32 oracle's own error against fp64 (p90 <= 1e-2, max <= 5e-2), one
-    train-mode step's loss within 1e-4 of the oracle's."""
+def test_f16x3_whole_network_parity(dev):
+    """The split-fp16 mode (`f16x3`, the default since round 5: the analogue of train.py:145-165's apex O1 — 16-bit products on the matrix pipe, fp32
+    accumulation and BatchNorm statistics, fp32 master weights — at fp32-class accuracy) set EXPLICITLY at NETWORK level on config 5's architecture: eval
+    logits within 1e-3 of the oracle, frozen-BN conv-weight gradients at 2x256x512 within 3x (median) / 4x (p90) / 6x (max) the fp32 oracle's own error against
+    the reference's fp64 gradients (the three-term split-bf16 form this mode replaced needed 10x / 1e-2 / 5e-2), one train-mode step's loss within 1e-4."""
     import addk
     prev = addk.get_precision()
     try:
-        addk.set_precision('bf16x3')
+        addk.set_precision('f16x3')
         hw = (256, 512)
         ma, mo, chk, args = _build(dev, 40, ARCH_C2, _geno('genotype_1'), seed=900)
         x = rand_tensor(61, 'f40_frozen_x', (2, 3) + hw)
@@ -245,7 +245,7 @@ def test_bf16x3_whole_network_parity(dev):
         ya, yo = ma(x.to(dev)), mo(x)
         for i, (a, o) in enumerate(zip(ya, yo)):
             e = rel_err(a, o)
-            _log('bf16x3 F40_g1 256x512 eval exit %d vs oracle %.3e', i, e)
+            _log('f16x3 F40_g1 256x512 eval exit %d vs oracle %.3e', i, e)
             assert e <= 1e-3
         (sum(crit(y, tgt.to(dev)) for y in ya) / 2).backward()
         (sum(crit(y, tgt) for y in yo) / 2).backward()
@@ -261,20 +261,19 @@ def test_bf16x3_whole_network_parity(dev):
                 theirs.append(fx.rel_err(k, p.grad))
         med = lambda v: sorted(v)[len(v) // 2]
         p90 = lambda v: sorted(v)[int(len(v) * 0.9)]
-        _log('bf16x3 F40_g1 frozen-BN 256x512, %d conv-weight gradients vs fp64: addk max %.2e p90 %.2e median %.2e | fp32 oracle max %.2e p90 %.2e median %.2e',
+        _log('f16x3 F40_g1 frozen-BN 256x512, %d conv-weight gradients vs fp64: addk max %.2e p90 %.2e median %.2e | fp32 oracle max %.2e p90 %.2e median %.2e',
              len(ours), max(ours), p90(ours), med(ours), max(theirs), p90(theirs), med(theirs))
-        # the 3-term mode carries ~8x fp32's per-product error (5e-7 rms per dot product, test_gpu_fast_kernels.py: 2e-4 against 2e-5) in EVERY
-        # k x k convolution, stem2 included since it runs on the split kernel: median within 10x the fp32 oracle's own; the upper tail is the
-        # unstable statistic of this network (one ulp on the oracle's input moves ITS maximum x3 and its p90 x1.9:
-        # profiles/r03_f40_frozen_bn_sensitivity_probe.txt) — p90 <= 1e-2, max <= 5e-2 (measured 6.9e-3 / 2.4e-2; 1.9e-3 / 6.8e-3 with stem2 on fp32)
-        assert med(ours) <= max(10 * med(theirs), 5e-4) and p90(ours) <= max(10 * p90(theirs), 1e-2) and max(ours) <= max(20 * max(theirs), 5e-2)
+        # measured: median 1.59e-4 / p90 6.5e-4 / max 3.3e-3 against the oracle's 7.3e-5 / 2.4e-4 / 1.2e-3 (ratios 2.2 / 2.7 / 2.7; bf16x6: 1.9 / 2.6 / 1.7); the upper
+        # tail is the unstable statistic of this network (one ulp on the oracle's input moves ITS maximum x3 and its p90 x1.9:
+        # profiles/r03_f40_frozen_bn_sensitivity_probe.txt)
+        assert med(ours) <= 3 * med(theirs) and p90(ours) <= 4 * p90(theirs) and max(ours) <= 6 * max(theirs)
         # one train-mode step (fresh parameters: the gradient buffers above belong to the eval plan)
         ma2, mo2, _, _ = _build(dev, 40, ARCH_C2, _geno('genotype_1'), seed=901)
         ma2.train(); mo2.train()
         with torch.no_grad():
             la = sum(crit(y, tgt.to(dev)) for y in ma2(x.to(dev))) / 2
             lo = sum(crit(y, tgt) for y in mo2(x)) / 2
-        _log('bf16x3 F40_g1 256x512 train-mode loss: addk %.7f  oracle %.7f', float(la), float(lo))
+        _log('f16x3 F40_g1 256x512 train-mode loss: addk %.7f  oracle %.7f', float(la), float(lo))
         assert abs(float(la) - float(lo)) <= 1e-4 * abs(float(lo))
     finally:
         addk.set_precision(prev)
