@@ -43,8 +43,9 @@ struct C3K {
 //     x*w  ~=  l*wh + h*wl + m*wm + m*wh + h*wm + h*wh          (dropped: m*wl, l*wm, l*wl  ~ 2^-26 relative)
 // Measured (scripts/bf16_split_probe.hip, K = 2048, random magnitudes over 6 octaves): max |err| / sum|a*b| = 3.0e-7, rms 5.6e-8 —
 // the same as the exact-fp32 v_mfma_f32_16x16x4_f32 chain (3.2e-7 / 6.8e-8) — at 6 x 16 = 96 matrix-pipe cycles per
-// 16x16x32 block of fp32 work instead of 256: 2.5x the fp32 MFMA rate (374 vs 149 TFLOP/s from registers).  The 3-term form
-// (h*wh + m*wh + h*wm, planes = 2) is the opt-in fast mode: 656 TFLOP/s, rms error 4.7e-7.
+// 16x16x32 block of fp32 work instead of 256: 2.5x the fp32 MFMA rate (374 vs 149 TFLOP/s from registers).  This is NP = 3 (--math bf16x6);
+// NP = 2 is the split-FP16 form (two fp16 terms under exact power-of-two scales, three product terms: common.h, the default since round 5) — it took the
+// place of the three-term split-bf16 form (h*wh + m*wh + h*wm: rms error 4.7e-7), whose speed it has at the six-term form's accuracy.
 //
 // Structure.  A block owns 128 pixels of one output row x (32 * WC) output channels; WAVE w owns channels [32w, 32w+32) of ALL
 // 128 pixels (four 32x32 accumulator tiles): the pixel fragments are shared through LDS (which has the bandwidth: 128 B/clk
